@@ -1,0 +1,161 @@
+/*
+ * bh.h — C-ABI of the MI355X-native Barnes-Hut engine (libbh.so).
+ *
+ * Drop-in boundary for the headless per-step path of the reference
+ * (bgcarmin/NBody-Barnes-Hut-CUDA, file `nbody_v5_bench.cu`; all "ref:" citations
+ * below are lines of that file).  The reference has no FFI/plugin interface: its
+ * boundary is a set of file-scope device pointers (ref:31-40), compile-time
+ * constants (ref:13-18) and `void simulationStep()` (ref:255-283) driven by
+ * `main()` (ref:285-390).  This header replaces that with one opaque context per
+ * GPU plus one entry point per reference stage, plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every call returns BH_OK (0) or a negative bh_status; nothing throws or aborts;
+ *   - host buffers are caller-owned SoA arrays of n floats (any alignment);
+ *   - device buffers are owned by the context; a context is bound to one HIP device
+ *     and one stream; calls on one context are not thread-safe;
+ *   - stage calls and bh_step are asynchronous on the context's stream;
+ *     bh_download*, bh_get_stats and bh_sync synchronise;
+ *   - the library never falls back to a CPU path: with no usable GPU bh_create fails.
+ */
+#ifndef BH_H_
+#define BH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_ABI_VERSION 1
+
+typedef struct bh_ctx bh_ctx; /* opaque; replaces the globals ref:31-40 */
+
+typedef enum bh_status {
+  BH_OK = 0,
+  BH_ERR_BAD_ARG = -1,      /* null pointer, n < 1, bad parameter value            */
+  BH_ERR_NO_DEVICE = -2,    /* no HIP device / device index out of range           */
+  BH_ERR_HIP = -3,          /* a HIP runtime call failed (see bh_last_hip_error)   */
+  BH_ERR_OOM = -4,          /* device or host allocation failed                    */
+  BH_ERR_POOL_OVERFLOW = -5,/* octree record pool exhausted (cannot happen with
+                               the 2n+8 pool; checked anyway, cf. ref:321 D8)     */
+  BH_ERR_ORDER = -6,        /* stage called before the stage it depends on         */
+  BH_ERR_SMALL_BUFFER = -7  /* caller buffer too small for a download              */
+} bh_status;
+
+/* Physical and structural parameters.  Defaults = the reference's #defines. */
+typedef struct bh_params {
+  float G;          /* G_CONST   0.5   ref:14 */
+  float theta;      /* THETA     0.5   ref:15 */
+  float dt;         /* DT        0.02  ref:16 */
+  float eps2;       /* SOFTENING 50.0  ref:17 — added to r^2 (ref:207); must be > 0 */
+  float max_speed;  /* MAX_SPEED 500.0 ref:18 */
+  int32_t leaf_cap;   /* bodies per leaf before a cell is split; 1 = reference intent (ref:100-124) */
+  int32_t max_depth;  /* deepest cell level; <= key_bits/3 (reference loop bound 25, ref:93) */
+  int32_t key_bits;   /* 63 (21 bits/axis, default) or 30 (10 bits/axis: bit-exact
+                         reference Morton code, ref:42-63)                         */
+  int32_t strict_fp;  /* 0: fast force kernel (fma + v_rsq_f32);
+                         1: force arithmetic exactly as the reference source text
+                            in IEEE fp32 (sqrtf, '/', no contraction; ref:203-213) */
+  int32_t reserved[7];
+} bh_params;
+
+/* One 32-byte octree record ("entry").  The tree is an array of entries:
+ * entry 0 is the root; the children of an internal entry are the `count`
+ * consecutive entries starting at `first` (ascending octant digit, empty
+ * octants omitted).  Replaces `struct OctreeNode` (ref:20-28, 76 B). */
+#define BH_KIND_BODY 0     /* exactly one body: (x,y,z,m) is the body, s = 0, first = sorted body index */
+#define BH_KIND_INTERNAL 1 /* subdivided cell: first/count = child block                               */
+#define BH_KIND_MULTI 2    /* unsplit cell holding `count` > 1 bodies [first, first+count) of the
+                              Morton-sorted body array (depth-capped or leaf_cap > 1)                  */
+typedef struct bh_node {
+  float x, y, z;  /* centre of mass (ref:22 comX..Z after finalizeCOM ref:175-189) */
+  float m;        /* total mass (ref:21)                                           */
+  float s;        /* cell edge length used by the MAC (ref:208 maxX-minX); 0 for a body */
+  int32_t first;
+  int32_t count;
+  int32_t kind;
+} bh_node;
+
+typedef struct bh_stats {
+  int32_t n;               /* bodies                                               */
+  int32_t n_internal;      /* subdivided cells ( = reference nodeCounter intent, ref:109) */
+  int32_t n_entries;       /* tree records in use (root + all children)            */
+  int32_t max_level;       /* deepest internal level + 1                           */
+  int32_t status_flags;    /* device-side sticky error bits (BH_FLAG_*)            */
+  int32_t steps;           /* bh_step calls since upload                           */
+  /* per-stage device time of the most recent timed step, milliseconds (hipEvent);
+     zero unless bh_set_timing(ctx,1).  Order = ref:259-282. */
+  float ms_bbox, ms_morton, ms_sort, ms_build, ms_com, ms_force, ms_integrate, ms_step;
+  /* interaction counters of the most recent bh_force_count call (whole system):
+     V = cell MAC evaluations, O = opened cells, P = body-body interactions.
+     SURVEY §8(d): B_alg = 24 V + 32 O + 16 P + 24 n bytes. */
+  uint64_t count_V, count_O, count_P;
+  int32_t reserved[8];
+} bh_stats;
+
+#define BH_FLAG_POOL_OVERFLOW 1
+#define BH_FLAG_STACK_OVERFLOW 2
+
+/* ---- lifecycle ( <-> cudaMalloc block ref:311-326, cudaFree ref:372-387 ) ---- */
+int bh_abi_version(void);
+int bh_default_params(bh_params* p);
+int bh_create(bh_ctx** out, int n, const bh_params* p, int device);
+/* same, but run on a caller-owned hipStream_t (e.g. torch's current stream) */
+int bh_create_on_stream(bh_ctx** out, int n, const bh_params* p, int device, void* hip_stream);
+void bh_destroy(bh_ctx* c);
+const char* bh_strerror(int status);
+int bh_last_hip_error(const bh_ctx* c); /* raw hipError_t of the last BH_ERR_HIP */
+
+/* ---- data in ( <-> 7x cudaMemcpy H2D ref:329-335 ) ---- */
+int bh_upload(bh_ctx* c, const float* x, const float* y, const float* z,
+              const float* vx, const float* vy, const float* vz, const float* m);
+
+/* ---- the step ( <-> simulationStep ref:255-283 ) and its stages, reference order ---- */
+int bh_step(bh_ctx* c);
+int bh_bbox(bh_ctx* c);      /* computeBoundingBoxKernel ref:134-156 / launch ref:259          */
+int bh_morton(bh_ctx* c);    /* computeMortonCodesKernel ref:51-63  / launch ref:260          */
+int bh_sort(bh_ctx* c);      /* thrust::sort_by_key ref:262-264 (+ physical gather) */
+int bh_build(bh_ctx* c);     /* memset+initRoot+insertParticles ref:266-275                    */
+int bh_com(bh_ctx* c);       /* computeCOM+finalizeCOM ref:279-280                             */
+int bh_force(bh_ctx* c);     /* computeForceKernel ref:281                                     */
+int bh_integrate(bh_ctx* c); /* integrateKernel ref:282                                        */
+
+/* force for the Morton-sorted bodies [lo,hi) only (multi-rank sharding) */
+int bh_force_range(bh_ctx* c, int lo, int hi);
+/* same traversal with per-body V/O/P counters; totals land in bh_stats */
+int bh_force_count(bh_ctx* c);
+
+/* ---- data out ---- */
+/* caller (upload) order; any pointer may be NULL */
+int bh_download(bh_ctx* c, float* x, float* y, float* z, float* vx, float* vy, float* vz);
+int bh_download_acc(bh_ctx* c, float* ax, float* ay, float* az);        /* caller order      */
+int bh_download_bounds(bh_ctx* c, float bounds[6]);                      /* ref:150-155 layout */
+int bh_download_keys(bh_ctx* c, uint64_t* keys);   /* current (sorted after bh_sort) order      */
+int bh_download_order(bh_ctx* c, int32_t* ids);    /* caller index of the body at each sorted slot */
+int bh_download_sorted_bodies(bh_ctx* c, float* xyzm /* 4n floats */);
+int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries);
+int bh_download_counters(bh_ctx* c, uint32_t* V, uint32_t* O, uint32_t* P); /* caller order */
+int bh_get_stats(bh_ctx* c, bh_stats* s);
+int bh_set_timing(bh_ctx* c, int on);
+int bh_sync(bh_ctx* c);
+
+/* ---- multi-rank plumbing: raw device views (valid until bh_destroy) ---- */
+/* acc is float4[n] (ax,ay,az,unused) in Morton-sorted order; an all-gather of the
+   per-rank [lo,hi) slabs straight into this buffer completes the exchange step. */
+int bh_device_acc(bh_ctx* c, void** dptr, int64_t* bytes);
+int bh_n(const bh_ctx* c);
+
+/* ---- synthetic initial conditions (host side; <-> IC loop ref:294-308) ---- */
+/* Plummer sphere, scale radius a, masses U[2,7) (same law as ref:302), counter-based
+   splitmix64 RNG keyed on (seed, body index): SURVEY §8(d). */
+int bh_ic_plummer(int n, uint64_t seed, float a, float G,
+                  float* x, float* y, float* z, float* vx, float* vy, float* vz, float* m);
+/* the reference's rotating thin disc (ref:297-307) with the same RNG */
+int bh_ic_disc(int n, uint64_t seed, float G,
+               float* x, float* y, float* z, float* vx, float* vy, float* vz, float* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BH_H_ */

@@ -1,0 +1,14 @@
+"""MI355X-native Barnes-Hut engine — Python host side.
+
+Thin mirror of the reference's host interface for the headless per-step path
+(bgcarmin/NBody-Barnes-Hut-CUDA, nbody_v5_bench.cu): `Engine.upload` <-> the H2D block
+:329-335, `Engine.step` (alias `simulationStep`) <-> simulationStep :255-283, one method
+per stage in the reference's order, `Engine.download` <-> the (absent) result read-back.
+All compute runs in libbh.so (hand-written HIP for gfx950); nothing here computes.
+"""
+from ._lib import lib, BhParams, BhNode, BhStats, LIB_PATH  # noqa: F401
+from .engine import Engine, BhError, default_params, KIND_BODY, KIND_INTERNAL, KIND_MULTI  # noqa: F401
+from .ic import plummer, disc  # noqa: F401
+
+__all__ = ["Engine", "BhError", "default_params", "plummer", "disc", "BhParams", "BhNode",
+           "BhStats", "KIND_BODY", "KIND_INTERNAL", "KIND_MULTI", "LIB_PATH"]

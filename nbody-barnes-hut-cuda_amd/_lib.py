@@ -1,0 +1,98 @@
+"""ctypes loader for libbh.so (the C-ABI of include/bh.h).
+
+There is no fallback of any kind: if the HIP library is missing or fails to load,
+importing this module raises, and every compute entry point needs a HIP device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbh.so")
+
+
+class BhParams(C.Structure):
+    """struct bh_params (include/bh.h) — defaults are the reference's #defines
+    (nbody_v5_bench.cu:14-18)."""
+    _fields_ = [
+        ("G", C.c_float), ("theta", C.c_float), ("dt", C.c_float), ("eps2", C.c_float),
+        ("max_speed", C.c_float),
+        ("leaf_cap", C.c_int32), ("max_depth", C.c_int32), ("key_bits", C.c_int32),
+        ("strict_fp", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class BhNode(C.Structure):
+    """struct bh_node: one 32-byte octree record."""
+    _fields_ = [
+        ("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("m", C.c_float),
+        ("s", C.c_float), ("first", C.c_int32), ("count", C.c_int32), ("kind", C.c_int32),
+    ]
+
+
+class BhStats(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("n_internal", C.c_int32), ("n_entries", C.c_int32),
+        ("max_level", C.c_int32), ("status_flags", C.c_int32), ("steps", C.c_int32),
+        ("ms_bbox", C.c_float), ("ms_morton", C.c_float), ("ms_sort", C.c_float),
+        ("ms_build", C.c_float), ("ms_com", C.c_float), ("ms_force", C.c_float),
+        ("ms_integrate", C.c_float), ("ms_step", C.c_float),
+        ("count_V", C.c_uint64), ("count_O", C.c_uint64), ("count_P", C.c_uint64),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+# every symbol include/bh.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+SYMBOLS = [
+    ("bh_abi_version", C.c_int, []),
+    ("bh_default_params", C.c_int, [C.POINTER(BhParams)]),
+    ("bh_create", C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(BhParams), C.c_int]),
+    ("bh_create_on_stream", C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(BhParams), C.c_int, _P]),
+    ("bh_destroy", None, [_P]),
+    ("bh_strerror", C.c_char_p, [C.c_int]),
+    ("bh_last_hip_error", C.c_int, [_P]),
+    ("bh_upload", C.c_int, [_P] + [_F] * 7),
+    ("bh_step", C.c_int, [_P]),
+    ("bh_bbox", C.c_int, [_P]),
+    ("bh_morton", C.c_int, [_P]),
+    ("bh_sort", C.c_int, [_P]),
+    ("bh_build", C.c_int, [_P]),
+    ("bh_com", C.c_int, [_P]),
+    ("bh_force", C.c_int, [_P]),
+    ("bh_integrate", C.c_int, [_P]),
+    ("bh_force_range", C.c_int, [_P, C.c_int, C.c_int]),
+    ("bh_force_count", C.c_int, [_P]),
+    ("bh_download", C.c_int, [_P] + [_F] * 6),
+    ("bh_download_acc", C.c_int, [_P] + [_F] * 3),
+    ("bh_download_bounds", C.c_int, [_P, _F]),
+    ("bh_download_keys", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("bh_download_order", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("bh_download_sorted_bodies", C.c_int, [_P, _F]),
+    ("bh_download_tree", C.c_int, [_P, C.POINTER(BhNode), C.c_int, C.POINTER(C.c_int)]),
+    ("bh_download_counters", C.c_int, [_P] + [C.POINTER(C.c_uint32)] * 3),
+    ("bh_get_stats", C.c_int, [_P, C.POINTER(BhStats)]),
+    ("bh_set_timing", C.c_int, [_P, C.c_int]),
+    ("bh_sync", C.c_int, [_P]),
+    ("bh_device_acc", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    ("bh_n", C.c_int, [_P]),
+    ("bh_ic_plummer", C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_float] + [_F] * 7),
+    ("bh_ic_disc", C.c_int, [C.c_int, C.c_uint64, C.c_float] + [_F] * 7),
+]
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C nbody-barnes-hut-cuda_amd). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()

@@ -1,0 +1,474 @@
+// bh_api.hip — host side of the C-ABI declared in include/bh.h.
+//
+// Mirrors the reference's host code (nbody_v5_bench.cu): the cudaMalloc block :311-326
+// (bh_create), the seven H2D copies :329-335 (bh_upload), simulationStep :255-283 (bh_step and
+// one entry point per stage, same order) and the cudaFree block :372-387 (bh_destroy).
+// Differences by design: an opaque context instead of file-scope globals, error codes instead
+// of unchecked calls, no per-step host synchronisation (the reference blocks on a
+// 4-byte D2H of nodeCounter every step, :277-278), per-stage hipEvent timers.
+// There is NO CPU fallback anywhere in this library: without a HIP device bh_create fails.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "bh_internal.h"
+
+#define BH_HIP(c, call)                       \
+  do {                                        \
+    hipError_t _e = (call);                   \
+    if (_e != hipSuccess) {                   \
+      (c)->last_hip = (int)_e;                \
+      return BH_ERR_HIP;                      \
+    }                                         \
+  } while (0)
+
+static_assert(sizeof(bh_node) == 32, "bh_node must be 32 bytes");
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t count) {
+  return hipMalloc((void**)p, count * sizeof(T) + 256);
+}
+
+extern "C" {
+
+int bh_abi_version(void) { return BH_ABI_VERSION; }
+
+int bh_default_params(bh_params* p) {
+  if (!p) return BH_ERR_BAD_ARG;
+  memset(p, 0, sizeof(*p));
+  p->G = 0.5f;            // ref:14
+  p->theta = 0.5f;        // ref:15
+  p->dt = 0.02f;          // ref:16
+  p->eps2 = 50.0f;        // ref:17
+  p->max_speed = 500.0f;  // ref:18
+  p->leaf_cap = 1;
+  p->max_depth = 21;
+  p->key_bits = 63;
+  p->strict_fp = 0;
+  return BH_OK;
+}
+
+const char* bh_strerror(int s) {
+  switch (s) {
+    case BH_OK: return "ok";
+    case BH_ERR_BAD_ARG: return "bad argument";
+    case BH_ERR_NO_DEVICE: return "no usable HIP device";
+    case BH_ERR_HIP: return "HIP runtime error";
+    case BH_ERR_OOM: return "out of memory";
+    case BH_ERR_POOL_OVERFLOW: return "octree record pool overflow";
+    case BH_ERR_ORDER: return "stage called out of order";
+    case BH_ERR_SMALL_BUFFER: return "caller buffer too small";
+    default: return "unknown status";
+  }
+}
+
+int bh_last_hip_error(const bh_ctx* c) { return c ? c->last_hip : 0; }
+int bh_n(const bh_ctx* c) { return c ? c->n : 0; }
+
+static void free_all(bh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc, c->stage_buf,
+                  c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->bbox_partial,
+                  c->bounds, c->pa, c->pb, c->pn,
+                  c->cb, c->rec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
+                  c->cV, c->cO, c->cP};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (int i = 0; i < 8; i++)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, void* hip_stream) {
+  if (!out) return BH_ERR_BAD_ARG;
+  *out = nullptr;
+  bh_params p;
+  if (pin) p = *pin; else bh_default_params(&p);
+  if (n < 1 || n > (1 << 30) / 2) return BH_ERR_BAD_ARG;
+  if (p.key_bits != 63 && p.key_bits != 30) return BH_ERR_BAD_ARG;
+  if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0)
+    return BH_ERR_BAD_ARG;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BH_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return BH_ERR_NO_DEVICE;
+
+  bh_ctx* c = new (std::nothrow) bh_ctx();
+  if (!c) return BH_ERR_OOM;
+  memset((void*)c, 0, sizeof(*c));
+  c->n = n;
+  c->p = p;
+  c->B = p.key_bits / 3;
+  c->D = p.max_depth < c->B ? p.max_depth : c->B;
+  c->cap = p.leaf_cap;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete c;
+    return BH_ERR_NO_DEVICE;
+  }
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return BH_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+
+  const size_t N = (size_t)n;
+  c->rec_cap = 2 * n + 8;
+  c->sort_tiles = (n + BH_SORT_TILE - 1) / BH_SORT_TILE;
+  // scans run over n (+1) ints, 256*sort_tiles ints and n fp64 quadruples
+  size_t scan_n = N + 1;
+  if ((size_t)256 * c->sort_tiles > scan_n) scan_n = (size_t)256 * c->sort_tiles;
+  c->scan_tmp_bytes = bhk_scan_tmp_bytes((int)scan_n);
+
+  bool ok = true;
+  ok = ok && dalloc(&c->posm[0], N) == hipSuccess && dalloc(&c->posm[1], N) == hipSuccess;
+  ok = ok && dalloc(&c->velid[0], N) == hipSuccess && dalloc(&c->velid[1], N) == hipSuccess;
+  ok = ok && dalloc(&c->acc, N) == hipSuccess;
+  ok = ok && dalloc(&c->stage_buf, 7 * N) == hipSuccess;
+  ok = ok && dalloc(&c->keys[0], N) == hipSuccess && dalloc(&c->keys[1], N) == hipSuccess;
+  ok = ok && dalloc(&c->vals[0], N) == hipSuccess && dalloc(&c->vals[1], N) == hipSuccess;
+  ok = ok && dalloc(&c->hist, (size_t)256 * c->sort_tiles + 1) == hipSuccess;
+  ok = ok && dalloc(&c->bbox_partial, (size_t)BH_BBOX_BLOCKS * 6) == hipSuccess;
+  ok = ok && dalloc(&c->bounds, 8) == hipSuccess;
+  ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;
+  ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
+  ok = ok && dalloc(&c->cb, N + 1) == hipSuccess;
+  ok = ok && dalloc(&c->rec, (size_t)c->rec_cap) == hipSuccess;
+  ok = ok && dalloc(&c->er_lo, (size_t)c->rec_cap) == hipSuccess;
+  ok = ok && dalloc(&c->er_hi, (size_t)c->rec_cap) == hipSuccess;
+  ok = ok && dalloc(&c->P, N + 1) == hipSuccess;
+  ok = ok && dalloc(&c->info, 1) == hipSuccess;
+  ok = ok && hipMalloc(&c->scan_tmp, c->scan_tmp_bytes) == hipSuccess;
+  ok = ok && dalloc(&c->cV, N) == hipSuccess && dalloc(&c->cO, N) == hipSuccess &&
+       dalloc(&c->cP, N) == hipSuccess;
+  for (int i = 0; ok && i < 8; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+  if (!ok) {
+    free_all(c);
+    return BH_ERR_OOM;
+  }
+  // the record pool is read up to 3 records past a child block (force kernel): keep it defined
+  if (hipMemsetAsync(c->rec, 0, (size_t)c->rec_cap * sizeof(bh_node), c->stream) != hipSuccess ||
+      hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream) != hipSuccess ||
+      hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream) != hipSuccess) {
+    free_all(c);
+    return BH_ERR_HIP;
+  }
+  *out = c;
+  return BH_OK;
+}
+
+int bh_create(bh_ctx** out, int n, const bh_params* p, int device) {
+  return bh_create_on_stream(out, n, p, device, nullptr);
+}
+
+void bh_destroy(bh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_all(c);
+}
+
+int bh_sync(bh_ctx* c) {
+  if (!c) return BH_ERR_BAD_ARG;
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  return BH_OK;
+}
+
+int bh_set_timing(bh_ctx* c, int on) {
+  if (!c) return BH_ERR_BAD_ARG;
+  c->timing = on != 0;
+  c->timed_valid = false;
+  return BH_OK;
+}
+
+// ---- upload: ref:329-335 ----
+int bh_upload(bh_ctx* c, const float* x, const float* y, const float* z, const float* vx,
+              const float* vy, const float* vz, const float* m) {
+  if (!c || !x || !y || !z || !vx || !vy || !vz || !m) return BH_ERR_BAD_ARG;
+  BH_HIP(c, hipSetDevice(c->device));
+  const size_t N = (size_t)c->n, nb = N * sizeof(float);
+  const float* src[7] = {x, y, z, vx, vy, vz, m};
+  for (int k = 0; k < 7; k++)
+    BH_HIP(c, hipMemcpyAsync(c->stage_buf + k * N, src[k], nb, hipMemcpyHostToDevice, c->stream));
+  c->cur = 0;
+  BH_HIP(c, bhk_pack(c));
+  BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));
+  BH_HIP(c, hipStreamSynchronize(c->stream));  // host buffers may be reused on return
+  c->stage = BH_ST_UPLOADED;
+  c->ever = BH_ST_UPLOADED;
+  c->steps = 0;
+  return BH_OK;
+}
+
+// ---- stages ----
+#define BH_NEED(c, bit)                          \
+  do {                                           \
+    if (!(c)) return BH_ERR_BAD_ARG;             \
+    if (!((c)->stage & (bit))) return BH_ERR_ORDER; \
+  } while (0)
+// downloads accept data of a stage that has run at least once since upload
+#define BH_NEED_EVER(c, bit)                     \
+  do {                                           \
+    if (!(c)) return BH_ERR_BAD_ARG;             \
+    if (!((c)->ever & (bit))) return BH_ERR_ORDER; \
+  } while (0)
+
+int bh_bbox(bh_ctx* c) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  BH_HIP(c, bhk_bbox(c));
+  c->stage = BH_ST_UPLOADED | BH_ST_BBOX;
+  c->ever |= BH_ST_BBOX;
+  return BH_OK;
+}
+int bh_morton(bh_ctx* c) {
+  BH_NEED(c, BH_ST_BBOX);
+  BH_HIP(c, bhk_keys(c));
+  c->stage |= BH_ST_MORTON;
+  c->ever |= BH_ST_MORTON;
+  c->ever &= ~BH_ST_SORT;
+  c->key_buf = 0;
+  return BH_OK;
+}
+int bh_sort(bh_ctx* c) {
+  BH_NEED(c, BH_ST_MORTON);
+  if (c->stage & BH_ST_SORT) return BH_ERR_ORDER;  // sorting twice would permute twice
+  BH_HIP(c, bhk_sort(c));
+  c->stage |= BH_ST_SORT;
+  c->ever |= BH_ST_SORT;
+  return BH_OK;
+}
+int bh_build(bh_ctx* c) {
+  BH_NEED(c, BH_ST_SORT);
+  BH_HIP(c, bhk_build(c));
+  c->stage |= BH_ST_BUILD;
+  c->ever |= BH_ST_BUILD;
+  return BH_OK;
+}
+int bh_com(bh_ctx* c) {
+  BH_NEED(c, BH_ST_BUILD);
+  BH_HIP(c, bhk_com(c));
+  c->stage |= BH_ST_COM;
+  c->ever |= BH_ST_COM;
+  return BH_OK;
+}
+int bh_force_range(bh_ctx* c, int lo, int hi) {
+  BH_NEED(c, BH_ST_COM);
+  if (lo < 0 || hi > c->n || lo > hi) return BH_ERR_BAD_ARG;
+  BH_HIP(c, bhk_force(c, lo, hi, false));
+  c->stage |= BH_ST_FORCE;
+  c->ever |= BH_ST_FORCE;
+  return BH_OK;
+}
+int bh_force(bh_ctx* c) {
+  if (!c) return BH_ERR_BAD_ARG;
+  return bh_force_range(c, 0, c->n);
+}
+int bh_integrate(bh_ctx* c) {
+  BH_NEED(c, BH_ST_FORCE);
+  BH_HIP(c, bhk_integrate(c));
+  c->stage = BH_ST_UPLOADED;  // positions changed: bbox..force must be redone
+  return BH_OK;
+}
+
+int bh_force_count(bh_ctx* c) {
+  BH_NEED(c, BH_ST_COM);
+  const size_t N = (size_t)c->n;
+  BH_HIP(c, bhk_force(c, 0, c->n, true));
+  c->stage |= BH_ST_FORCE;
+  c->ever |= BH_ST_FORCE;
+  u32* h = (u32*)malloc(3 * N * sizeof(u32));
+  if (!h) return BH_ERR_OOM;
+  hipError_t e = hipMemcpyAsync(h, c->cV, N * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h + N, c->cO, N * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h + 2 * N, c->cP, N * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    free(h);
+    c->last_hip = (int)e;
+    return BH_ERR_HIP;
+  }
+  u64 v = 0, o = 0, p = 0;
+  for (size_t i = 0; i < N; i++) {
+    v += h[i];
+    o += h[N + i];
+    p += h[2 * N + i];
+  }
+  free(h);
+  c->tV = v; c->tO = o; c->tP = p;
+  return BH_OK;
+}
+
+// ---- the step: ref:255-283, same stage order, no host sync ----
+int bh_step(bh_ctx* c) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  const bool t = c->timing;
+#define BH_MARK(i) if (t) BH_HIP(c, hipEventRecord(c->ev[i], c->stream))
+  BH_MARK(0);
+  BH_HIP(c, bhk_bbox(c));                      // ref:259
+  BH_MARK(1);
+  BH_HIP(c, bhk_keys(c));                      // ref:260
+  c->key_buf = 0;
+  BH_MARK(2);
+  BH_HIP(c, bhk_sort(c));                      // ref:262-264
+  BH_MARK(3);
+  BH_HIP(c, bhk_build(c));                     // ref:266-275
+  BH_MARK(4);
+  BH_HIP(c, bhk_com(c));                       // ref:279-280
+  BH_MARK(5);
+  BH_HIP(c, bhk_force(c, 0, c->n, false));     // ref:281
+  BH_MARK(6);
+  BH_HIP(c, bhk_integrate(c));                 // ref:282
+  BH_MARK(7);
+#undef BH_MARK
+  c->timed_valid = t;
+  c->stage = BH_ST_UPLOADED;
+  c->ever |= BH_ST_BBOX | BH_ST_MORTON | BH_ST_SORT | BH_ST_BUILD | BH_ST_COM | BH_ST_FORCE;
+  c->steps++;
+  return BH_OK;
+}
+
+// ---- downloads ----
+static int d2h(bh_ctx* c, void* dst, const void* src, size_t bytes) {
+  BH_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return BH_OK;
+}
+
+int bh_download(bh_ctx* c, float* x, float* y, float* z, float* vx, float* vy, float* vz) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  const size_t N = (size_t)c->n, nb = N * sizeof(float);
+  BH_HIP(c, bhk_unpack(c, 0));
+  float* dst[6] = {x, y, z, vx, vy, vz};
+  for (int k = 0; k < 6; k++)
+    if (dst[k]) {
+      int s = d2h(c, dst[k], c->stage_buf + k * N, nb);
+      if (s) return s;
+    }
+  return bh_sync(c);
+}
+
+int bh_download_acc(bh_ctx* c, float* ax, float* ay, float* az) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  if (!ax || !ay || !az) return BH_ERR_BAD_ARG;
+  const size_t N = (size_t)c->n, nb = N * sizeof(float);
+  BH_HIP(c, bhk_unpack(c, 1));
+  int s;
+  if ((s = d2h(c, ax, c->stage_buf, nb))) return s;
+  if ((s = d2h(c, ay, c->stage_buf + N, nb))) return s;
+  if ((s = d2h(c, az, c->stage_buf + 2 * N, nb))) return s;
+  return bh_sync(c);
+}
+
+int bh_download_counters(bh_ctx* c, uint32_t* V, uint32_t* O, uint32_t* P) {
+  BH_NEED_EVER(c, BH_ST_FORCE);
+  if (!V || !O || !P) return BH_ERR_BAD_ARG;
+  const size_t N = (size_t)c->n, nb = N * sizeof(u32);
+  BH_HIP(c, bhk_unpack(c, 2));
+  const u32* s = (const u32*)c->stage_buf;
+  int r;
+  if ((r = d2h(c, V, s, nb))) return r;
+  if ((r = d2h(c, O, s + N, nb))) return r;
+  if ((r = d2h(c, P, s + 2 * N, nb))) return r;
+  return bh_sync(c);
+}
+
+int bh_download_bounds(bh_ctx* c, float bounds[6]) {
+  BH_NEED_EVER(c, BH_ST_BBOX);
+  if (!bounds) return BH_ERR_BAD_ARG;
+  int s = d2h(c, bounds, c->bounds, 6 * sizeof(float));
+  if (s) return s;
+  return bh_sync(c);
+}
+
+int bh_download_keys(bh_ctx* c, uint64_t* keys) {
+  BH_NEED_EVER(c, BH_ST_MORTON);
+  if (!keys) return BH_ERR_BAD_ARG;
+  const int buf = (c->ever & BH_ST_SORT) ? c->key_buf : 0;
+  int s = d2h(c, keys, c->keys[buf], (size_t)c->n * sizeof(u64));
+  if (s) return s;
+  return bh_sync(c);
+}
+
+int bh_download_order(bh_ctx* c, int32_t* ids) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  if (!ids) return BH_ERR_BAD_ARG;
+  const size_t N = (size_t)c->n;
+  float4* h = (float4*)malloc(N * sizeof(float4));
+  if (!h) return BH_ERR_OOM;
+  int s = d2h(c, h, c->velid[c->cur], N * sizeof(float4));
+  if (!s) s = bh_sync(c);
+  if (!s)
+    for (size_t i = 0; i < N; i++) memcpy(&ids[i], &h[i].w, 4);
+  free(h);
+  return s;
+}
+
+int bh_download_sorted_bodies(bh_ctx* c, float* xyzm) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  if (!xyzm) return BH_ERR_BAD_ARG;
+  int s = d2h(c, xyzm, c->posm[c->cur], (size_t)c->n * sizeof(float4));
+  if (s) return s;
+  return bh_sync(c);
+}
+
+static int fetch_info(bh_ctx* c, bh_devinfo* h) {
+  int s = d2h(c, h, c->info, sizeof(bh_devinfo));
+  if (s) return s;
+  return bh_sync(c);
+}
+
+int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries) {
+  BH_NEED_EVER(c, BH_ST_BUILD);
+  bh_devinfo hi;
+  int s = fetch_info(c, &hi);
+  if (s) return s;
+  if (hi.flags & BH_FLAG_POOL_OVERFLOW) return BH_ERR_POOL_OVERFLOW;
+  if (n_entries) *n_entries = hi.n_entries;
+  if (!out) return BH_OK;
+  if (capacity < hi.n_entries) return BH_ERR_SMALL_BUFFER;
+  s = d2h(c, out, c->rec, (size_t)hi.n_entries * sizeof(bh_node));
+  if (s) return s;
+  return bh_sync(c);
+}
+
+int bh_get_stats(bh_ctx* c, bh_stats* st) {
+  if (!c || !st) return BH_ERR_BAD_ARG;
+  memset(st, 0, sizeof(*st));
+  bh_devinfo hi;
+  int s = fetch_info(c, &hi);
+  if (s) return s;
+  st->n = c->n;
+  st->n_internal = hi.n_internal;
+  st->n_entries = hi.n_entries;
+  st->max_level = hi.max_level;
+  st->status_flags = hi.flags;
+  st->steps = c->steps;
+  if (c->timed_valid) {
+    float* ms[7] = {&st->ms_bbox, &st->ms_morton, &st->ms_sort, &st->ms_build,
+                    &st->ms_com, &st->ms_force, &st->ms_integrate};
+    for (int i = 0; i < 7; i++) BH_HIP(c, hipEventElapsedTime(ms[i], c->ev[i], c->ev[i + 1]));
+    BH_HIP(c, hipEventElapsedTime(&st->ms_step, c->ev[0], c->ev[7]));
+  }
+  st->count_V = c->tV;
+  st->count_O = c->tO;
+  st->count_P = c->tP;
+  if (hi.flags & BH_FLAG_POOL_OVERFLOW) return BH_ERR_POOL_OVERFLOW;
+  return BH_OK;
+}
+
+int bh_device_acc(bh_ctx* c, void** dptr, int64_t* bytes) {
+  if (!c || !dptr) return BH_ERR_BAD_ARG;
+  *dptr = (void*)c->acc;
+  if (bytes) *bytes = (int64_t)c->n * (int64_t)sizeof(float4);
+  return BH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// bh_internal.h — context layout and kernel-launcher prototypes shared by the
+// translation units of libbh.so.  Not part of the public ABI (include/bh.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bh.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct bh_d4 {  // fp64 prefix-sum element: (sum m, sum m*x, sum m*y, sum m*z)
+  double m, x, y, z;
+};
+
+// stage bits for order checking
+enum {
+  BH_ST_UPLOADED = 1,
+  BH_ST_BBOX = 2,
+  BH_ST_MORTON = 4,
+  BH_ST_SORT = 8,
+  BH_ST_BUILD = 16,
+  BH_ST_COM = 32,
+  BH_ST_FORCE = 64,
+};
+
+// device-resident scalar block (no per-step host sync needed to read any of it)
+struct bh_devinfo {
+  int n_internal;  // M
+  int n_entries;   // E
+  int max_level;
+  int flags;       // BH_FLAG_*
+};
+
+struct bh_ctx {
+  int n;
+  bh_params p;
+  int B, D, cap;  // bits per axis, effective max depth, leaf cap
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  int last_hip;
+  int stage;
+  int ever;  // stages that have run at least once since upload (downloads of stale-but-present data)
+  int steps;
+
+  // particle state, Morton order after the first sort (HBM, float4 = one 16-B access per lane)
+  float4* posm[2];   // (x,y,z,m)           ping-pong (gather target)
+  float4* velid[2];  // (vx,vy,vz,bits(id))  ping-pong
+  int cur;
+  float4* acc;       // (ax,ay,az,0)
+  float* stage_buf;  // 7n floats: SoA staging for upload/download
+
+  // keys
+  u64* keys[2];
+  u32* vals[2];
+  int key_buf;  // which keys[] holds the sorted keys
+  u32* hist;    // 256 * ntiles
+  int sort_tiles;
+
+  // bbox
+  float* bbox_partial;  // [BH_BBOX_BLOCKS][6]
+  float* bounds;        // [8]: min xyz, min+size xyz, s0, pad
+
+  // tree build temporaries
+  int* pa;        // [n] first body of the cell whose first child boundary is j
+  int* pb;        // [n] end body of that cell
+  int* pn;        // [n] its child count (0: j represents no emitted cell)
+  int* cb;        // [n+1] exclusive scan of pn; cb[n] = records - 1
+  bh_node* rec;   // [rec_cap] tree records
+  int* er_lo;     // [rec_cap] body range of each record
+  int* er_hi;
+  int rec_cap;
+  bh_d4* P;       // [n+1] fp64 exclusive prefix of (m, m x, m y, m z) over sorted bodies
+  bh_devinfo* info;
+
+  // scan scratch
+  void* scan_tmp;
+  size_t scan_tmp_bytes;
+
+  // counters (bh_force_count)
+  u32 *cV, *cO, *cP;
+  u64 tV, tO, tP;
+
+  // timing
+  bool timing;
+  bool timed_valid;
+  hipEvent_t ev[8];
+};
+
+#define BH_BBOX_BLOCKS 1024
+#define BH_SCAN_TILE 2048  // 256 threads x 8 items
+#define BH_SORT_ITEMS 16
+#define BH_SORT_TILE (256 * BH_SORT_ITEMS)
+
+// ---- launchers (each enqueues on c->stream and returns hipGetLastError()) ----
+hipError_t bhk_pack(bh_ctx* c);                       // stage_buf SoA -> posm/velid
+hipError_t bhk_unpack(bh_ctx* c, int what);           // 0: pos+vel -> stage_buf (caller order); 1: acc
+hipError_t bhk_bbox(bh_ctx* c);
+hipError_t bhk_keys(bh_ctx* c);
+hipError_t bhk_sort(bh_ctx* c);                       // radix sort + gather
+hipError_t bhk_build(bh_ctx* c);
+hipError_t bhk_com(bh_ctx* c);
+hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
+hipError_t bhk_integrate(bh_ctx* c);
+
+// device-wide scans (bh_scan.hip)
+hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);
+hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n);
+size_t bhk_scan_tmp_bytes(int n);

@@ -1,0 +1,178 @@
+// bh_scan.hip — device-wide exclusive prefix sums (reduce-then-scan, 3 launches).
+//
+// Used by the octree build (cell counts -> cell ids, child counts -> child-block offsets)
+// and by the centre-of-mass stage (fp64 prefix of (m, m*x, m*y, m*z) over the Morton-sorted
+// bodies).  No atomics, no decoupled look-back: the association order is fixed by the tile
+// structure, so results are bit-reproducible run to run.
+// Tile = 256 threads x 8 items, blocked per thread (32 contiguous bytes per lane for int32:
+// two dwordx4 accesses; 256 B per lane for the fp64 quadruple).  Wave-level steps are
+// 64-lane __shfl_up; the four wave totals of a block go through LDS.
+#include "bh_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = 8;
+constexpr int kTile = kThreads * kItems;  // == BH_SCAN_TILE
+
+// ---- element ops ----
+struct OpI32 {
+  typedef int T;
+  static __device__ __forceinline__ T zero() { return 0; }
+  static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+  static __device__ __forceinline__ T shfl_up(T v, int d) { return __shfl_up(v, d, 64); }
+  static __device__ __forceinline__ T shfl(T v, int l) { return __shfl(v, l, 64); }
+};
+struct OpD4 {
+  typedef bh_d4 T;
+  static __device__ __forceinline__ T zero() { return bh_d4{0.0, 0.0, 0.0, 0.0}; }
+  static __device__ __forceinline__ T add(T a, T b) {
+    return bh_d4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z};
+  }
+  static __device__ __forceinline__ T shfl_up(T v, int d) {
+    return bh_d4{__shfl_up(v.m, d, 64), __shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64),
+                 __shfl_up(v.z, d, 64)};
+  }
+  static __device__ __forceinline__ T shfl(T v, int l) {
+    return bh_d4{__shfl(v.m, l, 64), __shfl(v.x, l, 64), __shfl(v.y, l, 64), __shfl(v.z, l, 64)};
+  }
+};
+
+// ---- loaders ----
+struct LoadI32 {
+  const int* p;
+  __device__ __forceinline__ int operator()(int i) const { return p[i]; }
+};
+struct LoadPM {  // body i -> (m, m x, m y, m z) in fp64; the products of two fp32 are exact in fp64
+  const float4* posm;
+  __device__ __forceinline__ bh_d4 operator()(int i) const {
+    float4 q = posm[i];
+    double m = (double)q.w;
+    return bh_d4{m, m * (double)q.x, m * (double)q.y, m * (double)q.z};
+  }
+};
+
+// inclusive scan across the 64 lanes of a wave
+template <typename Op>
+__device__ __forceinline__ typename Op::T wave_inclusive(typename Op::T v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    typename Op::T t = Op::shfl_up(v, d);
+    if (lane >= d) v = Op::add(t, v);
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread across a block of NT threads (NT/64 waves).
+// Returns the exclusive prefix of this thread; *total receives the block total.
+template <typename Op, int NT>
+__device__ __forceinline__ typename Op::T block_exclusive(typename Op::T v, typename Op::T* lds,
+                                                          typename Op::T* total) {
+  typedef typename Op::T T;
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  T incl = wave_inclusive<Op>(v, lane);
+  T excl = Op::shfl_up(incl, 1);
+  if (lane == 0) excl = Op::zero();
+  if (lane == 63) lds[w] = incl;
+  __syncthreads();
+  T wprefix = Op::zero(), tot = Op::zero();
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    T s = lds[i];
+    if (i < w) wprefix = Op::add(wprefix, s);
+    tot = Op::add(tot, s);
+  }
+  __syncthreads();
+  *total = tot;
+  return Op::add(wprefix, excl);
+}
+
+template <typename Op, typename Load>
+__global__ __launch_bounds__(kThreads) void scan_reduce_kernel(Load load, int n_static,
+                                                               const int* __restrict__ n_dev,
+                                                               typename Op::T* __restrict__ tile_sums) {
+  typedef typename Op::T T;
+  __shared__ T lds[kThreads / 64];
+  const int n = n_dev ? *n_dev : n_static;
+  const int i0 = blockIdx.x * kTile + threadIdx.x * kItems;
+  T s = Op::zero();
+#pragma unroll
+  for (int k = 0; k < kItems; k++)
+    if (i0 + k < n) s = Op::add(s, load(i0 + k));
+  T tot;
+  (void)block_exclusive<Op, kThreads>(s, lds, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of the tile sums in place; total -> tile_sums[ntiles]
+template <typename Op>
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(typename Op::T* __restrict__ tile_sums,
+                                                          int ntiles) {
+  typedef typename Op::T T;
+  __shared__ T lds[1024 / 64];
+  T carry = Op::zero();
+  for (int c0 = 0; c0 < ntiles; c0 += 1024) {
+    const int i = c0 + (int)threadIdx.x;
+    T v = (i < ntiles) ? tile_sums[i] : Op::zero();
+    T tot;
+    T ex = block_exclusive<Op, 1024>(v, lds, &tot);
+    if (i < ntiles) tile_sums[i] = Op::add(carry, ex);
+    carry = Op::add(carry, tot);
+  }
+  if (threadIdx.x == 0) tile_sums[ntiles] = carry;
+}
+
+template <typename Op, typename Load>
+__global__ __launch_bounds__(kThreads) void scan_apply_kernel(Load load, int n_static,
+                                                              const int* __restrict__ n_dev,
+                                                              const typename Op::T* __restrict__ tile_sums,
+                                                              int ntiles,
+                                                              typename Op::T* __restrict__ out) {
+  typedef typename Op::T T;
+  __shared__ T lds[kThreads / 64];
+  const int n = n_dev ? *n_dev : n_static;
+  const int i0 = blockIdx.x * kTile + threadIdx.x * kItems;
+  T v[kItems];
+  T s = Op::zero();
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    v[k] = (i0 + k < n) ? load(i0 + k) : Op::zero();
+    s = Op::add(s, v[k]);
+  }
+  T tot;
+  T ex = block_exclusive<Op, kThreads>(s, lds, &tot);
+  T run = Op::add(tile_sums[blockIdx.x], ex);
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    if (i0 + k < n) out[i0 + k] = run;
+    run = Op::add(run, v[k]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sums[ntiles];
+}
+
+template <typename Op, typename Load>
+hipError_t run_scan(bh_ctx* c, Load load, typename Op::T* out, int n, const int* n_dev) {
+  typedef typename Op::T T;
+  const int ntiles = (n + kTile - 1) / kTile;
+  T* sums = reinterpret_cast<T*>(c->scan_tmp);
+  scan_reduce_kernel<Op, Load><<<ntiles, kThreads, 0, c->stream>>>(load, n, n_dev, sums);
+  scan_tiles_kernel<Op><<<1, 1024, 0, c->stream>>>(sums, ntiles);
+  scan_apply_kernel<Op, Load><<<ntiles, kThreads, 0, c->stream>>>(load, n, n_dev, sums, ntiles, out);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t bhk_scan_tmp_bytes(int n) {
+  const size_t ntiles = ((size_t)n + kTile - 1) / kTile;
+  return (ntiles + 2) * sizeof(bh_d4);
+}
+
+hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out, int n, const int* n_dev) {
+  return run_scan<OpI32>(c, LoadI32{in}, out, n, n_dev);
+}
+
+hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out, int n) {
+  return run_scan<OpD4>(c, LoadPM{posm}, out, n, nullptr);
+}

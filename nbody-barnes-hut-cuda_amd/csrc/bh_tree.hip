@@ -1,0 +1,442 @@
+// bh_tree.hip — bounding cube, Morton keys, octree topology and centres of mass.
+//
+// Reference stages (nbody_v5_bench.cu): computeBoundingBoxKernel :134-156 (one GPU thread),
+// computeMortonCodesKernel :51-63, memset + initRoot + insertParticles :266-275 (a host loop
+// of N/1024 launches of a racy atomicCAS insertion), computeCOM + finalizeCOM :158-189
+// (4N float atomics on the root).  None of that structure is kept:
+//
+//  * bbox   : grid-stride float4 loads, wave64 shuffle min/max, LDS across the 4 waves,
+//             1024 partials folded by a second one-block launch.  min/max are exact, so the
+//             cube equals the reference's serial loop bit for bit.
+//  * build  : the (path-compressed) canonical octree is a pure function of the SORTED keys, so
+//             every internal cell is found independently — no levels, no allocation atomics, no
+//             races: one thread per adjacent key pair, binary searches on the key digits, one
+//             exclusive scan of the child counts to place each cell's children in one contiguous
+//             block of 32-byte records (details above pairs_kernel).
+//  * COM    : one fp64 exclusive prefix scan of (m, m x, m y, m z) over the sorted bodies;
+//             a cell's sums are P[hi] - P[lo], rounded once to fp32.  Deterministic, no atomics,
+//             more accurate than any fp32 summation order (the reference's is non-deterministic).
+#include "bh_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------ bbox
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+__device__ __forceinline__ void block_minmax(float mn[3], float mx[3], float* lds /* [4][6] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    mn[k] = wave_min(mn[k]);
+    mx[k] = wave_max(mx[k]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      lds[w * 6 + k] = mn[k];
+      lds[w * 6 + 3 + k] = mx[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 4; q++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        mn[k] = fminf(mn[k], lds[q * 6 + k]);
+        mx[k] = fmaxf(mx[k], lds[q * 6 + 3 + k]);
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const float4* __restrict__ posm, int n,
+                                                           float* __restrict__ partial) {
+  __shared__ float lds[24];
+  float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
+  float mx[3] = {-1e10f, -1e10f, -1e10f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 q = posm[i];
+    mn[0] = fminf(mn[0], q.x);
+    mn[1] = fminf(mn[1], q.y);
+    mn[2] = fminf(mn[2], q.z);
+    mx[0] = fmaxf(mx[0], q.x);
+    mx[1] = fmaxf(mx[1], q.y);
+    mx[2] = fmaxf(mx[2], q.z);
+  }
+  block_minmax(mn, mx, lds);
+  if (threadIdx.x == 0) {
+    float* o = partial + blockIdx.x * 6;
+    o[0] = mn[0]; o[1] = mn[1]; o[2] = mn[2];
+    o[3] = mx[0]; o[4] = mx[1]; o[5] = mx[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict__ partial, int nparts,
+                                                         float* __restrict__ bounds) {
+  __shared__ float lds[24];
+  float mn[3] = {1e10f, 1e10f, 1e10f};
+  float mx[3] = {-1e10f, -1e10f, -1e10f};
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    const float* o = partial + i * 6;
+    mn[0] = fminf(mn[0], o[0]); mn[1] = fminf(mn[1], o[1]); mn[2] = fminf(mn[2], o[2]);
+    mx[0] = fmaxf(mx[0], o[3]); mx[1] = fmaxf(mx[1], o[4]); mx[2] = fmaxf(mx[2], o[5]);
+  }
+  block_minmax(mn, mx, lds);
+  if (threadIdx.x == 0) {
+    const float size = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));  // ref:148
+    bounds[0] = mn[0];
+    bounds[1] = mn[1];
+    bounds[2] = mn[2];
+    bounds[3] = mn[0] + size;  // ref:152-154: cube anchored at the min corner
+    bounds[4] = mn[1] + size;
+    bounds[5] = mn[2] + size;
+    bounds[6] = fmaxf(bounds[3] - bounds[0], 1.0f);  // root edge s0, ref:55
+    bounds[7] = 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------ keys
+__device__ __forceinline__ u32 expand_bits10(u32 v) {  // ref:42-49
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+__device__ __forceinline__ u64 expand_bits21(u32 q) {
+  u64 x = q & 0x1fffffu;
+  x = (x | x << 32) & 0x001f00000000ffffull;
+  x = (x | x << 16) & 0x001f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void keys_kernel(const float4* __restrict__ posm,
+                                                   const float* __restrict__ bounds, int n,
+                                                   u64* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
+  const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
+  const float4 q = posm[i];
+  constexpr float scale = (B == 10) ? 1023.0f : 2097152.0f;  // ref:56-58 (x1023) / 2^21
+  constexpr u32 qmax = (1u << B) - 1u;
+  // IEEE subtract, divide, multiply in the reference's order; truncating conversion
+  u32 x = (u32)((q.x - minX) / size * scale);
+  u32 y = (u32)((q.y - minY) / size * scale);
+  u32 z = (u32)((q.z - minZ) / size * scale);
+  x = min(x, qmax);
+  y = min(y, qmax);
+  z = min(z, qmax);
+  u64 k;
+  if (B == 10)
+    k = (u64)((expand_bits10(x) << 2) | (expand_bits10(y) << 1) | expand_bits10(z));  // ref:61
+  else
+    k = (expand_bits21(x) << 2) | (expand_bits21(y) << 1) | expand_bits21(z);
+  keys[i] = k;
+}
+
+// ------------------------------------------------------------------ build
+// Path-compressed canonical octree from the sorted keys.
+//
+// Canonical rule (reference intent, nbody_v5_bench.cu:83-132 with D3-D5 removed): a cell is
+// subdivided iff it holds more than leaf_cap bodies and its level < max_depth.  A cell with a
+// single non-empty octant has the same (mass, COM) as that child and a larger edge, so under the
+// MAC `s/dist < theta` it is accepted only if the child would be too: dropping such chain cells
+// leaves every body's set of accepted cells/bodies unchanged (bit-identical sums in pre-order;
+// tests/test_oracle.py checks it on the oracle) and bounds the tree: internal cells <= n-1,
+// records <= 2n, whatever the input.  (The
+// reference's 2N-node pool overflows silently on close pairs)
+//
+// Every emitted internal cell BRANCHES (>= 2 non-empty octants), so it has a first child
+// boundary j: keys j-1 and j share exactly L = level digits.  Conversely each adjacent pair
+// (j-1, j) with d = common digits < D names the cell at level d containing both.  Thread j
+//   - finds that cell's start a (gallop + bisect on the top-d-digit prefix),
+//   - is the cell's representative iff key j-1 still has key a's digit at level d,
+//   - if so finds the end b, the <= 8 child ranges, and records nchild[j].
+// One exclusive scan of nchild[] places each cell's children in one contiguous block; the
+// representative index j doubles as the cell id, so no compaction pass is needed.
+__device__ __forceinline__ int common_digits(u64 a, u64 b, int B) {
+  const u64 x = a ^ b;
+  if (x == 0) return B;
+  const int hb = 63 - __clzll((long long)x);
+  return B - 1 - hb / 3;
+}
+
+__device__ __forceinline__ u64 key_prefix(u64 k, int sh) { return (sh >= 64) ? 0ull : (k >> sh); }
+
+// first index in (a, n] whose prefix differs from key a's (galloping + bisection)
+__device__ __forceinline__ int cell_end(const u64* __restrict__ k, int n, int a, int sh) {
+  const u64 pa = key_prefix(k[a], sh);
+  int lo = a, step = 1;  // invariant: prefix(lo) == pa
+  int hi;
+  for (;;) {
+    hi = lo + step;
+    if (hi >= n) {
+      hi = n;
+      break;
+    }
+    if (key_prefix(k[hi], sh) != pa) break;
+    lo = hi;
+    step <<= 1;
+  }
+  while (hi - lo > 1) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (key_prefix(k[mid], sh) == pa) lo = mid; else hi = mid;
+  }
+  return hi;
+}
+
+// smallest index whose prefix equals key j's, searching left of j
+__device__ __forceinline__ int cell_start(const u64* __restrict__ k, int j, int sh) {
+  const u64 pj = key_prefix(k[j], sh);
+  int hi = j, step = 1;  // invariant: prefix(hi) == pj
+  int lo;
+  for (;;) {
+    lo = hi - step;
+    if (lo < 0) {
+      lo = -1;
+      break;
+    }
+    if (key_prefix(k[lo], sh) != pj) break;
+    hi = lo;
+    step <<= 1;
+  }
+  while (hi - lo > 1) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (key_prefix(k[mid], sh) == pj) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
+// child boundaries of cell [a,b) at the level whose digit shift is dsh:
+// pos[v] = first j in [a,b) with digit(k[j]) >= v
+__device__ __forceinline__ void child_bounds(const u64* __restrict__ k, int a, int b, int dsh,
+                                             int pos[9]) {
+  pos[0] = a;
+  pos[8] = b;
+  if (b - a <= 16) {  // short range: one linear pass
+    int v = 0;
+    for (int j = a; j < b; j++) {
+      const int g = (int)((k[j] >> dsh) & 7ull);
+      while (v < g) pos[++v] = j;
+    }
+    while (v < 7) pos[++v] = b;
+    return;
+  }
+  int lo = a;
+  for (int v = 1; v < 8; v++) {
+    int l = lo, h = b;
+    while (l < h) {
+      const int mid = l + ((h - l) >> 1);
+      if ((int)((k[mid] >> dsh) & 7ull) < v) l = mid + 1; else h = mid;
+    }
+    pos[v] = l;
+    lo = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k, int n, int B, int D,
+                                                    int cap, int* __restrict__ pa, int* __restrict__ pb,
+                                                    int* __restrict__ pn, bh_devinfo* __restrict__ info) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int nc = 0, L = 0;
+  if (j >= 1) {
+    const u64 kj = k[j], kp = k[j - 1];
+    L = common_digits(kp, kj, B);
+    if (L < D) {
+      const int sh = 3 * (B - L), dsh = 3 * (B - 1 - L);
+      const int a = cell_start(k, j - 1, sh);
+      if (((kp >> dsh) & 7ull) == ((k[a] >> dsh) & 7ull)) {  // j is the cell's first child boundary
+        const int b = cell_end(k, n, j, sh);
+        if (b - a > cap) {
+          int pos[9];
+          child_bounds(k, a, b, dsh, pos);
+#pragma unroll
+          for (int v = 0; v < 8; v++) nc += (pos[v + 1] > pos[v]) ? 1 : 0;
+          pa[j] = a;
+          pb[j] = b;
+        }
+      }
+    }
+  }
+  pn[j] = nc;
+  if (nc) {  // integer atomics: totals are order-independent
+    atomicAdd(&info->n_internal, 1);
+    atomicMax(&info->max_level, L + 1);
+  }
+}
+
+// classify the child cell [c0,c1) of a cell at level L and fill the topology fields of its record
+__device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, int D, int cap, float s0,
+                                              const int* __restrict__ pn, const int* __restrict__ cb,
+                                              int c0, int c1, int child_level) {
+  bh_node r;
+  r.x = r.y = r.z = r.m = 0.0f;
+  const int m = c1 - c0;
+  if (m == 1) {
+    r.kind = BH_KIND_BODY;
+    r.first = c0;
+    r.count = 1;
+    r.s = -1.0f;  // negative edge: accepted by every theta >= 0
+    return r;
+  }
+  if (m <= cap) {
+    r.kind = BH_KIND_MULTI;
+    r.first = c0;
+    r.count = m;
+    r.s = ldexpf(s0, -child_level);
+    return r;
+  }
+  const int Lb = common_digits(k[c0], k[c1 - 1], B);  // branching level of the (compressed) cell
+  if (Lb >= D) {  // never branches above the depth cap: unsplit multi-body cell at level D
+    r.kind = BH_KIND_MULTI;
+    r.first = c0;
+    r.count = m;
+    r.s = ldexpf(s0, -D);
+    return r;
+  }
+  // representative = first index whose digit at level Lb exceeds that of key c0
+  const int dsh = 3 * (B - 1 - Lb);
+  const int g0 = (int)((k[c0] >> dsh) & 7ull);
+  int l = c0 + 1, h = c1 - 1;  // digit(k[c1-1]) > g0, so the answer is in [c0+1, c1-1]
+  while (l < h) {
+    const int mid = l + ((h - l) >> 1);
+    if ((int)((k[mid] >> dsh) & 7ull) > g0) h = mid; else l = mid + 1;
+  }
+  r.kind = BH_KIND_INTERNAL;
+  r.first = 1 + cb[l];
+  r.count = pn[l];
+  r.s = ldexpf(s0, -Lb);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k, int n, int B, int D, int cap,
+                                                   const int* __restrict__ pa, const int* __restrict__ pb,
+                                                   const int* __restrict__ pn, const int* __restrict__ cb,
+                                                   const float* __restrict__ bounds,
+                                                   bh_node* __restrict__ rec, int* __restrict__ er_lo,
+                                                   int* __restrict__ er_hi, int rec_cap,
+                                                   bh_devinfo* __restrict__ info) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float s0 = bounds[6];
+  if (j == 0) {  // root record (ref:65-81 initRootKernel)
+    const int E = 1 + cb[n];
+    info->n_entries = E;
+    if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
+    rec[0] = make_child(k, B, D, cap, s0, pn, cb, 0, n, 0);
+    er_lo[0] = 0;
+    er_hi[0] = n;
+    return;
+  }
+  const int nc = pn[j];
+  if (nc == 0) return;
+  int e = 1 + cb[j];
+  if (e + nc > rec_cap) return;  // cannot happen (records <= 2n); flagged by thread 0 if it did
+  const int a = pa[j], b = pb[j];
+  const int L = common_digits(k[j - 1], k[j], B);
+  int pos[9];
+  child_bounds(k, a, b, 3 * (B - 1 - L), pos);
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    const int c0 = pos[v], c1 = pos[v + 1];
+    if (c1 <= c0) continue;
+    rec[e] = make_child(k, B, D, cap, s0, pn, cb, c0, c1, L + 1);
+    er_lo[e] = c0;
+    er_hi[e] = c1;
+    e++;
+  }
+}
+
+// ------------------------------------------------------------------ COM
+__global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec,
+                                                  const int* __restrict__ er_lo,
+                                                  const int* __restrict__ er_hi,
+                                                  const bh_devinfo* __restrict__ info, int rec_cap,
+                                                  const float4* __restrict__ posm,
+                                                  const bh_d4* __restrict__ P) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int E = min(info->n_entries, rec_cap);
+  if (e >= E) return;
+  const int lo = er_lo[e], hi = er_hi[e];
+  float4 o;
+  if (rec[e].kind == BH_KIND_BODY) {
+    o = posm[lo];
+  } else {
+    const bh_d4 p1 = P[hi], p0 = P[lo];
+    const double M = p1.m - p0.m;
+    const double sx = p1.x - p0.x, sy = p1.y - p0.y, sz = p1.z - p0.z;
+    const float mass = (float)M;
+    o.w = mass;
+    if (mass > 1e-6f) {  // ref:180
+      o.x = (float)(sx / M);
+      o.y = (float)(sy / M);
+      o.z = (float)(sz / M);
+    } else {
+      o.x = (float)sx;
+      o.y = (float)sy;
+      o.z = (float)sz;
+    }
+  }
+  // x,y,z,m are the first 16 bytes of the record
+  *reinterpret_cast<float4*>(&rec[e]) = o;
+}
+
+}  // namespace
+
+hipError_t bhk_bbox(bh_ctx* c) {
+  const int n = c->n;
+  int blocks = (n + 1023) / 1024;
+  if (blocks > BH_BBOX_BLOCKS) blocks = BH_BBOX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  bbox_partial_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], n, c->bbox_partial);
+  bbox_final_kernel<<<1, 256, 0, c->stream>>>(c->bbox_partial, blocks, c->bounds);
+  return hipGetLastError();
+}
+
+hipError_t bhk_keys(bh_ctx* c) {
+  const int n = c->n;
+  const int blocks = (n + 255) / 256;
+  if (c->B == 10)
+    keys_kernel<10><<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, c->keys[0]);
+  else
+    keys_kernel<21><<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, c->keys[0]);
+  return hipGetLastError();
+}
+
+hipError_t bhk_build(bh_ctx* c) {
+  const int n = c->n;
+  const u64* k = c->keys[c->key_buf];
+  hipError_t e = hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream);
+  if (e != hipSuccess) return e;
+  const int blocks = (n + 255) / 256;
+  pairs_kernel<<<blocks, 256, 0, c->stream>>>(k, n, c->B, c->D, c->cap, c->pa, c->pb, c->pn, c->info);
+  e = bhk_scan_i32(c, c->pn, c->cb, n, nullptr);  // child-block offsets; cb[n] = total children
+  if (e != hipSuccess) return e;
+  emit_kernel<<<blocks, 256, 0, c->stream>>>(k, n, c->B, c->D, c->cap, c->pa, c->pb, c->pn, c->cb,
+                                             c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
+  return hipGetLastError();
+}
+
+hipError_t bhk_com(bh_ctx* c) {
+  const int n = c->n;
+  hipError_t e = bhk_scan_pm(c, c->posm[c->cur], c->P, n);
+  if (e != hipSuccess) return e;
+  const int blocks = (c->rec_cap + 255) / 256;
+  com_kernel<<<blocks, 256, 0, c->stream>>>(c->rec, c->er_lo, c->er_hi, c->info, c->rec_cap,
+                                            c->posm[c->cur], c->P);
+  return hipGetLastError();
+}

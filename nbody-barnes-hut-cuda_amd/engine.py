@@ -1,0 +1,183 @@
+"""Engine: one Barnes-Hut context on one MI355X (wraps bh_ctx of include/bh.h)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, BhParams, BhNode, BhStats
+
+KIND_BODY, KIND_INTERNAL, KIND_MULTI = 0, 1, 2
+_F = C.POINTER(C.c_float)
+
+
+class BhError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        super().__init__(f"{where}: {lib.bh_strerror(status).decode()} ({status})")
+
+
+def default_params(**kw):
+    """bh_params with the reference's constants (nbody_v5_bench.cu:14-18), overridable."""
+    p = BhParams()
+    lib.bh_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"bh_params has no field {k}")
+        setattr(p, k, v)
+    return p
+
+
+def _f32(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.shape != (n,):
+        raise ValueError(f"expected float32[{n}], got {a.shape}")
+    return a
+
+
+class Engine:
+    """Replaces the reference's file-scope globals + simulationStep() (:31-40, :255-283)."""
+
+    def __init__(self, n, params=None, device=0, stream=None, **kw):
+        self.n = int(n)
+        self.params = params if params is not None else default_params(**kw)
+        self._h = C.c_void_p()
+        if stream is None:
+            st = lib.bh_create(C.byref(self._h), self.n, C.byref(self.params), int(device))
+        else:
+            st = lib.bh_create_on_stream(C.byref(self._h), self.n, C.byref(self.params),
+                                         int(device), C.c_void_p(int(stream)))
+        if st != 0:
+            self._h = C.c_void_p()
+            raise BhError(st, "bh_create")
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib.bh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, st, where):
+        if st != 0:
+            raise BhError(st, where)
+
+    # -- data in (ref:329-335)
+    def upload(self, x, y, z, vx, vy, vz, m):
+        arrs = [_f32(a, self.n) for a in (x, y, z, vx, vy, vz, m)]
+        self._ck(lib.bh_upload(self._h, *[a.ctypes.data_as(_F) for a in arrs]), "bh_upload")
+
+    # -- the step and its stages, reference order (ref:259-282)
+    def step(self, steps=1):
+        for _ in range(int(steps)):
+            self._ck(lib.bh_step(self._h), "bh_step")
+
+    simulationStep = step  # the reference's name (ref:255)
+
+    def bbox(self):
+        self._ck(lib.bh_bbox(self._h), "bh_bbox")
+
+    def morton(self):
+        self._ck(lib.bh_morton(self._h), "bh_morton")
+
+    def sort(self):
+        self._ck(lib.bh_sort(self._h), "bh_sort")
+
+    def build(self):
+        self._ck(lib.bh_build(self._h), "bh_build")
+
+    def com(self):
+        self._ck(lib.bh_com(self._h), "bh_com")
+
+    def force(self, lo=None, hi=None):
+        if lo is None:
+            self._ck(lib.bh_force(self._h), "bh_force")
+        else:
+            self._ck(lib.bh_force_range(self._h, int(lo), int(hi)), "bh_force_range")
+
+    def force_count(self):
+        self._ck(lib.bh_force_count(self._h), "bh_force_count")
+
+    def integrate(self):
+        self._ck(lib.bh_integrate(self._h), "bh_integrate")
+
+    def tree_stages(self):
+        """bbox -> morton -> sort -> build -> com (everything before the force stage)."""
+        self.bbox(); self.morton(); self.sort(); self.build(); self.com()
+
+    def sync(self):
+        self._ck(lib.bh_sync(self._h), "bh_sync")
+
+    def set_timing(self, on=True):
+        self._ck(lib.bh_set_timing(self._h, 1 if on else 0), "bh_set_timing")
+
+    # -- data out
+    def download(self):
+        """-> x, y, z, vx, vy, vz in caller (upload) order."""
+        out = [np.empty(self.n, dtype=np.float32) for _ in range(6)]
+        self._ck(lib.bh_download(self._h, *[a.ctypes.data_as(_F) for a in out]), "bh_download")
+        return tuple(out)
+
+    def download_acc(self):
+        out = [np.empty(self.n, dtype=np.float32) for _ in range(3)]
+        self._ck(lib.bh_download_acc(self._h, *[a.ctypes.data_as(_F) for a in out]), "bh_download_acc")
+        return tuple(out)
+
+    def download_bounds(self):
+        b = np.empty(6, dtype=np.float32)
+        self._ck(lib.bh_download_bounds(self._h, b.ctypes.data_as(_F)), "bh_download_bounds")
+        return b
+
+    def download_keys(self):
+        k = np.empty(self.n, dtype=np.uint64)
+        self._ck(lib.bh_download_keys(self._h, k.ctypes.data_as(C.POINTER(C.c_uint64))), "bh_download_keys")
+        return k
+
+    def download_order(self):
+        ids = np.empty(self.n, dtype=np.int32)
+        self._ck(lib.bh_download_order(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32))), "bh_download_order")
+        return ids
+
+    def download_sorted_bodies(self):
+        a = np.empty((self.n, 4), dtype=np.float32)
+        self._ck(lib.bh_download_sorted_bodies(self._h, a.ctypes.data_as(_F)), "bh_download_sorted_bodies")
+        return a
+
+    def download_tree(self):
+        """-> structured numpy array of bh_node records (entry 0 = root)."""
+        cnt = C.c_int(0)
+        self._ck(lib.bh_download_tree(self._h, None, 0, C.byref(cnt)), "bh_download_tree")
+        dt = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("m", "f4"), ("s", "f4"),
+                       ("first", "i4"), ("count", "i4"), ("kind", "i4")])
+        rec = np.empty(cnt.value, dtype=dt)
+        self._ck(lib.bh_download_tree(self._h, rec.ctypes.data_as(C.POINTER(BhNode)), cnt.value,
+                                      C.byref(cnt)), "bh_download_tree")
+        return rec
+
+    def download_counters(self):
+        out = [np.empty(self.n, dtype=np.uint32) for _ in range(3)]
+        self._ck(lib.bh_download_counters(self._h, *[a.ctypes.data_as(C.POINTER(C.c_uint32)) for a in out]),
+                 "bh_download_counters")
+        return tuple(out)
+
+    def stats(self):
+        s = BhStats()
+        self._ck(lib.bh_get_stats(self._h, C.byref(s)), "bh_get_stats")
+        return s
+
+    # -- multi-rank plumbing
+    def device_acc(self):
+        """(device pointer, bytes) of the float4[n] acceleration buffer (Morton order)."""
+        p = C.c_void_p()
+        nb = C.c_int64()
+        self._ck(lib.bh_device_acc(self._h, C.byref(p), C.byref(nb)), "bh_device_acc")
+        return p.value, nb.value

@@ -1,0 +1,97 @@
+// bh_bench — headless benchmark driver over the C-ABI (include/bh.h).
+//
+// Command-line counterpart of the reference's `main()` (nbody_v5_bench.cu:285-390): generate
+// initial conditions, allocate, upload, run a frame loop timing every step, print the same
+// `Frame | Trajanje (ms) | FPS` table (:351,:366), free.  With no arguments it reproduces the
+// reference's run shape: disc IC, N = 500000 (:31), 1000 frames (:353).
+//   bh_bench [--n N] [--steps K] [--warmup W] [--ic disc|plummer] [--seed S] [--theta T]
+//            [--leaf-cap C] [--strict] [--quiet] [--device D]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "bh.h"
+
+static double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+#define CK(call)                                                         \
+  do {                                                                   \
+    int _s = (call);                                                     \
+    if (_s != BH_OK) {                                                   \
+      fprintf(stderr, "%s failed: %s (%d)\n", #call, bh_strerror(_s), _s); \
+      return 1;                                                          \
+    }                                                                    \
+  } while (0)
+
+int main(int argc, char** argv) {
+  int N = 500000;  // ref:31
+  int frames = 1000;  // ref:353
+  int warmup = 0;
+  int device = 0;
+  bool plummer = false, quiet = false;
+  unsigned long long seed = 42;  // ref:294 srand(42)
+  bh_params p;
+  bh_default_params(&p);
+  for (int i = 1; i < argc; i++) {
+    auto arg = [&](const char* name) { return !strcmp(argv[i], name) && i + 1 < argc; };
+    if (arg("--n")) N = atoi(argv[++i]);
+    else if (arg("--steps")) frames = atoi(argv[++i]);
+    else if (arg("--warmup")) warmup = atoi(argv[++i]);
+    else if (arg("--seed")) seed = strtoull(argv[++i], nullptr, 10);
+    else if (arg("--theta")) p.theta = (float)atof(argv[++i]);
+    else if (arg("--leaf-cap")) p.leaf_cap = atoi(argv[++i]);
+    else if (arg("--device")) device = atoi(argv[++i]);
+    else if (arg("--ic")) plummer = !strcmp(argv[++i], "plummer");
+    else if (!strcmp(argv[i], "--strict")) p.strict_fp = 1;
+    else if (!strcmp(argv[i], "--quiet")) quiet = true;
+    else {
+      fprintf(stderr, "unknown argument %s\n", argv[i]);
+      return 2;
+    }
+  }
+  printf("Pokretanje Benchmarka za N = %d...\n", N);  // ref:287
+
+  std::vector<float> x(N), y(N), z(N), vx(N), vy(N), vz(N), m(N);
+  if (plummer)
+    CK(bh_ic_plummer(N, seed, 400.0f, p.G, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
+  else
+    CK(bh_ic_disc(N, seed, p.G, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
+
+  bh_ctx* c = nullptr;
+  CK(bh_create(&c, N, &p, device));
+  CK(bh_upload(c, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
+  CK(bh_set_timing(c, 1));
+  for (int w = 0; w < warmup; w++) CK(bh_step(c));
+  CK(bh_sync(c));
+
+  printf("------------------------------------------\n");
+  printf("\n%-10s | %-15s | %-10s\n", "Frame", "Trajanje (ms)", "FPS");  // ref:351
+
+  double sum = 0.0, sum_force = 0.0;
+  bh_stats st;
+  for (int frame = 0; frame < frames; frame++) {
+    const double t0 = now_ms();
+    CK(bh_step(c));
+    CK(bh_sync(c));
+    const double ms = now_ms() - t0;
+    CK(bh_get_stats(c, &st));
+    sum += ms;
+    sum_force += st.ms_force;
+    if (!quiet) printf("%-10d | %-15.3f | %-10.1f\n", frame, ms, 1000.0 / ms);  // ref:366
+  }
+  const double avg = sum / (frames > 0 ? frames : 1);
+  printf("------------------------------------------\n");
+  printf("N=%d ic=%s theta=%.2f steps=%d avg %.3f ms/step  %.3e particles/s/step\n", N,
+         plummer ? "plummer" : "disc", p.theta, frames, avg, (double)N / (avg * 1e-3));
+  printf("last step stages (ms): bbox %.3f morton %.3f sort %.3f build %.3f com %.3f force %.3f integrate %.3f | "
+         "cells %d entries %d depth %d flags %d | avg force %.3f ms\n",
+         st.ms_bbox, st.ms_morton, st.ms_sort, st.ms_build, st.ms_com, st.ms_force, st.ms_integrate,
+         st.n_internal, st.n_entries, st.max_level, st.status_flags, sum_force / (frames > 0 ? frames : 1));
+  bh_destroy(c);  // ref:372-387
+  return 0;
+}

@@ -1,0 +1,105 @@
+"""CPU tests of the drop-in boundary: libbh.so loads, exports every symbol include/bh.h declares,
+host-only entry points work, and — with no GPU — compute entry points fail loudly instead of
+falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bh.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(pkg):
+    names = _declared_symbols()
+    assert len(names) >= 30
+    raw = C.CDLL(pkg.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"libbh.so does not export {n}"
+    bound = {s[0] for s in __import__("nbody_barnes_hut_cuda_amd")._lib.SYMBOLS}
+    assert set(names) == bound, set(names) ^ bound
+
+
+def test_struct_layouts(pkg):
+    assert C.sizeof(pkg.BhNode) == 32
+    assert C.sizeof(pkg.BhParams) == 5 * 4 + 4 * 4 + 7 * 4
+    assert pkg.lib.bh_abi_version() == 1
+
+
+def test_default_params_are_reference_constants(pkg):
+    p = pkg.default_params()   # nbody_v5_bench.cu:14-18
+    assert (p.G, p.theta, p.dt, p.eps2, p.max_speed) == (0.5, 0.5, np.float32(0.02), 50.0, 500.0)
+    assert (p.leaf_cap, p.max_depth, p.key_bits, p.strict_fp) == (1, 21, 63, 0)
+    with pytest.raises(AttributeError):
+        pkg.default_params(nonsense=1)
+
+
+def test_strerror(pkg):
+    assert pkg.lib.bh_strerror(0) == b"ok"
+    for s in range(-7, 0):
+        assert pkg.lib.bh_strerror(s) not in (b"ok", b"unknown status")
+    assert pkg.lib.bh_strerror(-99) == b"unknown status"
+
+
+def test_no_gpu_means_no_compute(pkg):
+    """There is no CPU fallback: without a HIP device bh_create returns BH_ERR_NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    with pytest.raises(pkg.BhError) as e:
+        pkg.Engine(1000)
+    assert e.value.status == -2
+
+
+def test_product_does_not_touch_the_oracle():
+    """nothing under the product package or the C-ABI sources mentions the oracle"""
+    pk = os.path.join(ROOT, "nbody-barnes-hut-cuda_amd")
+    for dirpath, _, files in os.walk(pk):
+        if "build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "bh_oracle" not in txt and "import oracle" not in txt and "bho_" not in txt, f
+
+
+def test_ic_plummer_properties(pkg):
+    n = 20000
+    x, y, z, vx, vy, vz, m = pkg.plummer(n, seed=42)
+    assert m.min() >= 2.0 and m.max() < 7.0 and abs(m.mean() - 4.5) < 0.05   # law of ref:302
+    r = np.sqrt(x.astype(np.float64) ** 2 + y.astype(np.float64) ** 2 + z.astype(np.float64) ** 2)
+    assert r.max() <= 4000.0 * (1 + 1e-6)                                    # r <= 10 a
+    # half-mass radius of a Plummer sphere = 1.305 a (slightly less with the 10a cut)
+    assert abs(np.median(r) / 400.0 - 1.30) < 0.05
+    v = np.sqrt(vx.astype(np.float64) ** 2 + vy.astype(np.float64) ** 2 + vz.astype(np.float64) ** 2)
+    vesc = np.sqrt(2 * 0.5 * m.astype(np.float64).sum() / 400.0) * (1 + (r / 400.0) ** 2) ** -0.25
+    assert np.all(v <= vesc * (1 + 1e-6))                                    # bound orbits
+    # counter-based: body i does not depend on n (masses and directions; speeds scale with M)
+    x2, _, _, _, _, _, m2 = pkg.plummer(100, seed=42)
+    assert np.array_equal(x2, x[:100]) and np.array_equal(m2, m[:100])
+    # different seed, different sample
+    assert not np.array_equal(pkg.plummer(100, seed=43)[0], x2)
+
+
+def test_ic_disc_matches_reference_formulae(pkg):
+    n = 5000
+    x, y, z, vx, vy, vz, m = pkg.disc(n, seed=42)   # nbody_v5_bench.cu:297-307
+    r = np.hypot(x.astype(np.float64), y.astype(np.float64))
+    assert r.min() >= 200.0 * (1 - 1e-6) and r.max() <= 1700.0 * (1 + 1e-6)
+    assert np.all(np.abs(z) <= 0.5 * r * 0.05 * (1 + 1e-5))
+    vmag = np.sqrt(0.5 * (50000.0 + r * 100.0) / r)
+    assert np.allclose(np.hypot(vx, vy), vmag, rtol=1e-5)
+    assert np.all(x * vy - y * vx > 0)              # all rotate the same way
+    assert np.all(np.abs(vz) <= 1.0)
+
+
+def test_ic_bad_args(pkg):
+    with pytest.raises(ValueError):
+        pkg.plummer(0)

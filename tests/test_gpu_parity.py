@@ -1,0 +1,292 @@
+"""GPU parity tests: every stage of the HIP path (through the C-ABI) against the CPU oracle
+on identical seeded inputs.  Integer / index / byte results are compared bit for bit; floating
+point tolerances are written next to each assert.
+
+The reference (nbody_v5_bench.cu) has no tests of its own; the cases follow SURVEY.md §4.
+"""
+import numpy as np
+import pytest
+
+from helpers import oracle_pipeline, oparams, special_ics
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 64, 65, 1000, 4096, 65536]
+
+
+def _engine(pkg, ic, **kw):
+    n = len(ic[0])
+    e = pkg.Engine(n, **kw)
+    e.upload(*ic)
+    return e
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_bbox_bit_exact(pkg, orc, n):
+    ic = pkg.plummer(n, seed=7)
+    e = _engine(pkg, ic)
+    e.bbox()
+    gb = e.download_bounds()
+    ob = orc.bbox(*ic[:3])
+    assert gb.tobytes() == ob.tobytes()
+    e.close()
+
+
+@pytest.mark.parametrize("key_bits", [63, 30])
+@pytest.mark.parametrize("n", [1, 65, 4096, 65536])
+def test_keys_bit_exact(pkg, orc, n, key_bits):
+    ic = pkg.plummer(n, seed=11)
+    e = _engine(pkg, ic, key_bits=key_bits, max_depth=key_bits // 3)
+    e.bbox(); e.morton()
+    gk = e.download_keys()
+    b = orc.bbox(*ic[:3])
+    ok = orc.keys(*ic[:3], b, key_bits)
+    assert np.array_equal(gk, ok)
+    if key_bits == 30:  # reference-literal Morton code (nbody_v5_bench.cu:42-63)
+        codes, idx = orc.morton30(*ic[:3], b)
+        assert np.array_equal(gk.astype(np.uint32), codes)
+        assert np.array_equal(idx, np.arange(n))
+    e.close()
+
+
+@pytest.mark.parametrize("key_bits", [63, 30])
+@pytest.mark.parametrize("n", [1, 2, 65, 4096, 4097, 65536, 300001])
+def test_sort_stable_permutation(pkg, orc, n, key_bits):
+    ic = pkg.plummer(n, seed=3)
+    e = _engine(pkg, ic, key_bits=key_bits, max_depth=key_bits // 3)
+    e.bbox(); e.morton(); e.sort()
+    gk = e.download_keys()
+    order = e.download_order()
+    b = orc.bbox(*ic[:3])
+    sk, perm = orc.sort(orc.keys(*ic[:3], b, key_bits))
+    assert np.array_equal(gk, sk)                    # ascending keys
+    assert np.array_equal(order, perm)               # stable: identical permutation
+    bodies = e.download_sorted_bodies()
+    assert np.array_equal(bodies[:, 0], ic[0][perm])  # physical gather
+    assert np.array_equal(bodies[:, 3], ic[6][perm])
+    e.close()
+
+
+def _check_tree(pkg, orc, ic, **kw):
+    e = _engine(pkg, ic, **kw)
+    e.tree_stages()
+    rec = e.download_tree()
+    st = e.stats()
+    p = oparams(orc, e.params)
+    o = oracle_pipeline(orc, ic, p)
+    orec = o["rec"]
+    assert st.status_flags == 0
+    assert len(rec) == len(orec) == st.n_entries
+    assert st.n_internal == o["n_internal"]
+    assert st.max_level == o["max_level"]
+    for f in ("kind", "first", "count"):
+        assert np.array_equal(rec[f], orec[f]), f
+    assert rec["s"].tobytes() == orec["s"].tobytes()
+    # centres of mass: GPU = fp64 prefix differences, oracle = fp64 per-cell sums, both rounded
+    # once to fp32 -> agree to 2 ulp of the coordinate scale; masses to 1 ulp
+    scale = max(float(np.abs(o["xyzm"][:, :3]).max()), 1.0)
+    tol = 4 * np.finfo(np.float32).eps * scale
+    for f in ("x", "y", "z"):
+        assert np.abs(rec[f] - orec[f]).max() <= tol, f
+    assert np.all(np.abs(rec["m"] - orec["m"]) <= 2 * np.finfo(np.float32).eps * np.abs(orec["m"]))
+    body = rec["kind"] == pkg.KIND_BODY
+    for f in ("x", "y", "z", "m"):  # body records are copies: exact
+        assert np.array_equal(rec[f][body], orec[f][body])
+    return e, rec, o, p
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_tree_topology_and_com(pkg, orc, n):
+    e, *_ = _check_tree(pkg, orc, pkg.plummer(n, seed=5))
+    e.close()
+
+
+@pytest.mark.parametrize("kw", [dict(leaf_cap=4), dict(leaf_cap=16), dict(max_depth=3),
+                                dict(max_depth=0), dict(key_bits=30, max_depth=10),
+                                dict(key_bits=30, max_depth=10, leaf_cap=8)])
+def test_tree_variants(pkg, orc, kw):
+    e, *_ = _check_tree(pkg, orc, pkg.plummer(5000, seed=9), **kw)
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["coincident", "collinear", "outlier", "pairs", "tiny", "grid", "zero_mass"])
+def test_tree_edge_cases(pkg, orc, name):
+    ic = special_ics(name, 777, np.random.default_rng(1))
+    e, *_ = _check_tree(pkg, orc, ic)
+    e.close()
+
+
+def _strict_force_check(pkg, orc, ic, **kw):
+    """strict_fp kernel vs the oracle walking THE GPU'S OWN tree in the same (batched) order:
+    identical interactions in identical order with identical IEEE arithmetic -> bit-exact."""
+    e = _engine(pkg, ic, strict_fp=1, **kw)
+    e.tree_stages()
+    e.force_count()
+    rec = e.download_tree()
+    bodies = e.download_sorted_bodies()
+    order = e.download_order()
+    p = oparams(orc, e.params)
+    oacc, V, O, P = orc.force(rec, bodies, p, orc.ORDER_BATCHED)
+    ax, ay, az = e.download_acc()
+    gV, gO, gP = e.download_counters()
+    assert np.array_equal(ax[order], oacc[:, 0])
+    assert np.array_equal(ay[order], oacc[:, 1])
+    assert np.array_equal(az[order], oacc[:, 2])
+    assert np.array_equal(gV[order], V)
+    assert np.array_equal(gO[order], O)
+    assert np.array_equal(gP[order], P)
+    st = e.stats()
+    assert st.count_V == int(V.sum()) and st.count_O == int(O.sum()) and st.count_P == int(P.sum())
+    assert st.status_flags == 0
+    return e, oacc, order
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 4096, 65536])
+def test_force_strict_bit_exact(pkg, orc, n):
+    e, *_ = _strict_force_check(pkg, orc, pkg.plummer(n, seed=42))
+    e.close()
+
+
+@pytest.mark.parametrize("theta", [0.0, 0.3, 1.0])
+def test_force_strict_theta(pkg, orc, theta):
+    e, *_ = _strict_force_check(pkg, orc, pkg.plummer(3000, seed=2), theta=theta)
+    e.close()
+
+
+@pytest.mark.parametrize("kw", [dict(leaf_cap=8), dict(max_depth=4), dict(key_bits=30, max_depth=10)])
+def test_force_strict_variants(pkg, orc, kw):
+    e, *_ = _strict_force_check(pkg, orc, pkg.plummer(5000, seed=4), **kw)
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["coincident", "collinear", "outlier", "pairs", "tiny", "grid", "zero_mass"])
+def test_force_strict_edge_cases(pkg, orc, name):
+    e, *_ = _strict_force_check(pkg, orc, special_ics(name, 777, np.random.default_rng(1)))
+    e.close()
+
+
+@pytest.mark.parametrize("n,theta", [(4096, 0.5), (65536, 0.5), (65536, 0.3)])
+def test_force_fast_vs_oracle(pkg, orc, n, theta):
+    """Default (fast) kernel: fma + v_rsq_f32 instead of sqrtf and '/'.  Stated fp32 tolerance:
+    relative deviation |a_gpu - a_oracle| / |a_oracle| has median <= 2e-6 and max <= 2e-4
+    (a MAC decision can flip on a 1-ulp tie; the flipped cell then differs by the
+    Barnes-Hut truncation error of one cell, far below the method's own ~1e-3 error)."""
+    ic = pkg.plummer(n, seed=42)
+    e = _engine(pkg, ic, theta=theta)
+    e.tree_stages(); e.force()
+    ax, ay, az = e.download_acc()
+    p = oparams(orc, e.params)
+    o = oracle_pipeline(orc, ic, p)
+    oacc, *_ = orc.force(o["rec"], o["xyzm"], p, orc.ORDER_PREORDER)
+    oa = np.zeros((n, 3), np.float32)
+    oa[o["perm"]] = oacc[:, :3]
+    ga = np.stack([ax, ay, az], 1)
+    rel = np.linalg.norm(ga - oa, axis=1) / np.linalg.norm(oa, axis=1)
+    assert np.median(rel) <= 2e-6
+    assert rel.max() <= 2e-4
+    e.close()
+
+
+def test_force_theta0_is_direct_sum(pkg, orc):
+    """theta = 0 opens every cell: the traversal must touch every body exactly once."""
+    n = 2048
+    ic = pkg.plummer(n, seed=8)
+    e = _engine(pkg, ic, theta=0.0)
+    e.tree_stages(); e.force_count()
+    gV, gO, gP = e.download_counters()
+    assert np.all(gP == n)
+    ax, ay, az = e.download_acc()
+    xyzm = np.stack([ic[0], ic[1], ic[2], ic[6]], 1)
+    d = orc.direct_f64(xyzm, e.params.G, e.params.eps2)
+    rel = np.linalg.norm(np.stack([ax, ay, az], 1) - d, axis=1) / np.linalg.norm(d, axis=1)
+    assert rel.max() <= 2e-5  # fp32 accumulation of 2048 terms
+    e.close()
+
+
+@pytest.mark.parametrize("n", [1, 1000, 65536])
+def test_integrate_bit_exact(pkg, orc, n):
+    ic = pkg.plummer(n, seed=6)
+    e = _engine(pkg, ic, max_speed=20.0)  # low clamp so the speed-limit branch is exercised
+    e.tree_stages(); e.force()
+    bodies = e.download_sorted_bodies()
+    order = e.download_order()
+    ax, ay, az = e.download_acc()
+    acc4 = np.zeros((n, 4), np.float32)
+    acc4[:, 0] = ax[order]; acc4[:, 1] = ay[order]; acc4[:, 2] = az[order]
+    vel = np.stack([ic[3], ic[4], ic[5]], 1)[order]
+    p = oparams(orc, e.params)
+    oxyzm, ovel = orc.integrate(bodies, vel, acc4, p)
+    speed = np.linalg.norm(ovel, axis=1)
+    if n >= 1000:
+        assert (speed >= 20.0 * 0.999).any(), "clamp branch not exercised"
+    e.integrate()
+    x, y, z, vx, vy, vz = e.download()
+    assert np.array_equal(x[order], oxyzm[:, 0])
+    assert np.array_equal(y[order], oxyzm[:, 1])
+    assert np.array_equal(z[order], oxyzm[:, 2])
+    assert np.array_equal(vx[order], ovel[:, 0])
+    assert np.array_equal(vy[order], ovel[:, 1])
+    assert np.array_equal(vz[order], ovel[:, 2])
+    e.close()
+
+
+@pytest.mark.parametrize("n,steps", [(4096, 100), (65536, 10)])
+def test_steps_end_to_end(pkg, orc, n, steps):
+    """K whole steps, Plummer sphere, theta = 0.5 (BASELINE config 1 at 65,536).
+    Tolerance after K steps (positions in units where the sphere has a = 400, velocities ~10):
+    strict kernel max |dx| <= 2e-3 and |dv| <= 2e-3; fast kernel max |dx| <= 1e-2, |dv| <= 1e-2."""
+    ic = pkg.plummer(n, seed=42)
+    o = orc.Oracle(n)
+    o.upload(*ic)
+    o.step(steps, order=orc.ORDER_BATCHED)
+    ref = np.stack(o.download(), 1)
+    for strict, tol in ((1, 2e-3), (0, 1e-2)):
+        e = _engine(pkg, ic, strict_fp=strict)
+        e.step(steps)
+        got = np.stack(e.download(), 1)
+        st = e.stats()
+        assert st.status_flags == 0 and st.steps == steps
+        assert np.abs(got[:, :3] - ref[:, :3]).max() <= tol, strict
+        assert np.abs(got[:, 3:] - ref[:, 3:]).max() <= tol, strict
+        e.close()
+    o.close()
+
+
+def test_stage_order_errors(pkg):
+    ic = pkg.plummer(100, seed=1)
+    e = pkg.Engine(100)
+    with pytest.raises(pkg.BhError):
+        e.step()            # nothing uploaded
+    e.upload(*ic)
+    with pytest.raises(pkg.BhError):
+        e.morton()          # bbox first
+    e.bbox(); e.morton(); e.sort()
+    with pytest.raises(pkg.BhError):
+        e.sort()            # sorting twice would permute twice
+    with pytest.raises(pkg.BhError):
+        e.force()           # build/com first
+    e.build(); e.com(); e.force(); e.integrate()
+    with pytest.raises(pkg.BhError):
+        e.integrate()       # force first
+    e.close()
+    with pytest.raises(pkg.BhError):
+        pkg.Engine(0)
+    with pytest.raises(pkg.BhError):
+        pkg.Engine(10, eps2=0.0)
+    with pytest.raises(pkg.BhError):
+        pkg.Engine(10, key_bits=48)
+
+
+def test_force_range_matches_full(pkg):
+    n = 10000
+    ic = pkg.plummer(n, seed=12)
+    e = _engine(pkg, ic)
+    e.tree_stages(); e.force()
+    full = np.stack(e.download_acc(), 1)
+    e2 = _engine(pkg, ic)
+    e2.tree_stages()
+    for lo, hi in ((0, 2500), (2500, 2501), (2501, 7777), (7777, n)):
+        e2.force(lo, hi)
+    part = np.stack(e2.download_acc(), 1)
+    assert np.array_equal(full, part)
+    e.close(); e2.close()
