@@ -144,7 +144,17 @@ int bh_sync(bh_ctx* c);
 /* acc is float4[n] (ax,ay,az,unused) in Morton-sorted order; an all-gather of the
    per-rank [lo,hi) slabs straight into this buffer completes the exchange step. */
 int bh_device_acc(bh_ctx* c, void** dptr, int64_t* bytes);
+/* make the engine write/read accelerations in a caller-owned device buffer of at least
+   n float4 (e.g. a torch tensor that is also the all-gather output); NULL restores the
+   engine's own buffer.  The caller keeps the buffer alive while it is bound. */
+int bh_bind_acc(bh_ctx* c, void* device_float4_n);
 int bh_n(const bh_ctx* c);
+
+/* per-step device times (hipEvent pairs recorded on the context's stream while
+   bh_set_timing is on) of the most recent steps, oldest first: ms_force[i], ms_step[i].
+   Synchronises.  At most BH_TIMING_RING steps are kept. */
+#define BH_TIMING_RING 256
+int bh_timing_history(bh_ctx* c, float* ms_force, float* ms_step, int capacity, int* count);
 
 /* ---- synthetic initial conditions (host side; <-> IC loop ref:294-308) ---- */
 /* Plummer sphere, scale radius a, masses U[2,7) (same law as ref:302), counter-based

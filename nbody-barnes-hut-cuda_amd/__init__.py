@@ -10,5 +10,7 @@ from ._lib import lib, BhParams, BhNode, BhStats, LIB_PATH  # noqa: F401
 from .engine import Engine, BhError, default_params, KIND_BODY, KIND_INTERNAL, KIND_MULTI  # noqa: F401
 from .ic import plummer, disc  # noqa: F401
 
+# `dist` (multi-GPU stepping) imports torch; import it explicitly: from <pkg> import dist
+
 __all__ = ["Engine", "BhError", "default_params", "plummer", "disc", "BhParams", "BhNode",
            "BhStats", "KIND_BODY", "KIND_INTERNAL", "KIND_MULTI", "LIB_PATH"]

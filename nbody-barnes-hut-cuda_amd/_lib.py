@@ -75,6 +75,8 @@ SYMBOLS = [
     ("bh_set_timing", C.c_int, [_P, C.c_int]),
     ("bh_sync", C.c_int, [_P]),
     ("bh_device_acc", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    ("bh_bind_acc", C.c_int, [_P, _P]),
+    ("bh_timing_history", C.c_int, [_P, _F, _F, C.c_int, C.POINTER(C.c_int)]),
     ("bh_n", C.c_int, [_P]),
     ("bh_ic_plummer", C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_float] + [_F] * 7),
     ("bh_ic_disc", C.c_int, [C.c_int, C.c_uint64, C.c_float] + [_F] * 7),

@@ -70,15 +70,18 @@ int bh_n(const bh_ctx* c) { return c ? c->n : 0; }
 static void free_all(bh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc, c->stage_buf,
+  void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->bbox_partial,
                   c->bounds, c->pa, c->pb, c->pn,
                   c->cb, c->rec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  for (int i = 0; i < 8; i++)
-    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->evring) {
+    for (int i = 0; i < BH_TIMING_RING * 8; i++)
+      if (c->evring[i]) (void)hipEventDestroy(c->evring[i]);
+    free(c->evring);
+  }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -132,7 +135,8 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   bool ok = true;
   ok = ok && dalloc(&c->posm[0], N) == hipSuccess && dalloc(&c->posm[1], N) == hipSuccess;
   ok = ok && dalloc(&c->velid[0], N) == hipSuccess && dalloc(&c->velid[1], N) == hipSuccess;
-  ok = ok && dalloc(&c->acc, N) == hipSuccess;
+  ok = ok && dalloc(&c->acc_own, N) == hipSuccess;
+  c->acc = c->acc_own;
   ok = ok && dalloc(&c->stage_buf, 7 * N) == hipSuccess;
   ok = ok && dalloc(&c->keys[0], N) == hipSuccess && dalloc(&c->keys[1], N) == hipSuccess;
   ok = ok && dalloc(&c->vals[0], N) == hipSuccess && dalloc(&c->vals[1], N) == hipSuccess;
@@ -150,7 +154,6 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && hipMalloc(&c->scan_tmp, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && dalloc(&c->cV, N) == hipSuccess && dalloc(&c->cO, N) == hipSuccess &&
        dalloc(&c->cP, N) == hipSuccess;
-  for (int i = 0; ok && i < 8; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
   if (!ok) {
     free_all(c);
     return BH_ERR_OOM;
@@ -185,8 +188,13 @@ int bh_sync(bh_ctx* c) {
 
 int bh_set_timing(bh_ctx* c, int on) {
   if (!c) return BH_ERR_BAD_ARG;
+  if (on && !c->evring) {
+    c->evring = (hipEvent_t*)calloc((size_t)BH_TIMING_RING * 8, sizeof(hipEvent_t));
+    if (!c->evring) return BH_ERR_OOM;
+    for (int i = 0; i < BH_TIMING_RING * 8; i++) BH_HIP(c, hipEventCreate(&c->evring[i]));
+  }
   c->timing = on != 0;
-  c->timed_valid = false;
+  c->timed_steps = 0;
   return BH_OK;
 }
 
@@ -311,7 +319,8 @@ int bh_force_count(bh_ctx* c) {
 int bh_step(bh_ctx* c) {
   BH_NEED(c, BH_ST_UPLOADED);
   const bool t = c->timing;
-#define BH_MARK(i) if (t) BH_HIP(c, hipEventRecord(c->ev[i], c->stream))
+  hipEvent_t* ev = t ? c->evring + (size_t)(c->timed_steps % BH_TIMING_RING) * 8 : nullptr;
+#define BH_MARK(i) if (t) BH_HIP(c, hipEventRecord(ev[i], c->stream))
   BH_MARK(0);
   BH_HIP(c, bhk_bbox(c));                      // ref:259
   BH_MARK(1);
@@ -329,7 +338,7 @@ int bh_step(bh_ctx* c) {
   BH_HIP(c, bhk_integrate(c));                 // ref:282
   BH_MARK(7);
 #undef BH_MARK
-  c->timed_valid = t;
+  if (t) c->timed_steps++;
   c->stage = BH_ST_UPLOADED;
   c->ever |= BH_ST_BBOX | BH_ST_MORTON | BH_ST_SORT | BH_ST_BUILD | BH_ST_COM | BH_ST_FORCE;
   c->steps++;
@@ -451,16 +460,42 @@ int bh_get_stats(bh_ctx* c, bh_stats* st) {
   st->max_level = hi.max_level;
   st->status_flags = hi.flags;
   st->steps = c->steps;
-  if (c->timed_valid) {
+  if (c->timing && c->timed_steps > 0) {
+    hipEvent_t* ev = c->evring + (size_t)((c->timed_steps - 1) % BH_TIMING_RING) * 8;
     float* ms[7] = {&st->ms_bbox, &st->ms_morton, &st->ms_sort, &st->ms_build,
                     &st->ms_com, &st->ms_force, &st->ms_integrate};
-    for (int i = 0; i < 7; i++) BH_HIP(c, hipEventElapsedTime(ms[i], c->ev[i], c->ev[i + 1]));
-    BH_HIP(c, hipEventElapsedTime(&st->ms_step, c->ev[0], c->ev[7]));
+    for (int i = 0; i < 7; i++) BH_HIP(c, hipEventElapsedTime(ms[i], ev[i], ev[i + 1]));
+    BH_HIP(c, hipEventElapsedTime(&st->ms_step, ev[0], ev[7]));
   }
   st->count_V = c->tV;
   st->count_O = c->tO;
   st->count_P = c->tP;
   if (hi.flags & BH_FLAG_POOL_OVERFLOW) return BH_ERR_POOL_OVERFLOW;
+  return BH_OK;
+}
+
+int bh_timing_history(bh_ctx* c, float* ms_force, float* ms_step, int capacity, int* count) {
+  if (!c || !count) return BH_ERR_BAD_ARG;
+  *count = 0;
+  if (!c->timing || c->timed_steps == 0) return BH_OK;
+  int s = bh_sync(c);
+  if (s) return s;
+  const long have = c->timed_steps < BH_TIMING_RING ? c->timed_steps : BH_TIMING_RING;
+  const long take = have < capacity ? have : capacity;
+  for (long i = 0; i < take; i++) {
+    const long step = c->timed_steps - take + i;
+    hipEvent_t* ev = c->evring + (size_t)(step % BH_TIMING_RING) * 8;
+    if (ms_force) BH_HIP(c, hipEventElapsedTime(&ms_force[i], ev[5], ev[6]));
+    if (ms_step) BH_HIP(c, hipEventElapsedTime(&ms_step[i], ev[0], ev[7]));
+  }
+  *count = (int)take;
+  return BH_OK;
+}
+
+int bh_bind_acc(bh_ctx* c, void* device_float4_n) {
+  if (!c) return BH_ERR_BAD_ARG;
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  c->acc = device_float4_n ? (float4*)device_float4_n : c->acc_own;
   return BH_OK;
 }
 

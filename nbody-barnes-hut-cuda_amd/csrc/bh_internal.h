@@ -48,7 +48,8 @@ struct bh_ctx {
   float4* posm[2];   // (x,y,z,m)           ping-pong (gather target)
   float4* velid[2];  // (vx,vy,vz,bits(id))  ping-pong
   int cur;
-  float4* acc;       // (ax,ay,az,0)
+  float4* acc;       // (ax,ay,az,0) — engine-owned or caller-bound (bh_bind_acc)
+  float4* acc_own;
   float* stage_buf;  // 7n floats: SoA staging for upload/download
 
   // keys
@@ -84,8 +85,8 @@ struct bh_ctx {
 
   // timing
   bool timing;
-  bool timed_valid;
-  hipEvent_t ev[8];
+  hipEvent_t* evring;  // [BH_TIMING_RING][8], created by the first bh_set_timing(1)
+  long timed_steps;    // steps recorded into the ring since timing was switched on
 };
 
 #define BH_BBOX_BLOCKS 1024

@@ -174,7 +174,21 @@ class Engine:
         self._ck(lib.bh_get_stats(self._h, C.byref(s)), "bh_get_stats")
         return s
 
+    def timing_history(self):
+        """-> (ms_force[], ms_step[]) of the most recent timed steps (hipEvent, engine stream)."""
+        cap = 256
+        f = np.empty(cap, np.float32)
+        t = np.empty(cap, np.float32)
+        cnt = C.c_int(0)
+        self._ck(lib.bh_timing_history(self._h, f.ctypes.data_as(_F), t.ctypes.data_as(_F), cap,
+                                       C.byref(cnt)), "bh_timing_history")
+        return f[:cnt.value].copy(), t[:cnt.value].copy()
+
     # -- multi-rank plumbing
+    def bind_acc(self, device_ptr):
+        """use a caller-owned device buffer (>= n float4) for the accelerations"""
+        self._ck(lib.bh_bind_acc(self._h, C.c_void_p(int(device_ptr) if device_ptr else None)), "bh_bind_acc")
+
     def device_acc(self):
         """(device pointer, bytes) of the float4[n] acceleration buffer (Morton order)."""
         p = C.c_void_p()
