@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="fast force kernel: 0 scalar DFS (default), 1 batched")
+    ap.add_argument("--xcd-mode", type=int, default=0, help="tuning: block->chunk placement (bh_params.xcd_mode)")
+    ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,7 +109,9 @@ def main():
     ic = pkg.plummer(n_total, seed=args.seed)  # identical on every rank (counter-based RNG)
 
     from nbody_barnes_hut_cuda_amd import dist as bhdist
-    eng, stepper = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta)
+    eng, stepper = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
+                                           force_variant=args.variant, xcd_mode=args.xcd_mode,
+                                           leaf_cap=args.leaf_cap)
     eng.upload(*ic)
 
     def barrier():
@@ -161,7 +166,8 @@ def main():
             roofline = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "force_kernel<false,false>", "avg_launch_ms": avg_force_ms,
+                "kernel": "force_fast_kernel" if args.variant != 1 else "force_batched_kernel",
+                "avg_launch_ms": avg_force_ms,
                 "launches_timed": int(len(f_ms)),
                 "algorithmic_bytes_per_launch": bytes_alg,
                 "per_body": {"V": V / n_total, "O": O / n_total, "P": P / n_total,

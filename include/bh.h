@@ -57,7 +57,13 @@ typedef struct bh_params {
   int32_t strict_fp;  /* 0: fast force kernel (fma + v_rsq_f32);
                          1: force arithmetic exactly as the reference source text
                             in IEEE fp32 (sqrtf, '/', no contraction; ref:203-213) */
-  int32_t reserved[7];
+  int32_t force_variant; /* fast force kernel: 0 = scalar-load depth-first kernel (default,
+                            fastest measured), 1 = batched kernel (LDS work list, prefetched
+                            vector loads; kept for A/B — see DESIGN.md)                       */
+  int32_t xcd_mode;      /* fast force kernels, block -> body-chunk placement (speed only):
+                            0 = one contiguous eighth of the Morton order per XCD, 1 = identity,
+                            2 = runs of 16 chunks per XCD dealt round-robin                       */
+  int32_t reserved[5];
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:
@@ -71,7 +77,8 @@ typedef struct bh_params {
 typedef struct bh_node {
   float x, y, z;  /* centre of mass (ref:22 comX..Z after finalizeCOM ref:175-189) */
   float m;        /* total mass (ref:21)                                           */
-  float s;        /* cell edge length used by the MAC (ref:208 maxX-minX); 0 for a body */
+  float s;        /* cell edge length used by the MAC (ref:208 maxX-minX); -1 for a body, so
+                     that `s/dist < theta` accepts it for every theta >= 0 (ref:208 `idx < n`) */
   int32_t first;
   int32_t count;
   int32_t kind;

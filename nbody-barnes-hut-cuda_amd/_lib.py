@@ -17,7 +17,8 @@ class BhParams(C.Structure):
         ("G", C.c_float), ("theta", C.c_float), ("dt", C.c_float), ("eps2", C.c_float),
         ("max_speed", C.c_float),
         ("leaf_cap", C.c_int32), ("max_depth", C.c_int32), ("key_bits", C.c_int32),
-        ("strict_fp", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("strict_fp", C.c_int32), ("force_variant", C.c_int32), ("xcd_mode", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 

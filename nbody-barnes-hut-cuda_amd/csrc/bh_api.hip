@@ -73,7 +73,7 @@ static void free_all(bh_ctx* c) {
   void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->bbox_partial,
                   c->bounds, c->pa, c->pb, c->pn,
-                  c->cb, c->rec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
+                  c->cb, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -140,13 +140,14 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->stage_buf, 7 * N) == hipSuccess;
   ok = ok && dalloc(&c->keys[0], N) == hipSuccess && dalloc(&c->keys[1], N) == hipSuccess;
   ok = ok && dalloc(&c->vals[0], N) == hipSuccess && dalloc(&c->vals[1], N) == hipSuccess;
-  ok = ok && dalloc(&c->hist, (size_t)256 * c->sort_tiles + 1) == hipSuccess;
+  ok = ok && dalloc(&c->hist, (size_t)256 * c->sort_tiles + 256) == hipSuccess;
   ok = ok && dalloc(&c->bbox_partial, (size_t)BH_BBOX_BLOCKS * 6) == hipSuccess;
   ok = ok && dalloc(&c->bounds, 8) == hipSuccess;
   ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->cb, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->rec, (size_t)c->rec_cap) == hipSuccess;
+  ok = ok && dalloc(&c->frec, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->er_lo, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->er_hi, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->P, N + 1) == hipSuccess;
@@ -160,6 +161,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   }
   // the record pool is read up to 3 records past a child block (force kernel): keep it defined
   if (hipMemsetAsync(c->rec, 0, (size_t)c->rec_cap * sizeof(bh_node), c->stream) != hipSuccess ||
+      hipMemsetAsync(c->frec, 0, (size_t)c->rec_cap * sizeof(bh_frec), c->stream) != hipSuccess ||
       hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream) != hipSuccess ||
       hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream) != hipSuccess) {
     free_all(c);

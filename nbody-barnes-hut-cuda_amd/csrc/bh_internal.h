@@ -9,6 +9,16 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// fast-kernel record: same block layout as bh_node, fields pre-digested by the COM stage
+struct bh_frec {
+  float x, y, z;  // centre of mass
+  float gm;       // G*m, 0 when m <= 0
+  float thr2;     // (s/theta)^2; -1 for a body or a mass<=0 record (always accepted)
+  int first;
+  int meta;       // count | (multi-body leaf ? 1<<31 : 0)
+  int pad;
+};
+
 struct bh_d4 {  // fp64 prefix-sum element: (sum m, sum m*x, sum m*y, sum m*z)
   double m, x, y, z;
 };
@@ -68,7 +78,8 @@ struct bh_ctx {
   int* pb;        // [n] end body of that cell
   int* pn;        // [n] its child count (0: j represents no emitted cell)
   int* cb;        // [n+1] exclusive scan of pn; cb[n] = records - 1
-  bh_node* rec;   // [rec_cap] tree records
+  bh_node* rec;   // [rec_cap] tree records (canonical: ABI download, strict/counting kernels)
+  bh_frec* frec;  // [rec_cap] pre-digested records for the fast force kernel (written by COM)
   int* er_lo;     // [rec_cap] body range of each record
   int* er_hi;
   int rec_cap;

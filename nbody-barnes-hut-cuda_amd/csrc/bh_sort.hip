@@ -3,7 +3,8 @@
 // Replaces thrust::sort_by_key (ref nbody_v5_bench.cu:262-264; CUB onesweep, not vendored).
 // Contract: result == stable ascending sort by key.  8-bit digits; per pass
 //   1. tile histogram (LDS integer atomics, 256 bins, tile = 256 threads x 16 keys),
-//   2. exclusive scan of the digit-major [256][ntiles] table,
+//   2. per-digit exclusive scan of the digit-major [256][ntiles] table (one block per digit);
+//      the 256 digit totals are scanned again inside every scatter block (cheap, no launch),
 //   3. stable scatter: each wave ranks its 64 keys per round with 8 wave64 ballots
 //      (match-any on the digit bits) against a wave-private LDS digit counter; the four
 //      waves' counters are then offset in wave order, which keeps the sort stable.
@@ -33,40 +34,46 @@ __global__ __launch_bounds__(kThreads) void sort_hist_kernel(const u64* __restri
   hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// single block exclusive scan of `total` u32 (digit-major table), in place
-__global__ __launch_bounds__(1024) void sort_scan_kernel(u32* __restrict__ hist, int total) {
-  __shared__ u32 wsum[16];
+// one block per digit: exclusive scan of that digit's row hist[digit][0..ntiles) in place;
+// the row total goes to tot[digit] (the scatter kernel turns the 256 totals into digit bases)
+__global__ __launch_bounds__(kThreads) void sort_rowscan_kernel(u32* __restrict__ hist, int ntiles,
+                                                                u32* __restrict__ tot) {
+  __shared__ u32 wsum[4];
+  u32* row = hist + (size_t)blockIdx.x * ntiles;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int per = (total + 1023) / 1024;
-  const int i0 = t * per;
-  u32 s = 0;
-  for (int k = 0; k < per; k++)
-    if (i0 + k < total) s += hist[i0 + k];
-  u32 incl = s;
+  u32 carry = 0;
+  for (int c0 = 0; c0 < ntiles; c0 += kThreads) {
+    const int i = c0 + t;
+    const u32 v = (i < ntiles) ? row[i] : 0u;
+    u32 incl = v;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    u32 v = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += v;
-  }
-  if (lane == 63) wsum[w] = incl;
-  __syncthreads();
-  u32 wp = 0;
-  for (int i = 0; i < w; i++) wp += wsum[i];
-  u32 run = wp + incl - s;
-  for (int k = 0; k < per; k++)
-    if (i0 + k < total) {
-      u32 v = hist[i0 + k];
-      hist[i0 + k] = run;
-      run += v;
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
     }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    u32 wp = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const u32 sv = wsum[q];
+      if (q < w) wp += sv;
+      total += sv;
+    }
+    __syncthreads();
+    if (i < ntiles) row[i] = carry + wp + incl - v;
+    carry += total;
+  }
+  if (t == 0) tot[blockIdx.x] = carry;
 }
 
 __global__ __launch_bounds__(kThreads) void sort_scatter_kernel(
     const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
-    u32* __restrict__ vout, int n, int shift, const u32* __restrict__ hist, int ntiles,
-    int first_pass) {
+    u32* __restrict__ vout, int n, int shift, const u32* __restrict__ hist,
+    const u32* __restrict__ tot, int ntiles, int first_pass) {
   __shared__ u32 wcnt[4][256];
   __shared__ u32 gbase[256];
+  __shared__ u32 dsum[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -110,7 +117,19 @@ __global__ __launch_bounds__(kThreads) void sort_scatter_kernel(
     wcnt[1][t] = c0;
     wcnt[2][t] = c0 + c1;
     wcnt[3][t] = c0 + c1 + c2;
-    gbase[t] = hist[t * ntiles + blockIdx.x];
+    // digit base = exclusive scan of the 256 digit totals (block scan), + this tile's row prefix
+    const u32 dv = tot[t];
+    u32 incl = dv;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
+    }
+    if (lane == 63) dsum[w] = incl;
+    __syncthreads();
+    u32 wp = 0;
+    for (int q = 0; q < w; q++) wp += dsum[q];
+    gbase[t] = wp + incl - dv + hist[(size_t)t * ntiles + blockIdx.x];
   }
   __syncthreads();
 #pragma unroll
@@ -148,16 +167,11 @@ hipError_t bhk_sort(bh_ctx* c) {
   for (int p = 0; p < passes; p++) {
     const int shift = 8 * p;
     sort_hist_kernel<<<ntiles, kThreads, 0, c->stream>>>(c->keys[src], n, shift, c->hist, ntiles);
-    const int total = 256 * ntiles;
-    if (total <= (1 << 18)) {
-      sort_scan_kernel<<<1, 1024, 0, c->stream>>>(c->hist, total);
-    } else {
-      hipError_t e = bhk_scan_i32(c, (const int*)c->hist, (int*)c->hist, total, nullptr);
-      if (e != hipSuccess) return e;
-    }
+    u32* tot = c->hist + (size_t)256 * ntiles;  // 256 digit totals behind the table
+    sort_rowscan_kernel<<<256, kThreads, 0, c->stream>>>(c->hist, ntiles, tot);
     sort_scatter_kernel<<<ntiles, kThreads, 0, c->stream>>>(c->keys[src], c->vals[src],
                                                             c->keys[src ^ 1], c->vals[src ^ 1], n,
-                                                            shift, c->hist, ntiles, p == 0);
+                                                            shift, c->hist, tot, ntiles, p == 0);
     src ^= 1;
   }
   c->key_buf = src;

@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k, in
 }
 
 // ------------------------------------------------------------------ COM
-__global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec,
+__global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_frec* __restrict__ frec,
+                                                  float G, float theta,
                                                   const int* __restrict__ er_lo,
                                                   const int* __restrict__ er_hi,
                                                   const bh_devinfo* __restrict__ info, int rec_cap,
@@ -393,6 +394,22 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec,
   }
   // x,y,z,m are the first 16 bytes of the record
   *reinterpret_cast<float4*>(&rec[e]) = o;
+  // digest for the fast force kernel (see bh_force.hip)
+  const bh_node r = rec[e];
+  bh_frec fr;
+  fr.x = o.x; fr.y = o.y; fr.z = o.z;
+  const bool massive = o.w > 0.0f;  // ref:203: records with mass <= 0 are skipped
+  fr.gm = massive ? G * o.w : 0.0f;
+  if (!massive || r.kind == BH_KIND_BODY) {
+    fr.thr2 = -1.0f;
+  } else {
+    const float t = r.s / theta;  // theta = 0 -> +inf: never accepted
+    fr.thr2 = t * t;
+  }
+  fr.first = r.first;
+  fr.meta = r.count | (r.kind == BH_KIND_MULTI ? (int)0x80000000 : 0);
+  fr.pad = 0;
+  frec[e] = fr;
 }
 
 }  // namespace
@@ -436,7 +453,7 @@ hipError_t bhk_com(bh_ctx* c) {
   hipError_t e = bhk_scan_pm(c, c->posm[c->cur], c->P, n);
   if (e != hipSuccess) return e;
   const int blocks = (c->rec_cap + 255) / 256;
-  com_kernel<<<blocks, 256, 0, c->stream>>>(c->rec, c->er_lo, c->er_hi, c->info, c->rec_cap,
+  com_kernel<<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info, c->rec_cap,
                                             c->posm[c->cur], c->P);
   return hipGetLastError();
 }

@@ -18,9 +18,18 @@ import torch
 import torch.distributed as dist
 
 
-def slab_bounds(n, world, rank):
-    """Morton slab of `rank`: equal padded slabs, the last one may be short."""
+SLAB_ALIGN = 256  # one force-kernel block: slab starts stay wave-aligned, so every wave holds the
+                  # same 64 bodies as in the 1-rank run (bit-identical results for every kernel variant)
+
+
+def slab_size(n, world):
     slab = (n + world - 1) // world
+    return (slab + SLAB_ALIGN - 1) // SLAB_ALIGN * SLAB_ALIGN
+
+
+def slab_bounds(n, world, rank):
+    """Morton slab of `rank`: equal 256-aligned slabs, trailing ones may be short or empty."""
+    slab = slab_size(n, world)
     lo = min(n, rank * slab)
     hi = min(n, lo + slab)
     return slab, lo, hi
@@ -68,7 +77,7 @@ def make_gpu_stepper(pkg, n, params=None, device=None, group=None, **kw):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if device is None:
         device = torch.cuda.current_device()
-    slab = (n + world - 1) // world
+    slab = slab_size(n, world)
     acc = torch.zeros((world * slab, 4), dtype=torch.float32, device=f"cuda:{device}")
     stream = torch.cuda.current_stream(device).cuda_stream
     eng = pkg.Engine(n, params=params, device=device, stream=stream, **kw)

@@ -700,3 +700,61 @@ void bho_last_counts(const bho_state* s, uint64_t* V, uint64_t* O, uint64_t* P, 
 }
 
 void bho_last_times(const bho_state* s, double t[7]) { memcpy(t, s->t, sizeof(s->t)); }
+
+/* ------------------------------------------------------------------ analysis helper */
+/* Work a group of `group` consecutive sorted bodies does when it walks ONE shared traversal
+   (the GPU kernel's scheme): a record is evaluated by the group if any member evaluates it.
+   Returns per group: records evaluated, blocks popped, multi-leaf bodies streamed. Not part of
+   the recurrence — used by tools/ and tests to size the kernel's lane efficiency. */
+typedef struct { const bho_node* rec; const float* xyzm; const bho_params* p; int g0, g1;
+                 uint64_t recs, pops, leafbodies; } gctx;
+
+static void group_walk(gctx* c, int first, int count, const uint8_t* active_in) {
+  uint8_t want[8][64];
+  int opened[8], no = 0;
+  const int G = c->g1 - c->g0;
+  c->pops++;
+  for (int k = 0; k < count; k++) {
+    const bho_node* r = &c->rec[first + k];
+    if (r->m <= 0.0f) continue;
+    c->recs++;
+    int any = 0;
+    for (int l = 0; l < G; l++) {
+      want[no][l] = 0;
+      if (!active_in[l]) continue;
+      const float* q = &c->xyzm[4 * (size_t)(c->g0 + l)];
+      float dx = r->x - q[0], dy = r->y - q[1], dz = r->z - q[2];
+      float dist = sqrtf(dx * dx + dy * dy + dz * dz + c->p->eps2);
+      if (r->kind != BHO_KIND_BODY && !(r->s / dist < c->p->theta)) { want[no][l] = 1; any = 1; }
+    }
+    if (any) {
+      if (r->kind == BHO_KIND_MULTI) c->leafbodies += (uint64_t)r->count;
+      else opened[no++] = first + k;
+    }
+  }
+  /* copy masks: recursion reuses the stack frame arrays */
+  for (int i = no - 1; i >= 0; i--) {
+    uint8_t m[64];
+    memcpy(m, want[i], 64);
+    group_walk(c, c->rec[opened[i]].first, c->rec[opened[i]].count, m);
+  }
+}
+
+void bho_group_stats(const bho_node* rec, const float* xyzm, int n, const bho_params* p, int group,
+                     int stride, uint64_t* recs, uint64_t* pops, uint64_t* leafbodies, uint64_t* groups) {
+  uint64_t R = 0, Pp = 0, Lb = 0, Gn = 0;
+  const int ngroups = (n + group - 1) / group;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : R, Pp, Lb, Gn)
+  for (int g = 0; g < ngroups; g += stride) {
+    gctx c;
+    c.rec = rec; c.xyzm = xyzm; c.p = p;
+    c.g0 = g * group;
+    c.g1 = c.g0 + group < n ? c.g0 + group : n;
+    c.recs = c.pops = c.leafbodies = 0;
+    uint8_t act[64];
+    memset(act, 1, 64);
+    group_walk(&c, 0, 1, act);
+    R += c.recs; Pp += c.pops; Lb += c.leafbodies; Gn += 1;
+  }
+  *recs = R; *pops = Pp; *leafbodies = Lb; *groups = Gn;
+}

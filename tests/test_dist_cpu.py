@@ -1,0 +1,65 @@
+"""Multi-rank path on CPU (gloo, world_size 2 and 3): the product's ShardedStepper — Morton-slab
+sharding of the force stage + one all-gather of accelerations per step — must reproduce the
+single-rank result bit for bit, and all replicas must stay identical.  (The reference has no
+multi-GPU path; this is the new design of SURVEY §8e.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(world, n, steps, tmp_path):
+    out = str(tmp_path / f"w{world}.npz")
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(steps)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT,
+                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return np.load(out)
+
+
+def test_slab_bounds(pkg):
+    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    for n in (1, 255, 256, 257, 3000, 1_000_000, 8_000_000):
+        for world in (1, 2, 3, 4, 8):
+            slab = bhdist.slab_size(n, world)
+            assert slab % 256 == 0 and slab * world >= n
+            covered = 0
+            prev_hi = 0
+            for r in range(world):
+                s, lo, hi = bhdist.slab_bounds(n, world, r)
+                assert s == slab and lo == min(n, r * slab) and lo == prev_hi and lo % 64 == 0 or lo == n
+                covered += hi - lo
+                prev_hi = hi
+            assert covered == n and prev_hi == n
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_equals_single_rank(orc, tmp_path, world):
+    n, steps = 3000, 3
+    ref = _run(1, n, steps, tmp_path)
+    got = _run(world, n, steps, tmp_path)
+    assert int(got["world"]) == world and int(got["replicas_identical"]) == 1
+    assert np.array_equal(ref["state"], got["state"])
+    # and the single-rank stepper equals the oracle's own step loop
+    import bhpkg
+    pkg = bhpkg.load()
+    o = orc.Oracle(n)
+    o.upload(*pkg.plummer(n, seed=42))
+    o.step(steps, order=orc.ORDER_PREORDER)
+    assert np.array_equal(np.stack(o.download(), 1), ref["state"])
