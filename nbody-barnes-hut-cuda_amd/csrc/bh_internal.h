@@ -74,6 +74,7 @@ struct bh_ctx {
   float* bounds;        // [8]: min xyz, min+size xyz, s0, pad
 
   // tree build temporaries
+  signed char* d8;  // [n+1] leading octal digits shared by keys j-1, j; d8[0] = d8[n] = -1
   int* pa;        // [n] first body of the cell whose first child boundary is j
   int* pb;        // [n] end body of that cell
   int* pn;        // [n] its child count (0: j represents no emitted cell)

@@ -247,35 +247,182 @@ __device__ __forceinline__ void child_bounds(const u64* __restrict__ k, int a, i
   }
 }
 
-__global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k, int n, int B, int D,
+// d[j] = leading octal digits shared by keys j-1 and j (0..B); d[0] = d[n] = -1 (sentinels)
+__global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int n, int B,
+                                                  signed char* __restrict__ d) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  d[j] = (j == 0 || j == n) ? (signed char)-1 : (signed char)common_digits(k[j - 1], k[j], B);
+}
+
+// the key-search path for pair j at level L (cells wider than the LDS window of pairs_kernel)
+__device__ __forceinline__ int pair_global(const u64* __restrict__ k, int n, int B, int cap, int j, int L,
+                                           int* a_out, int* b_out) {
+  const int sh = 3 * (B - L), dsh = 3 * (B - 1 - L);
+  const int a = cell_start(k, j - 1, sh);
+  if (((k[j - 1] >> dsh) & 7ull) != ((k[a] >> dsh) & 7ull)) return 0;  // not the first boundary
+  const int b = cell_end(k, n, j, sh);
+  if (b - a <= cap) return 0;
+  int pos[9], nc = 0;
+  child_bounds(k, a, b, dsh, pos);
+#pragma unroll
+  for (int v = 0; v < 8; v++) nc += (pos[v + 1] > pos[v]) ? 1 : 0;
+  *a_out = a;
+  *b_out = b;
+  return nc;
+}
+
+// Cell of pair j at level L = d[j]:   start a = nearest i < j with d[i] < L,
+//                                     end   b = nearest i > j with d[i] < L,
+//   j is its first child boundary iff the nearest i < j with d[i] <= L already has d[i] < L,
+//   children = 2 + #{ i in (j, b) : d[i] == L }.
+// All four are nearest-smaller-value queries on the byte array d[].  A block resolves them for
+// 1024 consecutive pairs inside an LDS window of 3072 positions (1024 of halo each side) using
+// per-level bitmasks  m[v+1][w] = ballot(d <= v)  built with wave64 ballots: a query is a masked
+// word, a short word scan, and clz / ctz / popcount.  Only cells that reach beyond the window
+// (about one pair per thousand) take the dependent global key searches of pair_global().
+constexpr int kPairTile = 1024;
+constexpr int kPairWin = 3 * kPairTile;
+constexpr int kPairWords = kPairWin / 64;  // 48
+constexpr int kPairLevels = 23;            // v = -1 .. 21
+
+__device__ __forceinline__ int prev_set(const u64* row, int p) {  // highest set bit below p, or -1
+  int w = p >> 6;
+  u64 bits = row[w] & ((1ull << (p & 63)) - 1ull);
+  while (bits == 0ull && w > 0) bits = row[--w];
+  return bits ? w * 64 + 63 - __clzll((long long)bits) : -1;
+}
+__device__ __forceinline__ int next_set(const u64* row, int p) {  // lowest set bit above p, or -1
+  int w = p >> 6;
+  u64 bits = row[w] & ~((2ull << (p & 63)) - 1ull);
+  while (bits == 0ull && w < kPairWords - 1) bits = row[++w];
+  return bits ? w * 64 + __ffsll((long long)bits) - 1 : -1;
+}
+__device__ __forceinline__ int count_between(const u64* row, int p, int q) {  // set bits in (p, q)
+  int w0 = p >> 6, w1 = q >> 6;
+  const u64 above_p = ~((2ull << (p & 63)) - 1ull);
+  const u64 below_q = (1ull << (q & 63)) - 1ull;
+  if (w0 == w1) return __popcll(row[w0] & above_p & below_q);
+  int c = __popcll(row[w0] & above_p) + __popcll(row[w1] & below_q);
+  for (int w = w0 + 1; w < w1; w++) c += __popcll(row[w]);
+  return c;
+}
+
+// fill the LDS window: dl[s] = d[base + s] (-1 outside [0, n]) and the per-level masks
+__device__ __forceinline__ void build_window(const signed char* __restrict__ d, int n, int base,
+                                             u64 (*m)[kPairWords], signed char* dl) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int s = threadIdx.x; s < kPairWin; s += 256) {
+    const int g = base + s;
+    dl[s] = (g < 0 || g > n) ? (signed char)-1 : d[g];
+  }
+  __syncthreads();
+  for (int w = wv; w < kPairWords; w += 4) {
+    const int dv = dl[w * 64 + lane];
+#pragma unroll
+    for (int v = -1; v < kPairLevels - 1; v++) {
+      const u64 bb = __ballot(dv <= v);
+      if (lane == 0) m[v + 1][w] = bb;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
+                                                    const signed char* __restrict__ d, int n, int B, int D,
                                                     int cap, int* __restrict__ pa, int* __restrict__ pb,
                                                     int* __restrict__ pn, bh_devinfo* __restrict__ info) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  int nc = 0, L = 0;
-  if (j >= 1) {
-    const u64 kj = k[j], kp = k[j - 1];
-    L = common_digits(kp, kj, B);
-    if (L < D) {
+  __shared__ u64 m[kPairLevels][kPairWords];
+  __shared__ signed char dl[kPairWin];
+  const int t0 = blockIdx.x * kPairTile;
+  const int base = t0 - kPairTile;  // global position of window slot 0
+  const int lane = threadIdx.x & 63;
+  build_window(d, n, base, m, dl);
+
+  __shared__ int wide[kPairTile];  // window slots of the pairs whose cell leaves the window
+  __shared__ int nwide;
+  if (threadIdx.x == 0) nwide = 0;
+  __syncthreads();
+
+  int cells = 0, maxl = 0;
+#pragma unroll 1
+  for (int r = 0; r < kPairTile / 256; r++) {
+    const int p = kPairTile + r * 256 + (int)threadIdx.x;  // window slot
+    const int j = base + p;
+    if (j >= n) break;
+    int nc = 0;
+    bool deferred = false;
+    const int L = dl[p];
+    if (j >= 1 && L >= 0 && L < D) {
+      int a = 0, b = 0;
+      const u64* mle = m[L + 1];  // d <= L
+      const u64* mlt = m[L];      // d <  L
+      const int q = prev_set(mle, p);
+      if (q < 0) {
+        deferred = true;  // cell starts left of the window
+      } else if (dl[q] < L) {  // j is the first child boundary
+        const int q2 = next_set(mlt, p);
+        if (q2 < 0) {
+          deferred = true;  // cell ends right of the window
+        } else {
+          a = base + q;
+          b = base + q2;
+          if (b - a > cap) nc = 2 + count_between(mle, p, q2);
+        }
+      }
+      if (nc) {
+        pa[j] = a;
+        pb[j] = b;
+        cells++;
+        maxl = max(maxl, L + 1);
+      }
+    }
+    if (deferred)
+      wide[atomicAdd(&nwide, 1)] = p;  // list order is irrelevant: results are keyed by j
+    else
+      pn[j] = nc;
+  }
+  __syncthreads();
+  // phase 2: wide cells by key search, 8 lanes per pair (lane v = octant v), all pairs of the
+  // block in flight together so the block pays one dependent-load chain, not one per round
+  {
+    const int sub = threadIdx.x & 7;
+    const int nw = nwide;
+    for (int idx = threadIdx.x >> 3; idx < nw; idx += 32) {
+      const int p = wide[idx];
+      const int j = base + p;
+      const int L = dl[p];
       const int sh = 3 * (B - L), dsh = 3 * (B - 1 - L);
       const int a = cell_start(k, j - 1, sh);
-      if (((kp >> dsh) & 7ull) == ((k[a] >> dsh) & 7ull)) {  // j is the cell's first child boundary
-        const int b = cell_end(k, n, j, sh);
+      int nc = 0, b = 0;
+      if (((k[j - 1] >> dsh) & 7ull) == ((k[a] >> dsh) & 7ull)) {  // j is the first child boundary
+        b = cell_end(k, n, j, sh);
         if (b - a > cap) {
-          int pos[9];
-          child_bounds(k, a, b, dsh, pos);
-#pragma unroll
-          for (int v = 0; v < 8; v++) nc += (pos[v + 1] > pos[v]) ? 1 : 0;
+          int l = a, h = b;  // lower bound of digit >= sub in [a, b)
+          while (l < h) {
+            const int mid = l + ((h - l) >> 1);
+            if ((int)((k[mid] >> dsh) & 7ull) < sub) l = mid + 1; else h = mid;
+          }
+          int nxt = __shfl_down(l, 1, 8);
+          if (sub == 7) nxt = b;
+          const u64 bal = __ballot(nxt > l);
+          nc = __popcll((bal >> (lane & ~7)) & 0xffull);
+        }
+      }
+      if (sub == 0) {
+        pn[j] = nc;
+        if (nc) {
           pa[j] = a;
           pb[j] = b;
+          cells++;
+          maxl = max(maxl, L + 1);
         }
       }
     }
   }
-  pn[j] = nc;
-  if (nc) {  // integer atomics: totals are order-independent
-    atomicAdd(&info->n_internal, 1);
-    atomicMax(&info->max_level, L + 1);
+  if (cells) {  // integer atomics: totals are order-independent
+    atomicAdd(&info->n_internal, cells);
+    atomicMax(&info->max_level, maxl);
   }
 }
 
@@ -323,41 +470,134 @@ __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, 
   return r;
 }
 
-__global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k, int n, int B, int D, int cap,
-                                                   const int* __restrict__ pa, const int* __restrict__ pb,
-                                                   const int* __restrict__ pn, const int* __restrict__ cb,
+// topology fields of the record of child [c0,c1) (window slots) of a cell at level L, resolved
+// with the window masks: the child's branching level Lb is the smallest v > L whose mask has a bit
+// strictly inside the child, and that first bit is the child's representative pair
+__device__ __forceinline__ bh_node make_child_win(u64 (*m)[kPairWords], int base, int B, int D, int cap,
+                                                  float s0, const int* __restrict__ pn,
+                                                  const int* __restrict__ cb, int c0, int c1, int L) {
+  bh_node r;
+  r.x = r.y = r.z = r.m = 0.0f;
+  const int cnt = c1 - c0;
+  r.first = base + c0;
+  r.count = cnt;
+  if (cnt == 1) {
+    r.kind = BH_KIND_BODY;
+    r.s = -1.0f;  // negative edge: accepted by every theta >= 0
+    return r;
+  }
+  r.kind = BH_KIND_MULTI;
+  if (cnt <= cap) {
+    r.s = ldexpf(s0, -(L + 1));
+    return r;
+  }
+  int Lb = B, jr = -1;
+  for (int v = L + 1; v < B; v++) {
+    const int s = next_set(m[v + 1], c0);
+    if (s >= 0 && s < c1) {
+      Lb = v;
+      jr = s;
+      break;
+    }
+  }
+  if (Lb >= D) {  // never branches above the depth cap: unsplit multi-body cell at level D
+    r.s = ldexpf(s0, -D);
+    return r;
+  }
+  r.kind = BH_KIND_INTERNAL;
+  r.first = 1 + cb[base + jr];
+  r.count = pn[base + jr];
+  r.s = ldexpf(s0, -Lb);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
+                                                   const signed char* __restrict__ d, int n, int B, int D,
+                                                   int cap, const int* __restrict__ pa,
+                                                   const int* __restrict__ pb, const int* __restrict__ pn,
+                                                   const int* __restrict__ cb,
                                                    const float* __restrict__ bounds,
                                                    bh_node* __restrict__ rec, int* __restrict__ er_lo,
                                                    int* __restrict__ er_hi, int rec_cap,
                                                    bh_devinfo* __restrict__ info) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  __shared__ u64 m[kPairLevels][kPairWords];
+  __shared__ signed char dl[kPairWin];
+  const int t0 = blockIdx.x * kPairTile;
+  const int base = t0 - kPairTile;
+  build_window(d, n, base, m, dl);
+  __shared__ int wide[kPairTile];
+  __shared__ int nwide;
+  if (threadIdx.x == 0) nwide = 0;
+  __syncthreads();
   const float s0 = bounds[6];
-  if (j == 0) {  // root record (ref:65-81 initRootKernel)
-    const int E = 1 + cb[n];
-    info->n_entries = E;
-    if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
-    rec[0] = make_child(k, B, D, cap, s0, pn, cb, 0, n, 0);
-    er_lo[0] = 0;
-    er_hi[0] = n;
-    return;
+#pragma unroll 1
+  for (int r = 0; r < kPairTile / 256; r++) {
+    const int p = kPairTile + r * 256 + (int)threadIdx.x;
+    const int j = base + p;
+    if (j >= n) break;
+    if (j == 0) {  // root record (ref:65-81 initRootKernel)
+      const int E = 1 + cb[n];
+      info->n_entries = E;
+      if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
+      rec[0] = make_child(k, B, D, cap, s0, pn, cb, 0, n, 0);
+      er_lo[0] = 0;
+      er_hi[0] = n;
+      continue;
+    }
+    const int nc = pn[j];
+    if (nc == 0) continue;
+    int e = 1 + cb[j];
+    if (e + nc > rec_cap) continue;  // cannot happen (records <= 2n); flagged by thread 0 if it did
+    const int a = pa[j], b = pb[j];
+    const int L = dl[p];
+    const int qa = a - base, qb = b - base;
+    if (qa < 0 || qb >= kPairWin) {  // cell wider than the window: phase 2
+      wide[atomicAdd(&nwide, 1)] = p;
+      continue;
+    }
+    // children = runs between the positions with d == L in (qa, qb); p is the first of them
+    const u64* mle = m[L + 1];
+    int c0 = qa, c1 = p;
+    for (;;) {
+      rec[e] = make_child_win(m, base, B, D, cap, s0, pn, cb, c0, c1, L);
+      er_lo[e] = base + c0;
+      er_hi[e] = base + c1;
+      e++;
+      if (c1 >= qb) break;
+      c0 = c1;
+      const int nx = next_set(mle, c0);
+      c1 = (nx < 0 || nx > qb) ? qb : nx;
+    }
   }
-  const int nc = pn[j];
-  if (nc == 0) return;
-  int e = 1 + cb[j];
-  if (e + nc > rec_cap) return;  // cannot happen (records <= 2n); flagged by thread 0 if it did
-  const int a = pa[j], b = pb[j];
-  const int L = common_digits(k[j - 1], k[j], B);
-  int pos[9];
-  child_bounds(k, a, b, 3 * (B - 1 - L), pos);
-#pragma unroll
-  for (int v = 0; v < 8; v++) {
-    const int c0 = pos[v], c1 = pos[v + 1];
-    if (c1 <= c0) continue;
-    rec[e] = make_child(k, B, D, cap, s0, pn, cb, c0, c1, L + 1);
-    er_lo[e] = c0;
-    er_hi[e] = c1;
-    e++;
+  __syncthreads();
+  // phase 2: wide cells, 8 lanes per cell, lane v emits the child in octant v (if non-empty)
+  {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x & 7;
+    const int nw = nwide;
+    for (int idx = threadIdx.x >> 3; idx < nw; idx += 32) {
+      const int p = wide[idx];
+      const int j = base + p;
+      const int L = dl[p];
+      const int a = pa[j], b = pb[j];
+      const int dsh = 3 * (B - 1 - L);
+      int l = a, h = b;  // lower bound of digit >= sub in [a, b)
+      while (l < h) {
+        const int mid = l + ((h - l) >> 1);
+        if ((int)((k[mid] >> dsh) & 7ull) < sub) l = mid + 1; else h = mid;
+      }
+      int nxt = __shfl_down(l, 1, 8);
+      if (sub == 7) nxt = b;
+      const bool nonempty = nxt > l;
+      const u64 grp = (__ballot(nonempty) >> (lane & ~7)) & 0xffull;
+      if (nonempty) {
+        const int e = 1 + cb[j] + __popcll(grp & ((1ull << sub) - 1ull));
+        if (e < rec_cap) {
+          rec[e] = make_child(k, B, D, cap, s0, pn, cb, l, nxt, L + 1);
+          er_lo[e] = l;
+          er_hi[e] = nxt;
+        }
+      }
+    }
   }
 }
 
@@ -439,12 +679,14 @@ hipError_t bhk_build(bh_ctx* c) {
   const u64* k = c->keys[c->key_buf];
   hipError_t e = hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream);
   if (e != hipSuccess) return e;
-  const int blocks = (n + 255) / 256;
-  pairs_kernel<<<blocks, 256, 0, c->stream>>>(k, n, c->B, c->D, c->cap, c->pa, c->pb, c->pn, c->info);
+  lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8);
+  pairs_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
+                                                                        c->pa, c->pb, c->pn, c->info);
   e = bhk_scan_i32(c, c->pn, c->cb, n, nullptr);  // child-block offsets; cb[n] = total children
   if (e != hipSuccess) return e;
-  emit_kernel<<<blocks, 256, 0, c->stream>>>(k, n, c->B, c->D, c->cap, c->pa, c->pb, c->pn, c->cb,
-                                             c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
+  emit_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->pa,
+                                                                       c->pb, c->pn, c->cb, c->bounds, c->rec,
+                                                                       c->er_lo, c->er_hi, c->rec_cap, c->info);
   return hipGetLastError();
 }
 
