@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1_000_000, help="bodies per GPU (weak scaling)")
+    ap.add_argument("--bodies", "--n", dest="n", type=int, default=1_000_000,
+                    help="bodies per GPU (weak scaling); use --bodies under torch.distributed.run")
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +102,10 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # BH_FORCE_DIST=1 runs the multi-rank code path (RCCL init, sharded stepper, all-gather) even at
+    # world size 1, so it can be exercised on a one-GPU box (tests/test_gpu_dist.py)
+    multi = world > 1 or os.environ.get("BH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
@@ -129,11 +133,11 @@ def main():
         eng.force_count()
         s = eng.stats()
         counts0 = (s.count_V, s.count_O, s.count_P)
-    eng.set_timing(world == 1)  # per-step hipEvent pairs on the engine's stream (1-GPU path)
+    eng.set_timing(not multi)  # per-step hipEvent pairs on the engine's stream (1-GPU path)
 
     barrier()
     t0 = time.perf_counter()
-    if world == 1:
+    if not multi:
         eng.step(args.steps)   # bh_step: the C-ABI's own fused stage sequence
     else:
         stepper.step(args.steps)
@@ -151,7 +155,7 @@ def main():
         value = n_total * args.steps / elapsed
         roofline = None
         stages = None
-        if world == 1:
+        if not multi:
             f_ms, s_ms = eng.timing_history()
             eng.set_timing(False)
             eng.tree_stages()
@@ -191,7 +195,7 @@ def main():
                             f"theta={args.theta}, G=0.5 eps2=50 dt=0.02, fp32, leaf_cap=1, 63-bit keys "
                             "(BASELINE.json configs[2]; x8 = configs[3])",
                 "n_total": n_total,
-                "parallelism": "1 GPU" if world == 1 else
+                "parallelism": "1 GPU" if not multi else
                                f"{world} ranks: replicated tree, Morton-slab sharded traversal, acc all-gather (RCCL)",
                 "tree": {"cells": st.n_internal, "records": st.n_entries, "max_level": st.max_level},
             },
@@ -202,7 +206,7 @@ def main():
         assert st.status_flags == 0, st.status_flags
     if dist is not None:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, n_total, args.theta, ic)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -90,6 +90,12 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C nbody-barnes-hut-cuda_amd). "
             "There is no CPU fallback.")
+    # PyTorch bundles its own libamdhip64; if libbh.so drags /opt/rocm's copy into the process first,
+    # torch later finds "No HIP GPUs".  Loading torch first makes both share one HIP runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the library does not export it

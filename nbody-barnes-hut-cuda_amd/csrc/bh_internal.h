@@ -115,6 +115,7 @@ hipError_t bhk_sort(bh_ctx* c);                       // radix sort + gather
 hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
+hipError_t bhk_force_fast(bh_ctx* c, int lo, int hi);  // bh_force_fast.hip, default fast kernel
 hipError_t bhk_integrate(bh_ctx* c);
 
 // device-wide scans (bh_scan.hip)

@@ -1,0 +1,60 @@
+"""GPU tests of the multi-rank plumbing that can run on ONE MI355X: the RCCL code path of bench.py at
+world size 1 (init, sharded stepper, all-gather into the bound acc buffer), and ShardedStepper ==
+bh_step on the device.  Real multi-GPU runs belong to the driver; the N > 1 logic itself is covered
+on CPU by tests/test_dist_cpu.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_distributed_path_world1():
+    env = dict(os.environ)
+    env["BH_FORCE_DIST"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--bodies", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
+    assert out["scaling"] == "weak" and out["config"]["n_total"] == 200000
+    assert "sharded" in out["config"]["parallelism"]
+
+
+def test_sharded_stepper_equals_bh_step(pkg):
+    """stage calls + bh_force_range + bound acc buffer (the multi-rank step) == bh_step"""
+    import torch
+    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    n = 50000
+    ic = pkg.plummer(n, seed=5)
+    e1 = pkg.Engine(n)
+    e1.upload(*ic)
+    e1.step(4)
+    ref = np.stack(e1.download(), 1)
+    e1.close()
+    e2, stepper = bhdist.make_gpu_stepper(pkg, n, device=0)
+    e2.upload(*ic)
+    stepper.step(4)
+    torch.cuda.synchronize()
+    got = np.stack(e2.download(), 1)
+    assert np.array_equal(ref, got)
+    e2.close()

@@ -89,6 +89,51 @@ __global__ __launch_bounds__(256) void k2(float* out, int iters, float eps2, int
   if (pushes == 123456789) *sink = pushes;
 }
 
+// packed fp32: two records per VALU instruction (v_pk_add/fma/mul_f32), 9 VALU per record
+typedef float f2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void kpk(float* out, int iters, float eps2, int xbits, float gm, float thr2,
+                                           u64 mask_in, int* sink) {
+  const int lane = threadIdx.x & 63;
+  const float px = (float)lane * 0.37f, py = (float)(threadIdx.x >> 6), pz = 1.5f + blockIdx.x * 1e-3f;
+  const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz}, e2 = {eps2, eps2};
+  f2 ax = {0, 0}, ay = {0, 0}, az = {0, 0};
+  u64 mask = mask_in;
+  int pushes = 0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk += 2) {
+      f2 rx, ry, rz;
+      rx[0] = __int_as_float(xbits + ((it * 4 + kk) & 1023));
+      rx[1] = __int_as_float(xbits + ((it * 4 + kk + 1) & 1023));
+      ry[0] = __int_as_float(xbits + ((it * 7 + kk) & 1023));
+      ry[1] = __int_as_float(xbits + ((it * 7 + kk + 1) & 1023));
+      rz[0] = __int_as_float(xbits + ((it * 3 + kk) & 1023));
+      rz[1] = __int_as_float(xbits + ((it * 3 + kk + 1) & 1023));
+      const f2 dx = rx - px2, dy = ry - py2, dz = rz - pz2;
+      const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+      const u64 acc0 = __builtin_amdgcn_ballot_w64(d2[0] > thr2);
+      const u64 acc1 = __builtin_amdgcn_ballot_w64(d2[1] > thr2);
+      const u64 open = (mask & ~acc0) | (mask & ~acc1);
+      f2 rinv;
+      rinv[0] = __builtin_amdgcn_rsqf(d2[0]);
+      rinv[1] = __builtin_amdgcn_rsqf(d2[1]);
+      const f2 gm2 = {gm, gm};
+      f2 f = (gm2 * rinv) * (rinv * rinv);
+      f[0] = __builtin_amdgcn_inverse_ballot_w64(mask & acc0) ? f[0] : 0.0f;
+      f[1] = __builtin_amdgcn_inverse_ballot_w64(mask & acc1) ? f[1] : 0.0f;
+      ax = __builtin_elementwise_fma(f, dx, ax);
+      ay = __builtin_elementwise_fma(f, dy, ay);
+      az = __builtin_elementwise_fma(f, dz, az);
+      if (open != 0ull) {
+        pushes++;
+        mask ^= open >> 1;
+      }
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = ax[0] + ax[1] + ay[0] + ay[1] + az[0] + az[1];
+  if (pushes == 123456789) *sink = pushes;
+}
+
 int main() {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
@@ -104,12 +149,14 @@ int main() {
   const float x0 = 100.0f;
   int xbits;
   memcpy(&xbits, &x0, 4);
-  for (int branchy = 0; branchy < 3; branchy++)
+  for (int branchy = 0; branchy < 4; branchy++)
     for (int bpc = 1; bpc <= 8; bpc *= 2) {  // blocks per CU: 1,2,4,8 -> waves/SIMD 1,2,4,8
       const int grid = cus * bpc;
       for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0);
-        if (branchy == 2)  // two bodies per lane, one branch per record
+        if (branchy == 3)  // packed fp32, two records per instruction, one branch per pair
+          kpk<<<grid, 256>>>(out, iters, 50.0f, xbits, 2.0f, 1e9f, ~0ull, sink);
+        else if (branchy == 2)  // two bodies per lane, one branch per record
           k2<<<grid, 256>>>(out, iters, 50.0f, xbits, 2.0f, 1e9f, ~0ull, sink);
         else if (branchy)
           k<1><<<grid, 256>>>(out, iters, 50.0f, xbits, 2.0f, 1e9f, ~0ull, sink);
