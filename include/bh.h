@@ -64,7 +64,10 @@ typedef struct bh_params {
   int32_t xcd_mode;      /* fast force kernels, block -> body-chunk placement (speed only):
                             0 = one contiguous eighth of the Morton order per XCD, 1 = identity,
                             2 = runs of 16 chunks per XCD dealt round-robin                       */
-  int32_t reserved[5];
+  int32_t sort_variant;  /* 0 = one kernel per radix pass with decoupled look-back (default),
+                            1 = histogram + scan + scatter kernels per pass (no inter-workgroup
+                            hand-off at all; A/B and fallback)                                     */
+  int32_t reserved[4];
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:
@@ -104,6 +107,7 @@ typedef struct bh_stats {
 
 #define BH_FLAG_POOL_OVERFLOW 1
 #define BH_FLAG_STACK_OVERFLOW 2
+#define BH_FLAG_SORT_TIMEOUT 4 /* a look-back spin of the radix sort hit its bound: order invalid */
 
 /* ---- lifecycle ( <-> cudaMalloc block ref:311-326, cudaFree ref:372-387 ) ---- */
 int bh_abi_version(void);

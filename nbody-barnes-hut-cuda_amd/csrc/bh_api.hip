@@ -71,7 +71,8 @@ static void free_all(bh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
-                  c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->bbox_partial,
+                  c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sw_hist, c->sw_status,
+                  c->sw_ticket, c->bbox_partial,
                   c->bounds, c->d8, c->pa, c->pb, c->pn,
                   c->cb, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
@@ -141,6 +142,13 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->keys[0], N) == hipSuccess && dalloc(&c->keys[1], N) == hipSuccess;
   ok = ok && dalloc(&c->vals[0], N) == hipSuccess && dalloc(&c->vals[1], N) == hipSuccess;
   ok = ok && dalloc(&c->hist, (size_t)256 * c->sort_tiles + 256) == hipSuccess;
+  ok = ok && dalloc(&c->sw_hist, (size_t)8 * 256) == hipSuccess;
+  ok = ok && dalloc(&c->sw_status, (size_t)8 * c->sort_tiles * 256) == hipSuccess;
+  ok = ok && dalloc(&c->sw_ticket, (size_t)8) == hipSuccess;
+  // look-back granules and tickets start at zero once; they are never cleared afterwards
+  // (granules carry the sort-call tag, tickets are monotonic)
+  ok = ok && hipMemset(c->sw_status, 0, (size_t)8 * c->sort_tiles * 256 * sizeof(u64)) == hipSuccess;
+  ok = ok && hipMemset(c->sw_ticket, 0, 8 * sizeof(u32)) == hipSuccess;
   ok = ok && dalloc(&c->bbox_partial, (size_t)BH_BBOX_BLOCKS * 6) == hipSuccess;
   ok = ok && dalloc(&c->bounds, 8) == hipSuccess;
   ok = ok && dalloc(&c->d8, N + 1) == hipSuccess;
@@ -212,6 +220,7 @@ int bh_upload(bh_ctx* c, const float* x, const float* y, const float* z, const f
     BH_HIP(c, hipMemcpyAsync(c->stage_buf + k * N, src[k], nb, hipMemcpyHostToDevice, c->stream));
   c->cur = 0;
   BH_HIP(c, bhk_pack(c));
+  BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));  // clears the sticky flags
   BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));
   BH_HIP(c, hipStreamSynchronize(c->stream));  // host buffers may be reused on return
   c->stage = BH_ST_UPLOADED;

@@ -67,6 +67,11 @@ struct bh_ctx {
   u32* vals[2];
   int key_buf;  // which keys[] holds the sorted keys
   u32* hist;    // 256 * ntiles
+  // onesweep sort (bh_sort_onesweep.hip)
+  u32* sw_hist;    // [8][256] global digit totals of every pass
+  u64* sw_status;  // [passes][ntiles][256] look-back granules {tag|state|count}
+  u32* sw_ticket;  // [8] monotonic tile tickets, one counter per pass
+  u32 sort_calls;
   int sort_tiles;
 
   // bbox
@@ -112,6 +117,7 @@ hipError_t bhk_unpack(bh_ctx* c, int what);           // 0: pos+vel -> stage_buf
 hipError_t bhk_bbox(bh_ctx* c);
 hipError_t bhk_keys(bh_ctx* c);
 hipError_t bhk_sort(bh_ctx* c);                       // radix sort + gather
+hipError_t bhk_sort_onesweep(bh_ctx* c);              // default implementation (bh_sort_onesweep.hip)
 hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);

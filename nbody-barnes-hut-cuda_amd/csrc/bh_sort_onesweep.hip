@@ -1,0 +1,204 @@
+// bh_sort_onesweep.hip — stable LSD radix sort, ONE kernel per 8-bit pass (default sort path).
+//
+// Replaces thrust::sort_by_key (ref nbody_v5_bench.cu:262-264).  Same contract as bh_sort.hip
+// (stable ascending by key, value = slot index), a third of the launches and two thirds of the
+// traffic: keys and values are read once and written once per pass.
+//   * one up-front kernel builds the global digit histograms of ALL passes (global digit totals do
+//     not depend on the order of the keys);
+//   * each pass kernel ranks its 4096-key tile exactly like sort_scatter_kernel (wave64 match-any
+//     with 8 ballots, wave-private LDS counters combined in wave order -> stable), then resolves
+//     the tile's per-digit prefix by DECOUPLED LOOK-BACK instead of a separate histogram + scan:
+//       - tiles take a ticket (atomicAdd) when they start, so a tile's predecessors are already
+//         running: look-back only ever waits on resident workgroups (no dispatch-order assumption);
+//       - per (tile, digit) ONE 8-byte granule {tag:30 | state:2 | count:32} written and polled with
+//         relaxed agent-scope atomics (the data-tagged single-granule hand-off of
+//         cdna_hip_programming.md Guideline 16: flag and value travel in one word, so no
+//         fence ordering between them is needed).  state 1 = this tile's count, 2 = inclusive
+//         prefix.  The tag is the sort-call number, so the table is never cleared and a stale
+//         entry from an earlier call reads as "not ready";
+//       - thread d walks back over digit d's granules (256 independent chains per block);
+//       - every spin is bounded; on timeout the kernel sets BH_FLAG_SORT_TIMEOUT and goes on
+//         (wrong order, loudly reported) instead of hanging the device.
+#include "bh_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = BH_SORT_ITEMS;
+constexpr int kTile = BH_SORT_TILE;
+constexpr u32 kSpinLimit = 1u << 22;
+
+__device__ __forceinline__ u64 pack_granule(u32 tag, u32 state, u32 value) {
+  return ((u64)((tag << 2) | state) << 32) | (u64)value;
+}
+
+// global digit histograms of every pass in one sweep over the keys
+__global__ __launch_bounds__(kThreads) void onesweep_hist_kernel(const u64* __restrict__ keys, int n,
+                                                                 int passes, u32* __restrict__ ghist) {
+  __shared__ u32 h[8][256];
+  for (int p = 0; p < 8; p++) h[p][threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kTile;
+#pragma unroll 4
+  for (int r = 0; r < kItems; r++) {
+    const int i = base + r * kThreads + (int)threadIdx.x;
+    if (i < n) {
+      const u64 k = keys[i];
+      for (int p = 0; p < passes; p++) atomicAdd(&h[p][(u32)(k >> (8 * p)) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < passes; p++) {
+    const u32 v = h[p][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], v);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
+    const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
+    u32* __restrict__ vout, int n, int shift, const u32* __restrict__ ghist_pass,
+    u64* __restrict__ status, u32* __restrict__ ticket, u32 ticket_base, u32 tag, int first_pass,
+    bh_devinfo* __restrict__ info) {
+  __shared__ u32 wcnt[4][256];
+  __shared__ u32 gbase[256];
+  __shared__ u32 dsum[4];
+  __shared__ u32 s_tile;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+#pragma unroll
+  for (int q = 0; q < 4; q++) wcnt[q][threadIdx.x] = 0;
+  __syncthreads();
+  const int tile = (int)s_tile;
+
+  const int base = tile * kTile + w * (64 * kItems);
+  u64 key[kItems];
+  u32 val[kItems];
+  u32 rk[kItems];
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int i = base + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? kin[i] : ~0ull;
+    val[r] = valid ? (first_pass ? (u32)i : vin[i]) : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int i = base + r * 64 + lane;
+    const bool valid = i < n;
+    const u32 g = (u32)(key[r] >> shift) & 255u;
+    u64 mask = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const bool b = (g >> bit) & 1u;
+      const u64 bb = __ballot(b);
+      mask &= b ? bb : ~bb;
+    }
+    const u32 rank = (u32)__popcll(mask & lt);
+    u32 prev = 0;
+    if (valid) prev = wcnt[w][g];
+    rk[r] = prev + rank;
+    if (valid && rank == 0) wcnt[w][g] = prev + (u32)__popcll(mask);
+  }
+  __syncthreads();
+  {
+    const int t = threadIdx.x;  // digit
+    const u32 c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
+    const u32 h = c0 + c1 + c2 + c3;
+    wcnt[0][t] = 0;
+    wcnt[1][t] = c0;
+    wcnt[2][t] = c0 + c1;
+    wcnt[3][t] = c0 + c1 + c2;
+    // publish this tile's count, then resolve the exclusive prefix over the earlier tiles
+    u64* mine = status + (size_t)tile * 256 + t;
+    u32 excl = 0;
+    if (tile == 0) {
+      __hip_atomic_store(mine, pack_granule(tag, 2u, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(mine, pack_granule(tag, 1u, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int tt = tile - 1;
+      u32 spins = 0;
+      for (;;) {
+        const u64 e = __hip_atomic_load(status + (size_t)tt * 256 + t, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+        const u32 hi = (u32)(e >> 32);
+        if ((hi >> 2) != tag || (hi & 3u) == 0u) {  // not published yet
+          if (++spins > kSpinLimit) {
+            atomicOr(&info->flags, BH_FLAG_SORT_TIMEOUT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += (u32)e;
+        if ((hi & 3u) == 2u) break;
+        tt--;
+      }
+      __hip_atomic_store(mine, pack_granule(tag, 2u, excl + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // digit base = exclusive scan of the 256 global digit totals of this pass
+    const u32 dv = ghist_pass[t];
+    u32 incl = dv;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 u = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += u;
+    }
+    if (lane == 63) dsum[w] = incl;
+    __syncthreads();
+    u32 wp = 0;
+    for (int q = 0; q < w; q++) wp += dsum[q];
+    gbase[t] = wp + incl - dv + excl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int i = base + r * 64 + lane;
+    if (i < n) {
+      const u32 g = (u32)(key[r] >> shift) & 255u;
+      const u32 pos = gbase[g] + wcnt[w][g] + rk[r];
+      if (pos < (u32)n) {  // always true unless a look-back timed out
+        kout[pos] = key[r];
+        vout[pos] = val[r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ perm,
+                                                      const float4* __restrict__ posm_in,
+                                                      const float4* __restrict__ velid_in,
+                                                      float4* __restrict__ posm_out,
+                                                      float4* __restrict__ velid_out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 j = perm[i];
+  posm_out[i] = posm_in[j];
+  velid_out[i] = velid_in[j];
+}
+
+}  // namespace
+
+hipError_t bhk_sort_onesweep(bh_ctx* c) {
+  const int n = c->n;
+  const int ntiles = c->sort_tiles;
+  const int passes = (c->p.key_bits + 7) / 8;
+  hipError_t e = hipMemsetAsync(c->sw_hist, 0, 8 * 256 * sizeof(u32), c->stream);
+  if (e != hipSuccess) return e;
+  onesweep_hist_kernel<<<ntiles, kThreads, 0, c->stream>>>(c->keys[0], n, passes, c->sw_hist);
+  const u32 call = c->sort_calls++;
+  const u32 tag = (call + 1u) & 0x3fffffffu;
+  int src = 0;
+  for (int p = 0; p < passes; p++) {
+    onesweep_pass_kernel<<<ntiles, kThreads, 0, c->stream>>>(
+        c->keys[src], c->vals[src], c->keys[src ^ 1], c->vals[src ^ 1], n, 8 * p, c->sw_hist + p * 256,
+        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, call * (u32)ntiles, tag, p == 0, c->info);
+    src ^= 1;
+  }
+  c->key_buf = src;
+  const int blocks = (n + 255) / 256;
+  gather2_kernel<<<blocks, 256, 0, c->stream>>>(c->vals[src], c->posm[c->cur], c->velid[c->cur],
+                                                 c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], n);
+  c->cur ^= 1;
+  return hipGetLastError();
+}

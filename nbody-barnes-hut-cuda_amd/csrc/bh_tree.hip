@@ -677,7 +677,8 @@ hipError_t bhk_keys(bh_ctx* c) {
 hipError_t bhk_build(bh_ctx* c) {
   const int n = c->n;
   const u64* k = c->keys[c->key_buf];
-  hipError_t e = hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream);
+  // tree statistics restart every build; the sticky error flags (4th word) survive until upload
+  hipError_t e = hipMemsetAsync(c->info, 0, 3 * sizeof(int), c->stream);
   if (e != hipSuccess) return e;
   lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8);
   pairs_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,

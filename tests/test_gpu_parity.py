@@ -49,11 +49,14 @@ def test_keys_bit_exact(pkg, orc, n, key_bits):
     e.close()
 
 
+@pytest.mark.parametrize("sort_variant", [0, 1])
 @pytest.mark.parametrize("key_bits", [63, 30])
 @pytest.mark.parametrize("n", [1, 2, 65, 4096, 4097, 65536, 300001])
-def test_sort_stable_permutation(pkg, orc, n, key_bits):
+def test_sort_stable_permutation(pkg, orc, n, key_bits, sort_variant):
+    """both radix-sort implementations (0 = one kernel per pass with decoupled look-back,
+    1 = histogram/scan/scatter) == the oracle's stable merge sort, exact permutation"""
     ic = pkg.plummer(n, seed=3)
-    e = _engine(pkg, ic, key_bits=key_bits, max_depth=key_bits // 3)
+    e = _engine(pkg, ic, key_bits=key_bits, max_depth=key_bits // 3, sort_variant=sort_variant)
     e.bbox(); e.morton(); e.sort()
     gk = e.download_keys()
     order = e.download_order()
@@ -64,6 +67,24 @@ def test_sort_stable_permutation(pkg, orc, n, key_bits):
     bodies = e.download_sorted_bodies()
     assert np.array_equal(bodies[:, 0], ic[0][perm])  # physical gather
     assert np.array_equal(bodies[:, 3], ic[6][perm])
+    assert e.stats().status_flags == 0
+    e.close()
+
+
+@pytest.mark.parametrize("sort_variant", [0, 1])
+def test_sort_many_ties_and_repeated_calls(pkg, orc, sort_variant):
+    """heavy ties (grid input, 30-bit keys) and 20 consecutive sorts on one context: the look-back
+    table is never cleared between calls (tagged granules, monotonic tickets)"""
+    ic = special_ics("grid", 50000, np.random.default_rng(3))
+    e = _engine(pkg, ic, key_bits=30, max_depth=10, sort_variant=sort_variant)
+    b = orc.bbox(*ic[:3])
+    sk, perm = orc.sort(orc.keys(*ic[:3], b, 30))
+    for it in range(20):
+        e.upload(*ic)
+        e.bbox(); e.morton(); e.sort()
+        assert np.array_equal(e.download_order(), perm), it
+        assert np.array_equal(e.download_keys(), sk), it
+    assert e.stats().status_flags == 0
     e.close()
 
 
