@@ -67,7 +67,12 @@ typedef struct bh_params {
   int32_t sort_variant;  /* 0 = one kernel per radix pass with decoupled look-back (default),
                             1 = histogram + scan + scatter kernels per pass (no inter-workgroup
                             hand-off at all; A/B and fallback)                                     */
-  int32_t reserved[4];
+  int32_t literal_force; /* 1 = reproduce the reference BINARY instead of its intent: the force on
+                            every body is the root monopole G*M*(COM-p)/(|COM-p|^2+eps2)^(3/2),
+                            which is what computeForceKernel literally evaluates (`idx < n`
+                            accepts the root, ref:198,208) — for diffing
+                            trajectories against nbody_v5_bench.exe                              */
+  int32_t reserved[3];
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:
@@ -148,6 +153,11 @@ int bh_download_order(bh_ctx* c, int32_t* ids);    /* caller index of the body a
 int bh_download_sorted_bodies(bh_ctx* c, float* xyzm /* 4n floats */);
 int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries);
 int bh_download_counters(bh_ctx* c, uint32_t* V, uint32_t* O, uint32_t* P); /* caller order */
+int bh_download_mass(bh_ctx* c, float* m);                              /* caller order      */
+/* interleaved xyz positions and speed-mapped RGB colours, caller order, 3n floats each
+   (the reference viewer's updateVisualsKernel, nbody_v5.cu:278-292: t = min(|v|/150, 1),
+   rgb = (0.4+0.6t, 0.3+0.4t, 1-0.7t)); written to host buffers instead of a GL VBO */
+int bh_export_visual(bh_ctx* c, float* pos_xyz, float* col_rgb);
 int bh_get_stats(bh_ctx* c, bh_stats* s);
 int bh_set_timing(bh_ctx* c, int on);
 int bh_sync(bh_ctx* c);
@@ -167,6 +177,22 @@ int bh_n(const bh_ctx* c);
    Synchronises.  At most BH_TIMING_RING steps are kept. */
 #define BH_TIMING_RING 256
 int bh_timing_history(bh_ctx* c, float* ms_force, float* ms_step, int capacity, int* count);
+
+/* ---- state dump / restart (host side, no GPU needed) ---- */
+/* text format of the reference's older generation (output_bh.txt:1-4):
+     # Barnes-Hut N-Body Simulation Results / # Final positions and velocities after K steps /
+     # Bodies: N, Theta: T, dt: D / # Format: x y z vx vy vz / one "%f %f %f %f %f %f" row per body */
+int bh_write_text(const char* path, int n, int steps, float theta, float dt, const float* x,
+                  const float* y, const float* z, const float* vx, const float* vy, const float* vz);
+/* reads at most capacity bodies; *n_out = bodies in the file (BH_ERR_SMALL_BUFFER if more) */
+int bh_read_text(const char* path, int capacity, int* n_out, int* steps_out, float* x, float* y,
+                 float* z, float* vx, float* vy, float* vz);
+/* lossless binary snapshot: header {magic "BHSNAP01", n, steps, bh_params} + 7 SoA float arrays */
+int bh_write_snapshot(const char* path, int n, int steps, const bh_params* p, const float* x,
+                      const float* y, const float* z, const float* vx, const float* vy,
+                      const float* vz, const float* m);
+int bh_read_snapshot(const char* path, int capacity, int* n_out, int* steps_out, bh_params* p_out,
+                     float* x, float* y, float* z, float* vx, float* vy, float* vz, float* m);
 
 /* ---- synthetic initial conditions (host side; <-> IC loop ref:294-308) ---- */
 /* Plummer sphere, scale radius a, masses U[2,7) (same law as ref:302), counter-based

@@ -8,6 +8,7 @@ All compute runs in libbh.so (hand-written HIP for gfx950); nothing here compute
 """
 from ._lib import lib, BhParams, BhNode, BhStats, LIB_PATH  # noqa: F401
 from .engine import Engine, BhError, default_params, KIND_BODY, KIND_INTERNAL, KIND_MULTI  # noqa: F401
+from .engine import write_text, read_text, read_snapshot  # noqa: F401
 from .ic import plummer, disc  # noqa: F401
 
 # `dist` (multi-GPU stepping) imports torch; import it explicitly: from <pkg> import dist

@@ -18,7 +18,7 @@ class BhParams(C.Structure):
         ("max_speed", C.c_float),
         ("leaf_cap", C.c_int32), ("max_depth", C.c_int32), ("key_bits", C.c_int32),
         ("strict_fp", C.c_int32), ("force_variant", C.c_int32), ("xcd_mode", C.c_int32),
-        ("sort_variant", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("sort_variant", C.c_int32), ("literal_force", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -72,6 +72,13 @@ SYMBOLS = [
     ("bh_download_sorted_bodies", C.c_int, [_P, _F]),
     ("bh_download_tree", C.c_int, [_P, C.POINTER(BhNode), C.c_int, C.POINTER(C.c_int)]),
     ("bh_download_counters", C.c_int, [_P] + [C.POINTER(C.c_uint32)] * 3),
+    ("bh_download_mass", C.c_int, [_P, _F]),
+    ("bh_export_visual", C.c_int, [_P, _F, _F]),
+    ("bh_write_text", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_float] + [_F] * 6),
+    ("bh_read_text", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)] + [_F] * 6),
+    ("bh_write_snapshot", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(BhParams)] + [_F] * 7),
+    ("bh_read_snapshot", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(BhParams)] + [_F] * 7),
     ("bh_get_stats", C.c_int, [_P, C.POINTER(BhStats)]),
     ("bh_set_timing", C.c_int, [_P, C.c_int]),
     ("bh_sync", C.c_int, [_P]),

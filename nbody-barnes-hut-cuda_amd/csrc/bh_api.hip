@@ -388,6 +388,27 @@ int bh_download_acc(bh_ctx* c, float* ax, float* ay, float* az) {
   return bh_sync(c);
 }
 
+int bh_download_mass(bh_ctx* c, float* m) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  if (!m) return BH_ERR_BAD_ARG;
+  const size_t N = (size_t)c->n;
+  BH_HIP(c, bhk_unpack(c, 0));  // slot 6 of the staging buffer = mass in caller order
+  int s = d2h(c, m, c->stage_buf + 6 * N, N * sizeof(float));
+  if (s) return s;
+  return bh_sync(c);
+}
+
+int bh_export_visual(bh_ctx* c, float* pos_xyz, float* col_rgb) {
+  BH_NEED(c, BH_ST_UPLOADED);
+  if (!pos_xyz || !col_rgb) return BH_ERR_BAD_ARG;
+  const size_t N = (size_t)c->n;
+  BH_HIP(c, bhk_unpack(c, 3));
+  int s;
+  if ((s = d2h(c, pos_xyz, c->stage_buf, 3 * N * sizeof(float)))) return s;
+  if ((s = d2h(c, col_rgb, c->stage_buf + 3 * N, 3 * N * sizeof(float)))) return s;
+  return bh_sync(c);
+}
+
 int bh_download_counters(bh_ctx* c, uint32_t* V, uint32_t* O, uint32_t* P) {
   BH_NEED_EVER(c, BH_ST_FORCE);
   if (!V || !O || !P) return BH_ERR_BAD_ARG;

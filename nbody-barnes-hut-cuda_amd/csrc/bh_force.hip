@@ -600,6 +600,49 @@ __global__ __launch_bounds__(256) void unpack_acc_kernel(const float4* __restric
   s[j] = a.x; s[N + j] = a.y; s[2 * N + j] = a.z;
 }
 
+// the reference viewer's updateVisualsKernel (nbody_v5.cu:278-292) without the GL interop:
+// s[0..3n) = interleaved xyz, s[3n..6n) = speed-mapped rgb, both in caller order
+__global__ __launch_bounds__(256) void unpack_visual_kernel(const float4* __restrict__ posm,
+                                                            const float4* __restrict__ velid, int n,
+                                                            float* __restrict__ s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posm[i], v = velid[i];
+  const size_t j = (size_t)__float_as_int(v.w);
+  float* vp = s + 3 * j;
+  float* vc = s + 3 * (size_t)n + 3 * j;
+  vp[0] = p.x; vp[1] = p.y; vp[2] = p.z;
+  const float speed = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);  // v5:286
+  const float t = fminf(speed / 150.0f, 1.0f);                   // v5:287
+  vc[0] = 0.4f + t * 0.6f;                                       // v5:288-290
+  vc[1] = 0.3f + t * 0.4f;
+  vc[2] = 1.0f - t * 0.7f;
+}
+
+// what the reference binary's force kernel literally computes: the root is
+// accepted for every body because `idx < n` holds for idx = 0 (ref:198,208), so the force is the
+// root monopole; source-text arithmetic ref:205-213, accumulating from zero
+__global__ __launch_bounds__(256) void force_literal_kernel(const bh_node* __restrict__ rec,
+                                                            const float4* __restrict__ posm,
+                                                            float4* __restrict__ acc, int lo, int hi, float G,
+                                                            float eps2) {
+  const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  const bh_node r = rec[0];
+  const float4 p = posm[i];
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  if (r.m > 0.0f) {  // ref:203
+    const float dx = r.x - p.x, dy = r.y - p.y, dz = r.z - p.z;
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const float dist = sqrtf(d2 + eps2);
+    const float f = G * r.m / (dist * dist * dist);
+    ax += f * dx;
+    ay += f * dy;
+    az += f * dz;
+  }
+  acc[i] = make_float4(ax, ay, az, 0.0f);
+}
+
 __global__ __launch_bounds__(256) void unpack_u32x3_kernel(const u32* __restrict__ a, const u32* __restrict__ b,
                                                            const u32* __restrict__ c3,
                                                            const float4* __restrict__ velid, int n,
@@ -619,6 +662,10 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
   const bh_node* rec = c->rec;
   const float4* posm = c->posm[c->cur];
   const float G = c->p.G, th = c->p.theta, e2 = c->p.eps2;
+  if (c->p.literal_force && !count) {
+    force_literal_kernel<<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, e2);
+    return hipGetLastError();
+  }
   if (count) {
     if (c->p.strict_fp)
       force_kernel<true, true><<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, th, e2, c->cV, c->cO, c->cP, c->info);
@@ -664,8 +711,10 @@ hipError_t bhk_unpack(bh_ctx* c, int what) {
     unpack_state_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], n, c->stage_buf);
   else if (what == 1)
     unpack_acc_kernel<<<blocks, 256, 0, c->stream>>>(c->acc, c->velid[c->cur], n, c->stage_buf);
-  else
+  else if (what == 2)
     unpack_u32x3_kernel<<<blocks, 256, 0, c->stream>>>(c->cV, c->cO, c->cP, c->velid[c->cur], n,
                                                        (u32*)c->stage_buf);
+  else
+    unpack_visual_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], n, c->stage_buf);
   return hipGetLastError();
 }

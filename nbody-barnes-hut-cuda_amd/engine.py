@@ -26,6 +26,42 @@ def default_params(**kw):
     return p
 
 
+def write_text(path, steps, theta, dt, x, y, z, vx, vy, vz):
+    """host-only: -> bh_status"""
+    arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, z, vx, vy, vz)]
+    return lib.bh_write_text(path.encode(), len(arrs[0]), int(steps), float(theta), float(dt),
+                             *[a.ctypes.data_as(_F) for a in arrs])
+
+
+def read_text(path):
+    """host-only: -> (steps, x, y, z, vx, vy, vz)"""
+    n, steps = C.c_int(0), C.c_int(0)
+    st = lib.bh_read_text(path.encode(), 0, C.byref(n), C.byref(steps), *([None] * 6))
+    if st not in (0, -7):
+        raise BhError(st, "bh_read_text")
+    arrs = [np.empty(n.value, dtype=np.float32) for _ in range(6)]
+    st = lib.bh_read_text(path.encode(), n.value, C.byref(n), C.byref(steps),
+                          *[a.ctypes.data_as(_F) for a in arrs])
+    if st != 0:
+        raise BhError(st, "bh_read_text")
+    return (steps.value,) + tuple(arrs)
+
+
+def read_snapshot(path):
+    """host-only: -> (n, steps, BhParams, (x, y, z, vx, vy, vz, m))"""
+    n, steps = C.c_int(0), C.c_int(0)
+    p = BhParams()
+    st = lib.bh_read_snapshot(path.encode(), 0, C.byref(n), C.byref(steps), C.byref(p), *([None] * 7))
+    if st != 0:
+        raise BhError(st, "bh_read_snapshot")
+    arrs = [np.empty(n.value, dtype=np.float32) for _ in range(7)]
+    st = lib.bh_read_snapshot(path.encode(), n.value, C.byref(n), C.byref(steps), C.byref(p),
+                              *[a.ctypes.data_as(_F) for a in arrs])
+    if st != 0:
+        raise BhError(st, "bh_read_snapshot")
+    return n.value, steps.value, p, tuple(arrs)
+
+
 def _f32(a, n):
     a = np.ascontiguousarray(a, dtype=np.float32)
     if a.shape != (n,):
@@ -173,6 +209,40 @@ class Engine:
         s = BhStats()
         self._ck(lib.bh_get_stats(self._h, C.byref(s)), "bh_get_stats")
         return s
+
+    def download_mass(self):
+        m = np.empty(self.n, dtype=np.float32)
+        self._ck(lib.bh_download_mass(self._h, m.ctypes.data_as(_F)), "bh_download_mass")
+        return m
+
+    def export_visual(self):
+        """-> (pos[n,3], rgb[n,3]) as the reference viewer's updateVisualsKernel fills its VBOs
+        (nbody_v5.cu:278-292), in caller order."""
+        pos = np.empty((self.n, 3), dtype=np.float32)
+        col = np.empty((self.n, 3), dtype=np.float32)
+        self._ck(lib.bh_export_visual(self._h, pos.ctypes.data_as(_F), col.ctypes.data_as(_F)),
+                 "bh_export_visual")
+        return pos, col
+
+    # -- state dump / restart (SURVEY §8f-2)
+    def dump_text(self, path):
+        """final-state text dump in the older generation's format (output_bh.txt:1-4)"""
+        arrs = self.download()
+        self._ck(write_text(path, self.stats().steps, self.params.theta, self.params.dt, *arrs), "bh_write_text")
+
+    def save_snapshot(self, path):
+        arrs = list(self.download()) + [self.download_mass()]
+        st = lib.bh_write_snapshot(path.encode(), self.n, self.stats().steps, C.byref(self.params),
+                                   *[a.ctypes.data_as(_F) for a in arrs])
+        self._ck(st, "bh_write_snapshot")
+
+    @classmethod
+    def restore(cls, path, device=0, stream=None):
+        """new Engine from a binary snapshot (same parameters, bodies uploaded)"""
+        n, steps, params, arrs = read_snapshot(path)
+        e = cls(n, params=params, device=device, stream=stream)
+        e.upload(*arrs)
+        return e
 
     def timing_history(self):
         """-> (ms_force[], ms_step[]) of the most recent timed steps (hipEvent, engine stream)."""

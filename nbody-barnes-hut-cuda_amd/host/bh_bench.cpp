@@ -6,6 +6,9 @@
 // reference's run shape: disc IC, N = 500000 (:31), 1000 frames (:353).
 //   bh_bench [--n N] [--steps K] [--warmup W] [--ic disc|plummer] [--seed S] [--theta T]
 //            [--leaf-cap C] [--strict] [--quiet] [--device D]
+//            [--literal-force]   the root-monopole force the CUDA binary literally computes
+//            [--dump FILE]       final state in the older generation's text format (output_bh.txt:1-4)
+//            [--snapshot FILE]   lossless binary snapshot for restart
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +37,8 @@ int main(int argc, char** argv) {
   int warmup = 0;
   int device = 0;
   bool plummer = false, quiet = false;
+  const char* dump_path = nullptr;  // final state, older generation's text format (output_bh.txt:1-4)
+  const char* snap_path = nullptr;  // lossless binary snapshot (checkpoint)
   unsigned long long seed = 42;  // ref:294 srand(42)
   bh_params p;
   bh_default_params(&p);
@@ -47,6 +52,9 @@ int main(int argc, char** argv) {
     else if (arg("--leaf-cap")) p.leaf_cap = atoi(argv[++i]);
     else if (arg("--device")) device = atoi(argv[++i]);
     else if (arg("--ic")) plummer = !strcmp(argv[++i], "plummer");
+    else if (arg("--dump")) dump_path = argv[++i];
+    else if (arg("--snapshot")) snap_path = argv[++i];
+    else if (!strcmp(argv[i], "--literal-force")) p.literal_force = 1;  // what the CUDA binary computes (D1)
     else if (!strcmp(argv[i], "--strict")) p.strict_fp = 1;
     else if (!strcmp(argv[i], "--quiet")) quiet = true;
     else {
@@ -92,6 +100,17 @@ int main(int argc, char** argv) {
          "cells %d entries %d depth %d flags %d | avg force %.3f ms\n",
          st.ms_bbox, st.ms_morton, st.ms_sort, st.ms_build, st.ms_com, st.ms_force, st.ms_integrate,
          st.n_internal, st.n_entries, st.max_level, st.status_flags, sum_force / (frames > 0 ? frames : 1));
+  if (dump_path || snap_path) {
+    CK(bh_download(c, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data()));
+    if (dump_path)
+      CK(bh_write_text(dump_path, N, warmup + frames, p.theta, p.dt, x.data(), y.data(), z.data(), vx.data(),
+                       vy.data(), vz.data()));
+    if (snap_path) {
+      CK(bh_download_mass(c, m.data()));
+      CK(bh_write_snapshot(snap_path, N, warmup + frames, &p, x.data(), y.data(), z.data(), vx.data(),
+                           vy.data(), vz.data(), m.data()));
+    }
+  }
   bh_destroy(c);  // ref:372-387
   return 0;
 }
