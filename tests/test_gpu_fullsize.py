@@ -1,0 +1,107 @@
+"""Parity at BASELINE.json's full single-GPU sizes (500,000 and 1,000,000 bodies, theta 0.5 and 0.3)
+through size-independent properties, plus oracle checks on a bounded sample:
+  * keys sorted, sort is a permutation, gather consistent;
+  * the tree is a tree: children partition their parent's body range, every body in exactly one
+    leaf, every emitted cell branches, cells <= n-1, records <= 2n, edges halve;
+  * root mass/COM = total mass / mass-weighted mean (fp64 on the host);
+  * strict kernel on a 4096-body slab == oracle walking the GPU's tree, bit for bit, and the V/O/P
+    counters of the slab match;
+  * fast kernel vs strict kernel within the stated tolerance over ALL bodies;
+  * a whole step conserves the body set and the sticky flags stay clear.
+"""
+import numpy as np
+import pytest
+
+from helpers import oparams
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [(500_000, 0.5), (1_000_000, 0.5), (1_000_000, 0.3)]
+
+
+def _tree_invariants_vectorised(rec, n):
+    kind, first, count, s = rec["kind"], rec["first"], rec["count"], rec["s"]
+    internal = np.flatnonzero(kind == 1)
+    assert len(internal) <= n - 1 and len(rec) <= 2 * n
+    assert count[internal].min() >= 2 and count[internal].max() <= 8   # every emitted cell branches
+    # every record except the root is the child of exactly one cell
+    ref = np.zeros(len(rec), np.int32)
+    starts = first[internal]
+    for k in range(8):
+        sel = count[internal] > k
+        np.add.at(ref, starts[sel] + k, 1)
+    assert ref[0] == 0 and np.all(ref[1:] == 1)
+    # body ranges: leaves cover [0, n) exactly once
+    leaves = np.flatnonzero(kind != 1)
+    lo = first[leaves].astype(np.int64)
+    cnt = np.where(kind[leaves] == 0, 1, count[leaves]).astype(np.int64)
+    order = np.argsort(lo)
+    lo, cnt = lo[order], cnt[order]
+    assert lo[0] == 0 and np.array_equal(lo[1:], (lo + cnt)[:-1]) and lo[-1] + cnt[-1] == n
+    # child edges are strictly smaller than the parent's
+    for k in range(8):
+        sel = count[internal] > k
+        ch = starts[sel] + k
+        cell = kind[ch] != 0
+        assert np.all(s[ch][cell] < s[internal[sel]][cell])
+    assert np.all(s[kind == 0] == -1.0)
+
+
+@pytest.mark.parametrize("n,theta", CONFIGS)
+def test_fullsize_properties(pkg, orc, n, theta):
+    ic = pkg.plummer(n, seed=42)
+    e = pkg.Engine(n, theta=theta, strict_fp=1)
+    e.upload(*ic)
+    e.tree_stages()
+    keys = e.download_keys()
+    assert np.all(keys[1:] >= keys[:-1])                                  # sortedness
+    order = e.download_order()
+    seen = np.zeros(n, np.bool_)
+    seen[order] = True
+    assert seen.all()                                                      # a permutation
+    bodies = e.download_sorted_bodies()
+    assert np.array_equal(bodies[:, 0], ic[0][order]) and np.array_equal(bodies[:, 3], ic[6][order])
+    rec = e.download_tree()
+    st = e.stats()
+    assert st.status_flags == 0 and st.n_entries == len(rec)
+    assert st.n_internal == int((rec["kind"] == 1).sum())
+    _tree_invariants_vectorised(rec, n)
+    m64 = ic[6].astype(np.float64)
+    M = m64.sum()
+    assert abs(float(rec["m"][0]) - M) <= 1e-6 * M
+    for f, a in (("x", ic[0]), ("y", ic[1]), ("z", ic[2])):
+        want = (m64 * a.astype(np.float64)).sum() / M
+        assert abs(float(rec[f][0]) - want) <= 1e-5 * 400.0
+    # strict kernel on a slab vs the oracle on the GPU's own tree (bit-exact, counters too)
+    lo = (n // 2) // 64 * 64
+    hi = lo + 4096
+    e.force_count()
+    gV, gO, gP = e.download_counters()
+    ax, ay, az = e.download_acc()
+    p = oparams(orc, e.params)
+    oacc, V, O, P = orc.force(rec, bodies, p, orc.ORDER_BATCHED, lo, hi)
+    sel = order[lo:hi]
+    assert np.array_equal(ax[sel], oacc[lo:hi, 0])
+    assert np.array_equal(ay[sel], oacc[lo:hi, 1])
+    assert np.array_equal(az[sel], oacc[lo:hi, 2])
+    assert np.array_equal(gV[sel], V[lo:hi]) and np.array_equal(gO[sel], O[lo:hi]) and np.array_equal(gP[sel], P[lo:hi])
+    strict = np.stack([ax, ay, az], 1)
+    e.close()
+    # fast kernel over all bodies vs strict.  Stated fp32 tolerance, as a distribution (a MAC
+    # decision can flip on a 1-ulp tie among ~1e9-1e10 decisions; the flipped cell then differs by
+    # one cell's Barnes-Hut truncation error, itself far below the method's ~1e-3 error):
+    # median <= 2e-6, 99.99th percentile <= 1e-4, max <= 1e-3 relative
+    f = pkg.Engine(n, theta=theta)
+    f.upload(*ic)
+    f.tree_stages(); f.force()
+    fast = np.stack(f.download_acc(), 1)
+    rel = np.linalg.norm(fast - strict, axis=1) / np.linalg.norm(strict, axis=1)
+    assert np.median(rel) <= 2e-6 and np.percentile(rel, 99.99) <= 1e-4 and rel.max() <= 1e-3
+    # one whole step keeps the body set intact
+    f.integrate()
+    f.step(2)
+    x, y, z, vx, vy, vz = f.download()
+    assert np.isfinite(x).all() and np.isfinite(vx).all()
+    assert np.array_equal(f.download_mass(), ic[6])                        # ids still line up
+    assert f.stats().status_flags == 0
+    f.close()
