@@ -73,7 +73,7 @@ static void free_all(bh_ctx* c) {
   void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sw_hist, c->sw_status,
                   c->sw_ticket, c->bbox_partial,
-                  c->bounds, c->d8, c->pa, c->pb, c->pn,
+                  c->bounds, c->d8, c->ksamp, c->pa, c->pb, c->pn,
                   c->cb, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
   for (void* p : ptrs)
@@ -152,6 +152,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->bbox_partial, (size_t)BH_BBOX_BLOCKS * 6) == hipSuccess;
   ok = ok && dalloc(&c->bounds, 8) == hipSuccess;
   ok = ok && dalloc(&c->d8, N + 1) == hipSuccess;
+  ok = ok && dalloc(&c->ksamp, (size_t)2048 + 8) == hipSuccess;
   ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->cb, N + 1) == hipSuccess;

@@ -80,6 +80,7 @@ struct bh_ctx {
 
   // tree build temporaries
   signed char* d8;  // [n+1] leading octal digits shared by keys j-1, j; d8[0] = d8[n] = -1
+  u64* ksamp;       // [<= 2048] every 2^ss-th sorted key (bisection seeds of the wide-cell searches)
   int* pa;        // [n] first body of the cell whose first child boundary is j
   int* pb;        // [n] end body of that cell
   int* pn;        // [n] its child count (0: j represents no emitted cell)

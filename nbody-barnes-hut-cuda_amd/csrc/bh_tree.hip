@@ -220,6 +220,59 @@ __device__ __forceinline__ int cell_start(const u64* __restrict__ k, int j, int 
   return hi;
 }
 
+// Sampled lower bound for the wide-cell searches: first index i in [0, n] with (k[i] >> sh) >= T.
+// `samp` (in LDS) holds every (1 << ss)-th key, so the first ~11 bisection steps cost LDS reads and
+// the dependent GLOBAL loads drop from ~log2(n) to ~ss, all inside one 2^ss-key (32 KiB) span.
+constexpr int kSampMax = 2048;
+__device__ __forceinline__ int key_lower_bound(const u64* __restrict__ k, int n, const u64* samp, int ns,
+                                               int ss, int sh, u64 T) {
+  int l = 0, h = ns;  // first sample whose prefix is >= T
+  while (l < h) {
+    const int mid = l + ((h - l) >> 1);
+    if (key_prefix(samp[mid], sh) < T) l = mid + 1; else h = mid;
+  }
+  if (l == 0) return 0;
+  int lo = ((l - 1) << ss) + 1;  // k[(l-1) << ss] < T
+  int hi = min(l << ss, n);      // k[l << ss] >= T, or past the end
+  // invariant: the answer is in [lo, hi].  16-ary rounds: 16 independent probes in flight per
+  // lane, so a 4096-key span costs 3 memory round trips instead of 12 dependent ones (measured:
+  // each dependent random probe of the key array costs ~2.5 us here).
+  while (hi - lo > 16) {
+    const int step = (hi - lo + 15) >> 4;
+    u64 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = k[min(lo + i * step + step - 1, hi - 1)];
+    int first = 16;
+#pragma unroll
+    for (int i = 15; i >= 0; i--)
+      if (key_prefix(v[i], sh) >= T) first = i;
+    if (first == 16) {  // every probe (the last one is hi-1) is below T
+      lo = hi;
+      break;
+    }
+    const int nlo = (first == 0) ? lo : min(lo + (first - 1) * step + step - 1, hi - 1) + 1;
+    hi = min(lo + first * step + step - 1, hi - 1);
+    lo = nlo;
+  }
+  if (hi > lo) {  // at most 16 keys left: one more round trip
+    u64 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = k[min(lo + i, hi - 1)];
+    int first = hi - lo;
+#pragma unroll
+    for (int i = 15; i >= 0; i--)
+      if (i < hi - lo && key_prefix(v[i], sh) >= T) first = i;
+    lo += first;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void ksample_kernel(const u64* __restrict__ k, int n, int ss,
+                                                      u64* __restrict__ samp, int ns) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ns) samp[i] = k[(size_t)i << ss];
+}
+
 // child boundaries of cell [a,b) at the level whose digit shift is dsh:
 // pos[v] = first j in [a,b) with digit(k[j]) >= v
 __device__ __forceinline__ void child_bounds(const u64* __restrict__ k, int a, int b, int dsh,
@@ -312,9 +365,19 @@ __device__ __forceinline__ int count_between(const u64* row, int p, int q) {  //
 __device__ __forceinline__ void build_window(const signed char* __restrict__ d, int n, int base,
                                              u64 (*m)[kPairWords], signed char* dl) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int s = threadIdx.x; s < kPairWin; s += 256) {
-    const int g = base + s;
-    dl[s] = (g < 0 || g > n) ? (signed char)-1 : d[g];
+  // one 16-byte load per thread (192 threads cover the window); a byte-per-thread loop compiles
+  // to 12 serialized global round trips per block and dominated this kernel
+  for (int s = threadIdx.x * 16; s < kPairWin; s += 256 * 16) {
+    const int g0 = base + s;
+    if (g0 >= 0 && g0 + 15 <= n) {
+      *reinterpret_cast<uint4*>(dl + s) = *reinterpret_cast<const uint4*>(d + g0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int g = g0 + q;
+        dl[s + q] = (g < 0 || g > n) ? (signed char)-1 : d[g];
+      }
+    }
   }
   __syncthreads();
   for (int w = wv; w < kPairWords; w += 4) {
@@ -330,10 +393,12 @@ __device__ __forceinline__ void build_window(const signed char* __restrict__ d, 
 
 __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
                                                     const signed char* __restrict__ d, int n, int B, int D,
-                                                    int cap, int* __restrict__ pa, int* __restrict__ pb,
+                                                    int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                                    int* __restrict__ pa, int* __restrict__ pb,
                                                     int* __restrict__ pn, bh_devinfo* __restrict__ info) {
+  __shared__ u64 s_samp[kSampMax];
   __shared__ u64 m[kPairLevels][kPairWords];
-  __shared__ signed char dl[kPairWin];
+  __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
   const int t0 = blockIdx.x * kPairTile;
   const int base = t0 - kPairTile;  // global position of window slot 0
   const int lane = threadIdx.x & 63;
@@ -388,21 +453,23 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   {
     const int sub = threadIdx.x & 7;
     const int nw = nwide;
+    if (nw > 0) {  // block-uniform: stage the key samples for the bisection seeds
+      for (int s = threadIdx.x; s < ns; s += 256) s_samp[s] = ksamp[s];
+    }
+    __syncthreads();
     for (int idx = threadIdx.x >> 3; idx < nw; idx += 32) {
       const int p = wide[idx];
       const int j = base + p;
       const int L = dl[p];
       const int sh = 3 * (B - L), dsh = 3 * (B - 1 - L);
-      const int a = cell_start(k, j - 1, sh);
+      const u64 pj = key_prefix(k[j], sh);
+      const int a = key_lower_bound(k, n, s_samp, ns, ss, sh, pj);
       int nc = 0, b = 0;
       if (((k[j - 1] >> dsh) & 7ull) == ((k[a] >> dsh) & 7ull)) {  // j is the first child boundary
-        b = cell_end(k, n, j, sh);
+        b = key_lower_bound(k, n, s_samp, ns, ss, sh, pj + 1ull);
         if (b - a > cap) {
-          int l = a, h = b;  // lower bound of digit >= sub in [a, b)
-          while (l < h) {
-            const int mid = l + ((h - l) >> 1);
-            if ((int)((k[mid] >> dsh) & 7ull) < sub) l = mid + 1; else h = mid;
-          }
+          // lower bound of digit >= sub inside the cell = first key with (L+1)-digit prefix >= pj*8+sub
+          const int l = (sub == 0) ? a : key_lower_bound(k, n, s_samp, ns, ss, dsh, (pj << 3) | (u64)sub);
           int nxt = __shfl_down(l, 1, 8);
           if (sub == 7) nxt = b;
           const u64 bal = __ballot(nxt > l);
@@ -420,16 +487,31 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       }
     }
   }
-  if (cells) {  // integer atomics: totals are order-independent
-    atomicAdd(&info->n_internal, cells);
-    atomicMax(&info->max_level, maxl);
+  // tree statistics: reduce in LDS, then ONE pair of global atomics per block (a global atomic per
+  // thread put ~31K same-address atomics in a row: 90 of this kernel's 116 us at 1M bodies).
+  // Integer sums / maxima: order-independent.
+  __shared__ int s_cells, s_maxl;
+  if (threadIdx.x == 0) {
+    s_cells = 0;
+    s_maxl = 0;
+  }
+  __syncthreads();
+  if (cells) {
+    atomicAdd(&s_cells, cells);
+    atomicMax(&s_maxl, maxl);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cells) {
+    atomicAdd(&info->n_internal, s_cells);
+    atomicMax(&info->max_level, s_maxl);
   }
 }
 
 // classify the child cell [c0,c1) of a cell at level L and fill the topology fields of its record
 __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, int D, int cap, float s0,
                                               const int* __restrict__ pn, const int* __restrict__ cb,
-                                              int c0, int c1, int child_level) {
+                                              int c0, int c1, int child_level, int n = 0,
+                                              const u64* samp = nullptr, int ns = 0, int ss = 0) {
   bh_node r;
   r.x = r.y = r.z = r.m = 0.0f;
   const int m = c1 - c0;
@@ -457,11 +539,18 @@ __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, 
   }
   // representative = first index whose digit at level Lb exceeds that of key c0
   const int dsh = 3 * (B - 1 - Lb);
-  const int g0 = (int)((k[c0] >> dsh) & 7ull);
-  int l = c0 + 1, h = c1 - 1;  // digit(k[c1-1]) > g0, so the answer is in [c0+1, c1-1]
-  while (l < h) {
-    const int mid = l + ((h - l) >> 1);
-    if ((int)((k[mid] >> dsh) & 7ull) > g0) h = mid; else l = mid + 1;
+  int l;
+  if (samp != nullptr && c1 - c0 > 64) {
+    // == first key whose (Lb+1)-digit prefix is >= prefix(k[c0]) + 1 (sample-seeded bisection)
+    l = key_lower_bound(k, n, samp, ns, ss, dsh, (k[c0] >> dsh) + 1ull);
+  } else {
+    const int g0 = (int)((k[c0] >> dsh) & 7ull);
+    int h = c1 - 1;  // digit(k[c1-1]) > g0, so the answer is in [c0+1, c1-1]
+    l = c0 + 1;
+    while (l < h) {
+      const int mid = l + ((h - l) >> 1);
+      if ((int)((k[mid] >> dsh) & 7ull) > g0) h = mid; else l = mid + 1;
+    }
   }
   r.kind = BH_KIND_INTERNAL;
   r.first = 1 + cb[l];
@@ -513,15 +602,17 @@ __device__ __forceinline__ bh_node make_child_win(u64 (*m)[kPairWords], int base
 
 __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
                                                    const signed char* __restrict__ d, int n, int B, int D,
-                                                   int cap, const int* __restrict__ pa,
+                                                   int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                                   const int* __restrict__ pa,
                                                    const int* __restrict__ pb, const int* __restrict__ pn,
                                                    const int* __restrict__ cb,
                                                    const float* __restrict__ bounds,
                                                    bh_node* __restrict__ rec, int* __restrict__ er_lo,
                                                    int* __restrict__ er_hi, int rec_cap,
                                                    bh_devinfo* __restrict__ info) {
+  __shared__ u64 s_samp[kSampMax];
   __shared__ u64 m[kPairLevels][kPairWords];
-  __shared__ signed char dl[kPairWin];
+  __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
   const int t0 = blockIdx.x * kPairTile;
   const int base = t0 - kPairTile;
   build_window(d, n, base, m, dl);
@@ -574,17 +665,19 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   {
     const int lane = threadIdx.x & 63, sub = threadIdx.x & 7;
     const int nw = nwide;
+    if (nw > 0) {  // block-uniform: stage the key samples for the bisection seeds
+      for (int s = threadIdx.x; s < ns; s += 256) s_samp[s] = ksamp[s];
+    }
+    __syncthreads();
     for (int idx = threadIdx.x >> 3; idx < nw; idx += 32) {
       const int p = wide[idx];
       const int j = base + p;
       const int L = dl[p];
       const int a = pa[j], b = pb[j];
       const int dsh = 3 * (B - 1 - L);
-      int l = a, h = b;  // lower bound of digit >= sub in [a, b)
-      while (l < h) {
-        const int mid = l + ((h - l) >> 1);
-        if ((int)((k[mid] >> dsh) & 7ull) < sub) l = mid + 1; else h = mid;
-      }
+      // lower bound of digit >= sub inside the cell = first key with (L+1)-digit prefix >= pj*8+sub
+      const u64 pj8 = (k[a] >> dsh) & ~7ull;
+      const int l = (sub == 0) ? a : key_lower_bound(k, n, s_samp, ns, ss, dsh, pj8 | (u64)sub);
       int nxt = __shfl_down(l, 1, 8);
       if (sub == 7) nxt = b;
       const bool nonempty = nxt > l;
@@ -592,7 +685,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       if (nonempty) {
         const int e = 1 + cb[j] + __popcll(grp & ((1ull << sub) - 1ull));
         if (e < rec_cap) {
-          rec[e] = make_child(k, B, D, cap, s0, pn, cb, l, nxt, L + 1);
+          rec[e] = make_child(k, B, D, cap, s0, pn, cb, l, nxt, L + 1, n, s_samp, ns, ss);
           er_lo[e] = l;
           er_hi[e] = nxt;
         }
@@ -681,11 +774,18 @@ hipError_t bhk_build(bh_ctx* c) {
   hipError_t e = hipMemsetAsync(c->info, 0, 3 * sizeof(int), c->stream);
   if (e != hipSuccess) return e;
   lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8);
+  // every 2^ss-th key, at most kSampMax of them: bisection seeds of the wide-cell searches
+  int ss = 12;
+  while (((n + (1 << ss) - 1) >> ss) > kSampMax) ss++;
+  const int ns = (n + (1 << ss) - 1) >> ss;
+  ksample_kernel<<<(ns + 255) / 256, 256, 0, c->stream>>>(k, n, ss, c->ksamp, ns);
   pairs_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
-                                                                        c->pa, c->pb, c->pn, c->info);
+                                                                        c->ksamp, ns, ss, c->pa, c->pb, c->pn,
+                                                                        c->info);
   e = bhk_scan_i32(c, c->pn, c->cb, n, nullptr);  // child-block offsets; cb[n] = total children
   if (e != hipSuccess) return e;
-  emit_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->pa,
+  emit_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
+                                                                       c->ksamp, ns, ss, c->pa,
                                                                        c->pb, c->pn, c->cb, c->bounds, c->rec,
                                                                        c->er_lo, c->er_hi, c->rec_cap, c->info);
   return hipGetLastError();
