@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="fast force kernel: 0 scalar DFS (default), 1 batched")
     ap.add_argument("--xcd-mode", type=int, default=0, help="tuning: block->chunk placement (bh_params.xcd_mode)")
     ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
+    ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,7 +116,7 @@ def main():
     from nbody_barnes_hut_cuda_amd import dist as bhdist
     eng, stepper = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
                                            force_variant=args.variant, xcd_mode=args.xcd_mode,
-                                           leaf_cap=args.leaf_cap)
+                                           leaf_cap=args.leaf_cap, force_block=args.force_block)
     eng.upload(*ic)
 
     def barrier():

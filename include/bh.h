@@ -72,7 +72,9 @@ typedef struct bh_params {
                             which is what computeForceKernel literally evaluates (`idx < n`
                             accepts the root, ref:198,208) — for diffing
                             trajectories against nbody_v5_bench.exe                              */
-  int32_t reserved[3];
+  int32_t force_block;   /* threads per workgroup of the default force kernel: 64, 128 or 256
+                            (0 = library default); waves never cooperate, speed only           */
+  int32_t reserved[2];
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:

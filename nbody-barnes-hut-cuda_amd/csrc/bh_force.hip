@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int chunk = block_chunk(xcd_mode);
-  const int i = lo + (chunk * 4 + wib) * 64 + lane;
+  // waves never cooperate, so the workgroup may be 1, 2 or 4 waves (bh_params.force_block): a CU
+  // slot is released when its LAST wave retires, and per-wave work varies by +-30 %
+  const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * 64 + lane;
   const bool valid = i < hi;
   float px, py, pz;
   {
@@ -680,10 +682,14 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       if (mode == 2) grid = (blocks + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
       if (c->p.force_variant == 3 && c->rec_cap < (1 << 28))
         return bhk_force_fast(c, lo, hi);  // bh_force_fast.hip (scalar overhead trimmed; measured 4 % slower)
-      if (c->p.force_variant != 1 || c->rec_cap >= (1 << 28))
-        force_fast_kernel<<<grid, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                     mode, c->info);
-      else
+      if (c->p.force_variant != 1 || c->rec_cap >= (1 << 28)) {
+        int tpb = c->p.force_block;  // 64, 128 or 256 threads per workgroup (0 = default)
+        if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
+        int g2 = (hi - lo + tpb - 1) / tpb;
+        if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+        force_fast_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
+                                                   mode, c->info);
+      } else
         force_batched_kernel<<<grid, 256, 0, c->stream>>>((const float4*)c->frec, posm, c->acc, lo, hi, G, e2,
                                                         c->rec_cap, mode, c->info);
     }

@@ -107,6 +107,7 @@ struct bh_ctx {
   long timed_steps;    // steps recorded into the ring since timing was switched on
 };
 
+#define BH_FORCE_BLOCK_DEFAULT 256
 #define BH_BBOX_BLOCKS 1024
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
 #define BH_SORT_ITEMS 16
