@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256) void keys_kernel(const float4* __restrict__ po
 // Every emitted internal cell BRANCHES (>= 2 non-empty octants), so it has a first child
 // boundary j: keys j-1 and j share exactly L = level digits.  Conversely each adjacent pair
 // (j-1, j) with d = common digits < D names the cell at level d containing both.  Thread j
-//   - finds that cell's start a (gallop + bisect on the top-d-digit prefix),
-//   - is the cell's representative iff key j-1 still has key a's digit at level d,
-//   - if so finds the end b, the <= 8 child ranges, and records nchild[j].
+//   - finds that cell's start a (nearest i < j with d[i] < d[j]),
+//   - is the cell's representative iff no boundary of the same level lies between a and j,
+//   - if so finds the end b, counts the <= 8 children, and records nchild[j]
+// (pairs_kernel below: LDS-window bitmask queries; key searches only for cells wider than the window).
 // One exclusive scan of nchild[] places each cell's children in one contiguous block; the
 // representative index j doubles as the cell id, so no compaction pass is needed.
 __device__ __forceinline__ int common_digits(u64 a, u64 b, int B) {
@@ -175,50 +176,6 @@ __device__ __forceinline__ int common_digits(u64 a, u64 b, int B) {
 }
 
 __device__ __forceinline__ u64 key_prefix(u64 k, int sh) { return (sh >= 64) ? 0ull : (k >> sh); }
-
-// first index in (a, n] whose prefix differs from key a's (galloping + bisection)
-__device__ __forceinline__ int cell_end(const u64* __restrict__ k, int n, int a, int sh) {
-  const u64 pa = key_prefix(k[a], sh);
-  int lo = a, step = 1;  // invariant: prefix(lo) == pa
-  int hi;
-  for (;;) {
-    hi = lo + step;
-    if (hi >= n) {
-      hi = n;
-      break;
-    }
-    if (key_prefix(k[hi], sh) != pa) break;
-    lo = hi;
-    step <<= 1;
-  }
-  while (hi - lo > 1) {
-    const int mid = lo + ((hi - lo) >> 1);
-    if (key_prefix(k[mid], sh) == pa) lo = mid; else hi = mid;
-  }
-  return hi;
-}
-
-// smallest index whose prefix equals key j's, searching left of j
-__device__ __forceinline__ int cell_start(const u64* __restrict__ k, int j, int sh) {
-  const u64 pj = key_prefix(k[j], sh);
-  int hi = j, step = 1;  // invariant: prefix(hi) == pj
-  int lo;
-  for (;;) {
-    lo = hi - step;
-    if (lo < 0) {
-      lo = -1;
-      break;
-    }
-    if (key_prefix(k[lo], sh) != pj) break;
-    hi = lo;
-    step <<= 1;
-  }
-  while (hi - lo > 1) {
-    const int mid = lo + ((hi - lo) >> 1);
-    if (key_prefix(k[mid], sh) == pj) hi = mid; else lo = mid;
-  }
-  return hi;
-}
 
 // Sampled lower bound for the wide-cell searches: first index i in [0, n] with (k[i] >> sh) >= T.
 // `samp` (in LDS) holds every (1 << ss)-th key, so the first ~11 bisection steps cost LDS reads and
@@ -308,23 +265,6 @@ __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int
   d[j] = (j == 0 || j == n) ? (signed char)-1 : (signed char)common_digits(k[j - 1], k[j], B);
 }
 
-// the key-search path for pair j at level L (cells wider than the LDS window of pairs_kernel)
-__device__ __forceinline__ int pair_global(const u64* __restrict__ k, int n, int B, int cap, int j, int L,
-                                           int* a_out, int* b_out) {
-  const int sh = 3 * (B - L), dsh = 3 * (B - 1 - L);
-  const int a = cell_start(k, j - 1, sh);
-  if (((k[j - 1] >> dsh) & 7ull) != ((k[a] >> dsh) & 7ull)) return 0;  // not the first boundary
-  const int b = cell_end(k, n, j, sh);
-  if (b - a <= cap) return 0;
-  int pos[9], nc = 0;
-  child_bounds(k, a, b, dsh, pos);
-#pragma unroll
-  for (int v = 0; v < 8; v++) nc += (pos[v + 1] > pos[v]) ? 1 : 0;
-  *a_out = a;
-  *b_out = b;
-  return nc;
-}
-
 // Cell of pair j at level L = d[j]:   start a = nearest i < j with d[i] < L,
 //                                     end   b = nearest i > j with d[i] < L,
 //   j is its first child boundary iff the nearest i < j with d[i] <= L already has d[i] < L,
@@ -333,7 +273,8 @@ __device__ __forceinline__ int pair_global(const u64* __restrict__ k, int n, int
 // 1024 consecutive pairs inside an LDS window of 3072 positions (1024 of halo each side) using
 // per-level bitmasks  m[v+1][w] = ballot(d <= v)  built with wave64 ballots: a query is a masked
 // word, a short word scan, and clz / ctz / popcount.  Only cells that reach beyond the window
-// (about one pair per thousand) take the dependent global key searches of pair_global().
+// (about one pair per thousand) are deferred to phase 2: sample-seeded 16-ary searches on the keys,
+// 8 lanes per cell (key_lower_bound above).
 constexpr int kPairTile = 1024;
 constexpr int kPairWin = 3 * kPairTile;
 constexpr int kPairWords = kPairWin / 64;  // 48
