@@ -83,6 +83,10 @@ static void free_all(bh_ctx* c) {
       if (c->evring[i]) (void)hipEventDestroy(c->evring[i]);
     free(c->evring);
   }
+  if (c->scan_tmp2) (void)hipFree(c->scan_tmp2);
+  if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
+  if (c->ev_pscan) (void)hipEventDestroy(c->ev_pscan);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -163,6 +167,10 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->P, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->info, 1) == hipSuccess;
   ok = ok && hipMalloc(&c->scan_tmp, c->scan_tmp_bytes) == hipSuccess;
+  ok = ok && hipMalloc(&c->scan_tmp2, c->scan_tmp_bytes) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_pscan, hipEventDisableTiming) == hipSuccess;
   ok = ok && dalloc(&c->cV, N) == hipSuccess && dalloc(&c->cO, N) == hipSuccess &&
        dalloc(&c->cP, N) == hipSuccess;
   if (!ok) {
@@ -189,6 +197,7 @@ void bh_destroy(bh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   free_all(c);
 }
 
@@ -342,9 +351,23 @@ int bh_step(bh_ctx* c) {
   BH_MARK(2);
   BH_HIP(c, bhk_sort(c));                      // ref:262-264
   BH_MARK(3);
-  BH_HIP(c, bhk_build(c));                     // ref:266-275
-  BH_MARK(4);
-  BH_HIP(c, bhk_com(c));                       // ref:279-280
+  // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan
+  // on the side stream while the main stream builds the tree (both are small, latency-bound grids)
+  static const bool overlap = getenv("BH_NO_OVERLAP") == nullptr;  // A/B switch
+  if (overlap) {
+    BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
+    BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
+    BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, true));
+    BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
+    BH_HIP(c, bhk_build(c));                     // ref:266-275
+    BH_MARK(4);
+    BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
+    BH_HIP(c, bhk_com_records(c));               // ref:279-280
+  } else {
+    BH_HIP(c, bhk_build(c));
+    BH_MARK(4);
+    BH_HIP(c, bhk_com(c));
+  }
   BH_MARK(5);
   BH_HIP(c, bhk_force(c, 0, c->n, false));     // ref:281
   BH_MARK(6);

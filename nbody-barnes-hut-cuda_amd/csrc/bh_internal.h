@@ -96,6 +96,10 @@ struct bh_ctx {
   // scan scratch
   void* scan_tmp;
   size_t scan_tmp_bytes;
+  // side stream: bh_step runs the COM prefix scan here, concurrently with the tree build
+  hipStream_t stream2;
+  hipEvent_t ev_sorted, ev_pscan;
+  void* scan_tmp2;
 
   // counters (bh_force_count)
   u32 *cV, *cO, *cP;
@@ -128,5 +132,6 @@ hipError_t bhk_integrate(bh_ctx* c);
 
 // device-wide scans (bh_scan.hip)
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);
-hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n);
+hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n, bool side);
+hipError_t bhk_com_records(bh_ctx* c);  // second half of bhk_com: records from the prefix sums
 size_t bhk_scan_tmp_bytes(int n);

@@ -152,13 +152,14 @@ __global__ __launch_bounds__(kThreads) void scan_apply_kernel(Load load, int n_s
 }
 
 template <typename Op, typename Load>
-hipError_t run_scan(bh_ctx* c, Load load, typename Op::T* out, int n, const int* n_dev) {
+hipError_t run_scan(hipStream_t stream, void* tmp, Load load, typename Op::T* out, int n,
+                    const int* n_dev) {
   typedef typename Op::T T;
   const int ntiles = (n + kTile - 1) / kTile;
-  T* sums = reinterpret_cast<T*>(c->scan_tmp);
-  scan_reduce_kernel<Op, Load><<<ntiles, kThreads, 0, c->stream>>>(load, n, n_dev, sums);
-  scan_tiles_kernel<Op><<<1, 1024, 0, c->stream>>>(sums, ntiles);
-  scan_apply_kernel<Op, Load><<<ntiles, kThreads, 0, c->stream>>>(load, n, n_dev, sums, ntiles, out);
+  T* sums = reinterpret_cast<T*>(tmp);
+  scan_reduce_kernel<Op, Load><<<ntiles, kThreads, 0, stream>>>(load, n, n_dev, sums);
+  scan_tiles_kernel<Op><<<1, 1024, 0, stream>>>(sums, ntiles);
+  scan_apply_kernel<Op, Load><<<ntiles, kThreads, 0, stream>>>(load, n, n_dev, sums, ntiles, out);
   return hipGetLastError();
 }
 
@@ -170,9 +171,12 @@ size_t bhk_scan_tmp_bytes(int n) {
 }
 
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out, int n, const int* n_dev) {
-  return run_scan<OpI32>(c, LoadI32{in}, out, n, n_dev);
+  return run_scan<OpI32>(c->stream, c->scan_tmp, LoadI32{in}, out, n, n_dev);
 }
 
-hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out, int n) {
-  return run_scan<OpD4>(c, LoadPM{posm}, out, n, nullptr);
+// side = true: run on the context's side stream with its own scratch (bh_step overlaps this scan,
+// which needs only the sorted bodies, with the tree build, which needs only the sorted keys)
+hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out, int n, bool side) {
+  return run_scan<OpD4>(side ? c->stream2 : c->stream, side ? c->scan_tmp2 : c->scan_tmp, LoadPM{posm}, out,
+                        n, nullptr);
 }

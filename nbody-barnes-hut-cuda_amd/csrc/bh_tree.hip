@@ -733,9 +733,12 @@ hipError_t bhk_build(bh_ctx* c) {
 }
 
 hipError_t bhk_com(bh_ctx* c) {
-  const int n = c->n;
-  hipError_t e = bhk_scan_pm(c, c->posm[c->cur], c->P, n);
+  hipError_t e = bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, false);
   if (e != hipSuccess) return e;
+  return bhk_com_records(c);
+}
+
+hipError_t bhk_com_records(bh_ctx* c) {
   const int blocks = (c->rec_cap + 255) / 256;
   com_kernel<<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info, c->rec_cap,
                                             c->posm[c->cur], c->P);
