@@ -115,6 +115,7 @@ typedef struct bh_stats {
 #define BH_FLAG_POOL_OVERFLOW 1
 #define BH_FLAG_STACK_OVERFLOW 2
 #define BH_FLAG_SORT_TIMEOUT 4 /* a look-back spin of the radix sort hit its bound: order invalid */
+#define BH_FLAG_TRAVERSAL_LIMIT 128 /* a wave popped > 2^22 cells: malformed record pool, forces invalid */
 
 /* ---- lifecycle ( <-> cudaMalloc block ref:311-326, cudaFree ref:372-387 ) ---- */
 int bh_abi_version(void);
@@ -173,6 +174,72 @@ int bh_device_acc(bh_ctx* c, void** dptr, int64_t* bytes);
    engine's own buffer.  The caller keeps the buffer alive while it is bound. */
 int bh_bind_acc(bh_ctx* c, void* device_float4_n);
 int bh_n(const bh_ctx* c);
+
+/* ---- domain-decomposed multi-GPU stepping (the reference is single-GPU) ----
+ * One context per rank, each owning the bodies of one contiguous Morton-key range.  Per step
+ * the host side (nbody-barnes-hut-cuda_amd/dist.py: DomainStepper) alternates these calls with
+ * four all-gathers of plain device buffers; the library never communicates itself:
+ *
+ *   bh_dd_cube_pack      -> all-gather X1 -> bh_dd_cube_apply      global cube (exact) + splitters
+ *   bh_dd_migrate_pack   -> all-gather X2 -> bh_dd_migrate_apply   bodies that left the key range
+ *   bh_dd_tree           -> all-gather X3                          local octree; piece descriptors
+ *   bh_dd_let_pack       -> all-gather X4 (into the record pool)   locally-essential records
+ *   bh_dd_top, bh_dd_force, bh_dd_let_check, bh_integrate
+ *
+ * The local octree of a rank is the canonical octree of the global cube restricted to its bodies;
+ * every cell that does not touch either end of the rank's body range is a complete global cell.
+ * The children of the end-touching ("spine") cells are the rank's PIECES; the canonical tree above
+ * the pieces of all ranks (the top tree) is rebuilt identically on every rank from the gathered
+ * piece descriptors, so the stitched tree is the same octree a single GPU builds and forces agree
+ * with the 1-rank run up to summation order (cell sums: fp64, differently associated).
+ * A LET segment holds the child blocks of every local cell that some body of another rank could
+ * open (conservative box test against the remote pieces).  Requires key_bits 63 and leaf_cap 1. */
+#define BH_DD_PIECE_CAP 512          /* pieces per rank: <= 2 spines x 21 levels x 7 = 294      */
+#define BH_FLAG_DD_BODIES 16         /* local body count exceeded the context's capacity         */
+#define BH_FLAG_DD_PIECES 32         /* more than BH_DD_PIECE_CAP pieces                          */
+#define BH_FLAG_DD_LET 64            /* LET segment did not fit the stride (bh_dd_let_check)     */
+
+typedef struct bh_dd_sizes {
+  int64_t x1_bytes;     /* per-rank payload of exchange X1                                       */
+  int64_t x2_bytes;     /* per-rank payload of exchange X2 (header + mig_cap bodies of 32 B)     */
+  int64_t x3_bytes;     /* per-rank payload of exchange X3 (header + BH_DD_PIECE_CAP descriptors) */
+  int64_t pool_records; /* 32-byte records the caller's pool must hold                           */
+  int64_t seg_base;     /* pool index of LET segment 0: X4 gathers world x stride records here   */
+  int64_t let_min;      /* smallest legal stride (header + piece slots)                          */
+  int64_t let_cap;      /* largest legal stride                                                  */
+  int64_t top_base;     /* pool index of the top-tree root                                       */
+} bh_dd_sizes;
+
+/* sizes for a context created with capacity n_cap bodies */
+int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* out);
+/* switch a context (created with n = body capacity) to domain-decomposed stepping; `pool` is a
+   caller-owned device buffer of pool_records x 32 B that becomes the context's record pool */
+int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int let_cap,
+               void* pool, int64_t pool_records);
+/* the bodies this rank starts with (any subset; a Morton slab of the global order avoids a large
+   first migration) and their global ids, host pointers */
+int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const float* z,
+                 const float* vx, const float* vy, const float* vz, const float* m,
+                 const int32_t* ids);
+int bh_dd_cube_pack(bh_ctx* c, void* send_x1);
+int bh_dd_cube_apply(bh_ctx* c, const void* gathered_x1);
+/* limit = emigrant slots per rank in this round's X2 (header 32 B + limit x 32 B per rank,
+   1 <= limit <= mig_cap); emigrants beyond it wait for another round of the same step */
+int bh_dd_migrate_pack(bh_ctx* c, void* send_x2, int limit);
+/* synchronises; *n_loc = bodies this rank now holds, *more = 1 when some rank still holds
+   emigrants (run another pack/gather/apply round), *most = most emigrants found on any rank */
+int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_loc, int* more,
+                        int* most);
+int bh_dd_tree(bh_ctx* c, void* send_x3);
+/* stride = records per LET segment in this step's X4 (let_min <= stride <= let_cap) */
+int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride);
+int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride);
+int bh_dd_force(bh_ctx* c);
+/* synchronises up to the end of X4 only; counts[world] = records each rank needed.  Returns
+   BH_OK, or BH_ERR_SMALL_BUFFER when some count exceeds stride (repeat let_pack..force larger) */
+int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts);
+/* local bodies in local Morton order: posm[4 n_loc] = x,y,z,m; velid[4 n_loc] = vx,vy,vz,bits(id) */
+int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc);
 
 /* per-step device times (hipEvent pairs recorded on the context's stream while
    bh_set_timing is on) of the most recent steps, oldest first: ms_force[i], ms_step[i].

@@ -43,6 +43,14 @@ class BhStats(C.Structure):
     ]
 
 
+class BhDdSizes(C.Structure):
+    """struct bh_dd_sizes: buffer sizes of the domain-decomposed stepping."""
+    _fields_ = [(k, C.c_int64) for k in
+                ("x1_bytes", "x2_bytes", "x3_bytes", "pool_records", "seg_base", "let_min", "let_cap", "top_base")]
+
+
+BH_DD_PIECE_CAP = 512
+
 # every symbol include/bh.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
@@ -87,6 +95,19 @@ SYMBOLS = [
     ("bh_bind_acc", C.c_int, [_P, _P]),
     ("bh_timing_history", C.c_int, [_P, _F, _F, C.c_int, C.POINTER(C.c_int)]),
     ("bh_n", C.c_int, [_P]),
+    ("bh_dd_query", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BhDdSizes)]),
+    ("bh_dd_init", C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P, C.c_int64]),
+    ("bh_dd_upload", C.c_int, [_P, C.c_int] + [_F] * 7 + [C.POINTER(C.c_int32)]),
+    ("bh_dd_cube_pack", C.c_int, [_P, _P]),
+    ("bh_dd_cube_apply", C.c_int, [_P, _P]),
+    ("bh_dd_migrate_pack", C.c_int, [_P, _P, C.c_int]),
+    ("bh_dd_migrate_apply", C.c_int, [_P, _P, C.c_int] + [C.POINTER(C.c_int)] * 3),
+    ("bh_dd_tree", C.c_int, [_P, _P]),
+    ("bh_dd_let_pack", C.c_int, [_P, _P, _P, C.c_int]),
+    ("bh_dd_top", C.c_int, [_P, _P, C.c_int]),
+    ("bh_dd_force", C.c_int, [_P]),
+    ("bh_dd_let_check", C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),
+    ("bh_dd_download", C.c_int, [_P, _F, _F, _F]),
     ("bh_ic_plummer", C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_float] + [_F] * 7),
     ("bh_ic_disc", C.c_int, [C.c_int, C.c_uint64, C.c_float] + [_F] * 7),
 ]

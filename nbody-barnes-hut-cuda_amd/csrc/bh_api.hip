@@ -70,6 +70,10 @@ int bh_n(const bh_ctx* c) { return c ? c->n : 0; }
 static void free_all(bh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->dd) {  // the bound record pool is caller-owned
+    c->frec = c->frec_own;
+    bh_dd_free(c);
+  }
   void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sw_hist, c->sw_status,
                   c->sw_ticket, c->bbox_partial,

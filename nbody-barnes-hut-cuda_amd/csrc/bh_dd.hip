@@ -1,0 +1,1002 @@
+// bh_dd.hip — domain-decomposed multi-GPU stepping (include/bh.h "bh_dd_*").
+//
+// The reference is single-GPU; nothing here has a reference counterpart.  One context per rank owns
+// the bodies of one contiguous Morton-key range.  The library never communicates: each entry point
+// packs or consumes a plain device buffer and the host side (dist.py) moves the buffers with four
+// all-gathers per step (RCCL over xGMI).
+//
+//  X1 cube + splitters  each rank's min/max (6 floats) and a regular sample of its body positions
+//                       (one body in every n_total / 4096).  min/max are exact, so the global cube —
+//                       hence every Morton key — is bit-identical to the single-GPU run.  Every rank
+//                       keys all samples under the NEW cube, sorts them and takes the world-1
+//                       equal-count quantiles as this step's splitter keys.  (Splitters carried over
+//                       from the previous step do not survive a moving cube: a boundary body that
+//                       crosses a top-level cell plane changes its key by whole octants.)
+//  X2 migration         owner(key) = #{splitter keys <= key}.  Bodies whose owner changed are
+//                       compacted into a fixed-capacity buffer; every rank picks its immigrants out
+//                       of the gathered buffers.  Scan-based, so arrival order is deterministic.
+//  X3 piece descriptors after the local sort/build/COM.  A local cell that does not touch either end
+//                       of the local body range is a complete global cell (its key prefix is bounded
+//                       by local bodies on both sides).  The end-touching cells form two root-to-leaf
+//                       "spines"; their other children are the rank's PIECES (<= 2 x 21 x 7).  The
+//                       canonical octree above all pieces (top tree) is a pure function of the piece
+//                       keys, so every rank rebuilds it identically (dd_top_kernel).
+//  X4 LET segments      child blocks of every local cell some body of another rank could open:
+//                       conservative test of the cell's MAC radius against the boxes of the remote
+//                       pieces.  Records are written with pool-relative child indices, so the gathered
+//                       segments are traversable in place.
+//
+// The stitched pool [local tree | top tree | world x LET segment] is the same canonical octree a
+// single GPU builds; the unchanged force kernel traverses it from the top-tree root.
+#include <stdlib.h>
+#include <string.h>
+
+#include "bh_internal.h"
+#include "bh_keys.h"
+
+struct bh_dd_piece {  // X3 descriptor, 80 B
+  u64 key;                // key of the piece's first body
+  float bx, by, bz, bs;   // box: min corner and edge (0 for a single body)
+  double sm, sx, sy, sz;  // fp64 sums (m, m x, m y, m z) of its bodies
+  int rec_idx;            // local record index on the owner
+  int owner;
+  int count;              // bodies
+  int kind;
+  int pad[2];
+};
+static_assert(sizeof(bh_dd_piece) == 80, "descriptor layout");
+
+struct bh_dd_state {
+  int world, rank;
+  long long n_total;
+  int mig_cap, let_cap;
+  bh_frec* pool;
+  long long pool_records;
+  int top_base, seg_base;
+  int* w;          // [rec_cap + 1] records a cell exports (0: not needed by any other rank)
+  int* dst;        // [rec_cap + 1] exclusive scan of w
+  int* flag;       // [max(n_cap, world*mig_cap) + 1]
+  int* fpos;       // same, exclusive scan of flag
+  int* nloc;       // [world] body count of every rank after this step's migration
+  int samp_cap;    // sample slots per rank in X1 (kSampTotal / world)
+  u64* skeys;      // [world-1] splitter keys under the current cube, ascending
+  int* piece_tmp;  // [BH_DD_PIECE_CAP] unsorted piece records
+  int* piece_idx;  // [BH_DD_PIECE_CAP] pieces in body order
+  int* ddi;        // [8] device scalars: 0 pieces found, 1 remote boxes, 4..6 migration results
+  float4* boxes;   // [world * BH_DD_PIECE_CAP] remote piece boxes (corner, edge), margin applied
+  bh_d4* top_ps;   // [kTopMax + 1] fp64 prefix of the piece sums
+  int* top_a;      // [kTopMax]
+  int* top_b;      // [kTopMax]
+  int* host;       // pinned: [world] LET counts, [world .. world+3] migration results
+  hipEvent_t ev_let;
+  bool let_copy_pending;
+};
+
+namespace {
+
+constexpr int kB = 21;
+constexpr int kTopMax = 4096;  // pieces in the whole system
+constexpr int kDescPerRank = 1 + BH_DD_PIECE_CAP;
+
+constexpr int kSampTotal = 4096;  // position samples in the whole system (sorted in LDS: 32 KiB)
+__host__ __device__ inline int samp_cap_of(int world) { return kSampTotal / world; }
+__host__ __device__ inline int x1_floats(int world) { return 8 + 4 * samp_cap_of(world); }
+
+__device__ __forceinline__ int owner_of(u64 key, const u64* sk, int nsplit) {
+  int o = 0;
+  for (int q = 0; q < nsplit; q++) o += (sk[q] <= key) ? 1 : 0;
+  return o;
+}
+
+// ------------------------------------------------------------------ X1
+// samples k = 0 .. : the body at local index (k + 1/2) * g, g = n_total / kSampTotal — the same
+// stride on every rank, so the merged samples weight every body equally
+__global__ __launch_bounds__(256) void dd_x1_tail_kernel(float* __restrict__ send, int n_loc,
+                                                         const float4* __restrict__ posm, double g,
+                                                         int samp_cap) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    send[6] = __int_as_float(n_loc);
+    send[7] = 0.0f;
+  }
+  if (t >= samp_cap) return;
+  const long long idx = (long long)(((double)t + 0.5) * g);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < n_loc) {
+    o = posm[idx];
+    o.w = 1.0f;
+  }
+  reinterpret_cast<float4*>(send + 8)[t] = o;
+}
+
+// keys of all samples under the new cube, bitonic sort, equal-count quantiles -> splitter keys
+__global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict__ g, int world, int xf,
+                                                        int samp_cap, const float* __restrict__ bounds,
+                                                        u64* __restrict__ skeys) {
+  __shared__ u64 k[kSampTotal];
+  __shared__ int nvalid;
+  const int tid = threadIdx.x;
+  if (tid == 0) nvalid = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < kSampTotal; i += 1024) {
+    u64 key = ~0ull;
+    const int r = i / samp_cap, t = i - r * samp_cap;
+    if (r < world) {
+      const float4 p = reinterpret_cast<const float4*>(g + (size_t)r * xf + 8)[t];
+      if (p.w > 0.5f) {
+        key = morton_key<kB>(p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
+        mine++;
+      }
+    }
+    k[i] = key;
+  }
+  if (mine) atomicAdd(&nvalid, mine);
+  __syncthreads();
+  for (int size = 2; size <= kSampTotal; size <<= 1) {
+    for (int j = size >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < kSampTotal; i += 1024) {
+        const int partner = i ^ j;
+        if (partner > i) {
+          const u64 a = k[i], b = k[partner];
+          const bool up = (i & size) == 0;
+          if ((a > b) == up) {
+            k[i] = b;
+            k[partner] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int M = nvalid;  // valid samples sort first (invalid = all ones)
+  if (tid < world - 1) skeys[tid] = M > 0 ? k[(int)(((long long)(tid + 1) * M) / world)] : ~0ull;
+}
+
+// ------------------------------------------------------------------ X2
+__global__ __launch_bounds__(256) void dd_classify_kernel(const u64* __restrict__ keys, int n,
+                                                          const u64* __restrict__ skeys, int nsplit, int me,
+                                                          int* __restrict__ flag) {
+  __shared__ u64 sk[64];
+  if ((int)threadIdx.x < nsplit) sk[threadIdx.x] = skeys[threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = owner_of(keys[i], sk, nsplit) == me ? 1 : 0;
+}
+
+// kept bodies -> the other ping-pong buffer (stable); the first `limit` emigrants -> X2 payload
+// (header 2 x float4); emigrants beyond the limit stay behind the kept bodies and leave in a later
+// round of the same step.  Header: [0] emigrants found, [1] kept, [2] sent, [3] bodies still held.
+__global__ __launch_bounds__(256) void dd_compact_kernel(const float4* __restrict__ posm,
+                                                         const float4* __restrict__ velid, int n,
+                                                         const int* __restrict__ flag,
+                                                         const int* __restrict__ fpos,
+                                                         float4* __restrict__ posm2,
+                                                         float4* __restrict__ velid2, float4* __restrict__ send,
+                                                         int limit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kept = fpos[n];
+  if (i == 0) {
+    int* h = reinterpret_cast<int*>(send);
+    const int sent = min(n - kept, limit);
+    h[0] = n - kept;
+    h[1] = kept;
+    h[2] = sent;
+    h[3] = n - sent;
+    h[4] = h[5] = h[6] = h[7] = 0;
+  }
+  if (i >= n) return;
+  const float4 p = posm[i], v = velid[i];
+  const int k = fpos[i];
+  if (flag[i]) {
+    posm2[k] = p;
+    velid2[k] = v;
+  } else {
+    const int slot = i - k;
+    if (slot < limit) {
+      send[2 + 2 * (size_t)slot] = p;
+      send[3 + 2 * (size_t)slot] = v;
+    } else {
+      posm2[kept + slot - limit] = p;
+      velid2[kept + slot - limit] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void dd_nloc_init_kernel(const float4* __restrict__ g, int world, size_t f4,
+                                                          int* __restrict__ nloc) {
+  const int q = threadIdx.x;
+  if (q < world) nloc[q] = reinterpret_cast<const int*>(g + (size_t)q * f4)[3];
+}
+
+// one thread per gathered emigrant slot: owner under the current cube; mine -> flag; every rank's
+// body count after this round (block-reduced: a global atomic per thread serialises)
+__global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __restrict__ g, int world,
+                                                             int limit, size_t f4,
+                                                             const float* __restrict__ bounds,
+                                                             const u64* __restrict__ skeys, int me,
+                                                             int* __restrict__ flag2, int* __restrict__ nloc) {
+  __shared__ u64 sk[64];
+  __shared__ int cnt[64];
+  const int nsplit = world - 1;
+  if ((int)threadIdx.x < nsplit) sk[threadIdx.x] = skeys[threadIdx.x];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < world * limit) {
+    const int q = slot / limit, k = slot - q * limit;
+    const int* h = reinterpret_cast<const int*>(g + (size_t)q * f4);
+    const int ne = min(h[2], limit);
+    int f = 0;
+    if (k < ne) {
+      const float4 p = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
+      const u64 key = morton_key<kB>(p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
+      const int o = owner_of(key, sk, nsplit);
+      atomicAdd(&cnt[o], 1);
+      f = (o == me && q != me) ? 1 : 0;
+    }
+    flag2[slot] = f;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < world && cnt[threadIdx.x]) atomicAdd(&nloc[threadIdx.x], cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void dd_absorb_copy_kernel(const float4* __restrict__ g, int world,
+                                                             int limit, size_t f4, int me,
+                                                             const int* __restrict__ flag2,
+                                                             const int* __restrict__ fpos2, int n_cap,
+                                                             float4* __restrict__ posm2,
+                                                             float4* __restrict__ velid2,
+                                                             bh_devinfo* __restrict__ info) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= world * limit || !flag2[slot]) return;
+  const int q = slot / limit, k = slot - q * limit;
+  const int held = reinterpret_cast<const int*>(g + (size_t)me * f4)[3];
+  const int d = held + fpos2[slot];
+  if (d >= n_cap) {
+    atomicOr(&info->flags, BH_FLAG_DD_BODIES);
+    return;
+  }
+  posm2[d] = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
+  velid2[d] = g[(size_t)q * f4 + 3 + 2 * (size_t)k];
+}
+
+// out: [0] bodies this rank now holds, [1] flags, [2] most emigrants still waiting on any rank,
+// [3] most emigrants found on any rank (sizes the next exchange)
+__global__ void dd_migrate_result_kernel(const float4* __restrict__ g, int world, size_t f4,
+                                         const int* __restrict__ nloc, int me,
+                                         const bh_devinfo* __restrict__ info, int* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    int left = 0, most = 0;
+    for (int q = 0; q < world; q++) {
+      const int* h = reinterpret_cast<const int*>(g + (size_t)q * f4);
+      left = max(left, h[0] - h[2]);
+      most = max(most, h[0]);
+    }
+    out[0] = nloc[me];
+    out[1] = info->flags;
+    out[2] = left;
+    out[3] = most;
+  }
+}
+
+// ------------------------------------------------------------------ X3: pieces
+__device__ __forceinline__ bool is_spine(const bh_node* __restrict__ rec, const int* __restrict__ er_lo,
+                                         const int* __restrict__ er_hi, int e, int n) {
+  return rec[e].kind == BH_KIND_INTERNAL && (er_lo[e] == 0 || er_hi[e] == n);
+}
+
+__global__ __launch_bounds__(256) void dd_spine_kernel(const bh_node* __restrict__ rec,
+                                                       const int* __restrict__ er_lo,
+                                                       const int* __restrict__ er_hi,
+                                                       const bh_devinfo* __restrict__ info, int rec_cap, int n,
+                                                       int* __restrict__ piece_tmp, int* __restrict__ ddi) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int E = min(info->n_entries, rec_cap);
+  if (e >= E) return;
+  if (e == 0 && rec[0].kind != BH_KIND_INTERNAL) {  // the whole rank is one body / one unsplit cell
+    piece_tmp[atomicAdd(&ddi[0], 1)] = 0;
+    return;
+  }
+  if (!is_spine(rec, er_lo, er_hi, e, n)) return;
+  const bh_node r = rec[e];
+  for (int k = 0; k < r.count; k++) {
+    const int c = r.first + k;
+    if (!is_spine(rec, er_lo, er_hi, c, n)) {
+      const int idx = atomicAdd(&ddi[0], 1);  // order fixed below by the body range
+      if (idx < BH_DD_PIECE_CAP) piece_tmp[idx] = c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
+    const int* __restrict__ piece_tmp, const int* __restrict__ ddi, const bh_node* __restrict__ rec,
+    const int* __restrict__ er_lo, const int* __restrict__ er_hi, const u64* __restrict__ keys,
+    const bh_d4* __restrict__ P, const float4* __restrict__ posm, const float* __restrict__ bounds, int me,
+    int n_loc, bh_dd_piece* __restrict__ out, int* __restrict__ piece_idx, bh_devinfo* __restrict__ info) {
+  __shared__ int lo[BH_DD_PIECE_CAP], idx[BH_DD_PIECE_CAP];
+  const int found = ddi[0];
+  const int np = min(found, BH_DD_PIECE_CAP);
+  const int t = threadIdx.x;
+  if (t == 0) {
+    if (found > BH_DD_PIECE_CAP) atomicOr(&info->flags, BH_FLAG_DD_PIECES);
+    int* h = reinterpret_cast<int*>(out);
+    for (int i = 0; i < 20; i++) h[i] = 0;
+    h[0] = np;
+    h[1] = n_loc;
+  }
+  if (t < np) {
+    idx[t] = piece_tmp[t];
+    lo[t] = er_lo[idx[t]];
+  }
+  __syncthreads();
+  if (t >= np) return;
+  int rank = 0;
+  for (int u = 0; u < np; u++) rank += (lo[u] < lo[t]) ? 1 : 0;  // pieces are disjoint: distinct starts
+  const int e = idx[t];
+  piece_idx[rank] = e;
+  const int a = lo[t], b = er_hi[e];
+  bh_dd_piece d;
+  d.key = keys[a];
+  d.rec_idx = e;
+  d.owner = me;
+  d.count = b - a;
+  d.kind = rec[e].kind;
+  d.pad[0] = d.pad[1] = 0;
+  const float size = bounds[6];
+  if (b - a == 1) {
+    const float4 q = posm[a];
+    const double m = (double)q.w;
+    d.sm = m; d.sx = m * (double)q.x; d.sy = m * (double)q.y; d.sz = m * (double)q.z;
+    d.bx = q.x; d.by = q.y; d.bz = q.z; d.bs = 0.0f;
+  } else {
+    const bh_d4 p1 = P[b], p0 = P[a];
+    d.sm = p1.m - p0.m; d.sx = p1.x - p0.x; d.sy = p1.y - p0.y; d.sz = p1.z - p0.z;
+    // box of the compressed cell: the Lb leading digits its bodies share
+    const int Lb = common_digits(keys[a], keys[b - 1], kB);
+    const int sh = 3 * (kB - Lb);
+    const u64 kp = (sh >= 63) ? 0ull : ((keys[a] >> sh) << sh);
+    const u32 ix = compact_bits21(kp >> 2), iy = compact_bits21(kp >> 1), iz = compact_bits21(kp);
+    d.bx = bounds[0] + (float)ix / 2097152.0f * size;
+    d.by = bounds[1] + (float)iy / 2097152.0f * size;
+    d.bz = bounds[2] + (float)iz / 2097152.0f * size;
+    d.bs = ldexpf(size, -Lb);
+  }
+  out[1 + rank] = d;
+}
+
+// ------------------------------------------------------------------ X4: LET
+// dense list of the other ranks' piece boxes, grown by a margin that covers the fp32 fuzz of the
+// key quantisation (<= 0.25 key units) and of the box arithmetic
+__global__ __launch_bounds__(256) void dd_boxes_kernel(const bh_dd_piece* __restrict__ g, int world, int me,
+                                                       const float* __restrict__ bounds,
+                                                       float4* __restrict__ boxes, int* __restrict__ ddi) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= world * BH_DD_PIECE_CAP) return;
+  const int q = t / BH_DD_PIECE_CAP, k = t - q * BH_DD_PIECE_CAP;
+  if (q == me) return;
+  const int np = min(reinterpret_cast<const int*>(g + (size_t)q * kDescPerRank)[0], BH_DD_PIECE_CAP);
+  if (k >= np) return;
+  const bh_dd_piece d = g[(size_t)q * kDescPerRank + 1 + k];
+  const float mg = 1e-5f * bounds[6];
+  boxes[atomicAdd(&ddi[1], 1)] = make_float4(d.bx - mg, d.by - mg, d.bz - mg, d.bs + 2.0f * mg);
+}
+
+// w[e] = records cell e must export = its child count when some remote body could open it:
+// min over the remote boxes of |com - box|^2 + eps2 <= (s/theta)^2, with slack on both sides
+__global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict__ frec,
+                                                      const bh_devinfo* __restrict__ info, int rec_cap,
+                                                      const float4* __restrict__ boxes,
+                                                      const int* __restrict__ ddi, float eps2,
+                                                      int* __restrict__ w) {
+  __shared__ float4 sb[1024];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int E = min(info->n_entries, rec_cap);
+  const int NB = ddi[1];
+  bool cand = false;
+  float x = 0.f, y = 0.f, z = 0.f, thr = 0.f;
+  int cnt = 0;
+  if (e < E) {
+    const bh_frec r = frec[e];
+    cand = r.thr2 >= 0.0f;
+    x = r.x; y = r.y; z = r.z;
+    thr = r.thr2 * 1.0001f;
+    cnt = r.meta & 0x7fffffff;
+  }
+  bool open = false;
+  for (int base = 0; base < NB; base += 1024) {
+    const int m = min(1024, NB - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 256) sb[i] = boxes[base + i];
+    __syncthreads();
+    if (cand && !open) {
+      for (int i = 0; i < m; i++) {
+        const float4 b = sb[i];
+        const float dx = fmaxf(fmaxf(b.x - x, x - (b.x + b.w)), 0.0f);
+        const float dy = fmaxf(fmaxf(b.y - y, y - (b.y + b.w)), 0.0f);
+        const float dz = fmaxf(fmaxf(b.z - z, z - (b.z + b.w)), 0.0f);
+        const float d2 = (dx * dx + dy * dy + dz * dz) * 0.9999f + eps2;
+        if (d2 <= thr) {
+          open = true;
+          break;
+        }
+      }
+    }
+  }
+  if (e <= rec_cap) w[e] = (cand && open) ? cnt : 0;
+}
+
+__device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restrict__ w,
+                                         const int* __restrict__ dst, int blocks0) {
+  const int wc = w[c];
+  if (wc > 0) {
+    fr.first = blocks0 + dst[c];
+    fr.meta = wc;  // an exported unsplit cell becomes a block of body records
+  } else if (fr.thr2 >= 0.0f) {
+    fr.first = 0;  // never opened by a remote body (conservative test): index unused
+  }
+  return fr;
+}
+
+// send[0] header, send[1 .. PIECE_CAP] the pieces' own records, then the child blocks in scan order.
+// Child indices are pool indices of the receiving side: seg0 = pool index of this rank's segment.
+__global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restrict__ frec,
+                                                        const float4* __restrict__ posm, int rec_cap,
+                                                        const int* __restrict__ w, const int* __restrict__ dst,
+                                                        const int* __restrict__ piece_idx,
+                                                        const int* __restrict__ ddi, int seg0, int stride,
+                                                        float G, bh_frec* __restrict__ send) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int blocks0 = seg0 + 1 + BH_DD_PIECE_CAP;
+  const int np = min(ddi[0], BH_DD_PIECE_CAP);
+  if (e == 0) {
+    bh_frec h;
+    memset(&h, 0, sizeof(h));
+    h.first = 1 + BH_DD_PIECE_CAP + dst[rec_cap];  // records this rank needs (may exceed stride)
+    h.meta = np;
+    send[0] = h;
+  }
+  // a segment that does not fit is sent closed: its pieces are made unopenable, so the (discarded)
+  // force pass that runs before the host sees the header never walks unwritten records
+  const bool fits = 1 + BH_DD_PIECE_CAP + dst[rec_cap] <= stride;
+  if (e < BH_DD_PIECE_CAP) {
+    bh_frec fr;
+    memset(&fr, 0, sizeof(fr));
+    if (e < np) fr = reloc(frec[piece_idx[e]], piece_idx[e], w, dst, blocks0);
+    if (!fits) fr.thr2 = -1.0f;
+    send[1 + e] = fr;
+  }
+  if (e >= rec_cap || !fits) return;
+  const int wv = w[e];
+  if (wv == 0) return;
+  const int off = 1 + BH_DD_PIECE_CAP + dst[e];
+  if (off + wv > stride) return;  // does not fit: the header tells the host to repeat with more room
+  const bh_frec fr = frec[e];
+  if (fr.meta < 0) {  // unsplit multi-body cell: its bodies travel as body records
+    for (int k = 0; k < wv; k++) {
+      const float4 q = posm[fr.first + k];
+      bh_frec o;
+      o.x = q.x; o.y = q.y; o.z = q.z;
+      o.gm = q.w > 0.0f ? G * q.w : 0.0f;
+      o.thr2 = -1.0f;
+      o.first = 0;
+      o.meta = 1;
+      o.pad = 0;
+      send[off + k] = o;
+    }
+  } else {
+    for (int k = 0; k < wv; k++) send[off + k] = reloc(frec[fr.first + k], fr.first + k, w, dst, blocks0);
+  }
+}
+
+// ------------------------------------------------------------------ top tree
+// block-wide exclusive scans over up to kTopMax items, 4 consecutive items per thread
+__device__ __forceinline__ int top_scan_i32(int* v /* LDS [kTopMax+1] */, int T, int* wsum /* [16] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int x[4], s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int t = 4 * tid + i;
+    x[i] = t < T ? v[t] : 0;
+    s += x[i];
+  }
+  int inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += u;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int pre = 0, tot = 0;
+  for (int i = 0; i < 16; i++) {
+    if (i < wv) pre += wsum[i];
+    tot += wsum[i];
+  }
+  int run = pre + inc - s;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int t = 4 * tid + i;
+    if (t < T) v[t] = run;
+    run += x[i];
+  }
+  if (tid == 0) v[T] = tot;
+  __syncthreads();
+  return tot;
+}
+
+__device__ __forceinline__ bh_d4 d4_add(bh_d4 a, bh_d4 b) { return bh_d4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ bh_d4 d4_shfl_up(bh_d4 v, int d) {
+  return bh_d4{__shfl_up(v.m, d, 64), __shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64)};
+}
+
+__device__ __forceinline__ bh_frec top_piece_record(const bh_dd_piece* __restrict__ g, int slot, int me,
+                                                    const bh_frec* __restrict__ pool, int seg_base, int stride) {
+  const bh_dd_piece d = g[slot];
+  if (d.owner == me) return pool[d.rec_idx];
+  const int k = slot - d.owner * kDescPerRank - 1;
+  return pool[(size_t)seg_base + (size_t)d.owner * stride + 1 + k];
+}
+
+// record of the top-tree child [c0, c1) (piece positions): a piece, or the cell branching at the
+// first lowest boundary strictly inside the range
+__device__ __forceinline__ bh_frec top_child(const bh_dd_piece* __restrict__ g, const int* tslot,
+                                             const signed char* d, const int* pn, const int* cb,
+                                             const bh_d4* __restrict__ ps, int c0, int c1, int me,
+                                             const bh_frec* __restrict__ pool, int top_base, int seg_base,
+                                             int stride, float s0, float G, float theta) {
+  if (c1 - c0 == 1) return top_piece_record(g, tslot[c0], me, pool, seg_base, stride);
+  int l = c0 + 1, Lb = d[c0 + 1];
+  for (int i = c0 + 2; i < c1; i++)
+    if (d[i] < Lb) {
+      Lb = d[i];
+      l = i;
+    }
+  const bh_d4 p1 = ps[c1], p0 = ps[c0];
+  const double M = p1.m - p0.m;
+  const double sx = p1.x - p0.x, sy = p1.y - p0.y, sz = p1.z - p0.z;
+  bh_frec fr;
+  const float mass = (float)M;
+  if (mass > 1e-6f) {  // ref:180, as com_kernel
+    fr.x = (float)(sx / M); fr.y = (float)(sy / M); fr.z = (float)(sz / M);
+  } else {
+    fr.x = (float)sx; fr.y = (float)sy; fr.z = (float)sz;
+  }
+  const bool massive = mass > 0.0f;
+  fr.gm = massive ? G * mass : 0.0f;
+  if (massive) {
+    const float t = ldexpf(s0, -Lb) / theta;
+    fr.thr2 = t * t;
+  } else {
+    fr.thr2 = -1.0f;
+  }
+  fr.first = top_base + 1 + cb[l];
+  fr.meta = pn[l];
+  fr.pad = 0;
+  return fr;
+}
+
+__global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restrict__ g, int world, int me,
+                                                      bh_frec* __restrict__ pool, int top_base, int seg_base,
+                                                      int stride, const float* __restrict__ bounds, float G,
+                                                      float theta, bh_d4* __restrict__ ps, int* __restrict__ ta,
+                                                      int* __restrict__ tb, bh_devinfo* __restrict__ info) {
+  __shared__ int offs[65];
+  __shared__ int tslot[kTopMax];
+  __shared__ signed char d[kTopMax + 1];
+  __shared__ int pn[kTopMax + 1];
+  __shared__ int cb[kTopMax + 1];
+  __shared__ int wsum[16];
+  __shared__ bh_d4 wsum4[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    int o = 0;
+    offs[0] = 0;
+    for (int q = 0; q < world; q++) {
+      o += min(reinterpret_cast<const int*>(g + (size_t)q * kDescPerRank)[0], BH_DD_PIECE_CAP);
+      offs[q + 1] = o;
+    }
+    if (o > kTopMax) atomicOr(&info->flags, BH_FLAG_DD_PIECES);
+  }
+  __syncthreads();
+  const int T = min(offs[world], kTopMax);
+  if (T < 1) return;
+  for (int t = tid; t < T; t += 1024) {
+    int q = 0;
+    while (offs[q + 1] <= t) q++;
+    tslot[t] = q * kDescPerRank + 1 + (t - offs[q]);
+  }
+  __syncthreads();
+  for (int t = tid; t <= T; t += 1024)
+    d[t] = (t == 0 || t == T) ? (signed char)-1
+                              : (signed char)common_digits(g[tslot[t - 1]].key, g[tslot[t]].key, kB);
+  // fp64 exclusive prefix of the piece sums (fixed association: identical on every rank)
+  {
+    bh_d4 x[4], s = bh_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int t = 4 * tid + i;
+      if (t < T) {
+        const bh_dd_piece p = g[tslot[t]];
+        x[i] = bh_d4{p.sm, p.sx, p.sy, p.sz};
+      } else {
+        x[i] = bh_d4{0.0, 0.0, 0.0, 0.0};
+      }
+      s = d4_add(s, x[i]);
+    }
+    bh_d4 inc = s;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const bh_d4 u = d4_shfl_up(inc, dd);
+      if (lane >= dd) inc = d4_add(u, inc);
+    }
+    if (lane == 63) wsum4[wv] = inc;
+    __syncthreads();
+    bh_d4 pre = bh_d4{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < wv; i++) pre = d4_add(pre, wsum4[i]);
+    bh_d4 excl = d4_shfl_up(inc, 1);
+    if (lane == 0) excl = bh_d4{0.0, 0.0, 0.0, 0.0};
+    bh_d4 run = d4_add(pre, excl);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int t = 4 * tid + i;
+      if (t < T) ps[t] = run;
+      run = d4_add(run, x[i]);
+      if (t == T - 1) ps[T] = run;
+    }
+  }
+  __syncthreads();
+  // cells: pair j at level L = d[j] names the cell [a, b); representative = its first boundary
+  for (int j = tid; j < T; j += 1024) {
+    int nc = 0;
+    if (j >= 1) {
+      const int L = d[j];
+      int i = j - 1;
+      while (d[i] > L) i--;
+      if (d[i] < L) {  // no earlier boundary of the same level inside the cell
+        const int a = i;
+        nc = 2;
+        i = j + 1;
+        while (d[i] >= L) {
+          if (d[i] == L) nc++;
+          i++;
+        }
+        ta[j] = a;
+        tb[j] = i;
+      }
+    }
+    pn[j] = nc;
+  }
+  __syncthreads();
+  for (int j = tid; j < T; j += 1024) cb[j] = pn[j];
+  __syncthreads();
+  (void)top_scan_i32(cb, T, wsum);
+  const float s0 = bounds[6];
+  if (tid == 0)
+    pool[top_base] = top_child(g, tslot, d, pn, cb, ps, 0, T, me, pool, top_base, seg_base, stride, s0, G, theta);
+  for (int j = tid; j < T; j += 1024) {
+    if (pn[j] == 0) continue;
+    const int L = d[j], b = tb[j];
+    int e = top_base + 1 + cb[j];
+    int c0 = ta[j], c1 = j;
+    for (;;) {
+      pool[e++] = top_child(g, tslot, d, pn, cb, ps, c0, c1, me, pool, top_base, seg_base, stride, s0, G, theta);
+      if (c1 >= b) break;
+      c0 = c1;
+      c1 = c0 + 1;
+      while (c1 < b && d[c1] != L) c1++;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dd_pack_ids_kernel(const float* __restrict__ s, const int* __restrict__ ids,
+                                                          int n, float4* __restrict__ posm,
+                                                          float4* __restrict__ velid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t N = (size_t)n;
+  posm[i] = make_float4(s[i], s[N + i], s[2 * N + i], s[6 * N + i]);
+  velid[i] = make_float4(s[3 * N + i], s[4 * N + i], s[5 * N + i], __int_as_float(ids[i]));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+#define BH_HIP(c, call)                       \
+  do {                                        \
+    hipError_t _e = (call);                   \
+    if (_e != hipSuccess) {                   \
+      (c)->last_hip = (int)_e;                \
+      return BH_ERR_HIP;                      \
+    }                                         \
+  } while (0)
+
+static void dd_set_n(bh_ctx* c, int n) {
+  c->n = n;
+  c->sort_tiles = (n + BH_SORT_TILE - 1) / BH_SORT_TILE;
+  if (c->sort_tiles < 1) c->sort_tiles = 1;
+}
+
+void bh_dd_free(bh_ctx* c) {
+  bh_dd_state* d = c->dd;
+  if (!d) return;
+  void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
+                  d->piece_idx, d->ddi, d->boxes, d->top_ps, d->top_a, d->top_b};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (d->host) (void)hipHostFree(d->host);
+  if (d->ev_let) (void)hipEventDestroy(d->ev_let);
+  free(d);
+  c->dd = nullptr;
+}
+
+extern "C" {
+
+int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) {
+  if (!o || n_cap < 1 || world < 1 || world > 64 || mig_cap < 1) return BH_ERR_BAD_ARG;
+  const long long let_min = 1 + BH_DD_PIECE_CAP;
+  if (let_cap < let_min) return BH_ERR_BAD_ARG;
+  const long long rec_cap = 2LL * n_cap + 8;
+  const long long top_cap = 2LL * kTopMax + 8;
+  o->x1_bytes = (int64_t)x1_floats(world) * 4;
+  o->x2_bytes = 32 + 32LL * mig_cap;
+  o->x3_bytes = (int64_t)sizeof(bh_dd_piece) * kDescPerRank;
+  o->top_base = rec_cap;
+  o->seg_base = rec_cap + top_cap;
+  o->pool_records = o->seg_base + (long long)world * let_cap + 8;
+  o->let_min = let_min;
+  o->let_cap = let_cap;
+  if (o->pool_records >= (1LL << 31)) return BH_ERR_BAD_ARG;
+  return BH_OK;
+}
+
+int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int let_cap, void* pool,
+               int64_t pool_records) {
+  if (!c || !pool || rank < 0 || rank >= world || c->dd) return BH_ERR_BAD_ARG;
+  if (c->p.key_bits != 63 || c->p.leaf_cap != 1 || c->p.strict_fp || c->p.literal_force) return BH_ERR_BAD_ARG;
+  bh_dd_sizes sz;
+  // the context was created with n = body capacity
+  const int n_cap = c->n;
+  int s = bh_dd_query(n_cap, world, mig_cap, let_cap, &sz);
+  if (s) return s;
+  if (pool_records < sz.pool_records || (long long)world * mig_cap > 4LL * n_cap || n_cap < 1024)
+    return BH_ERR_BAD_ARG;
+  BH_HIP(c, hipSetDevice(c->device));
+  bh_dd_state* d = (bh_dd_state*)calloc(1, sizeof(bh_dd_state));
+  if (!d) return BH_ERR_OOM;
+  c->dd = d;
+  d->world = world;
+  d->rank = rank;
+  d->n_total = n_total;
+  d->mig_cap = mig_cap;
+  d->let_cap = let_cap;
+  d->pool = (bh_frec*)pool;
+  d->pool_records = pool_records;
+  d->top_base = (int)sz.top_base;
+  d->seg_base = (int)sz.seg_base;
+  size_t fl = (size_t)n_cap;
+  if ((size_t)world * mig_cap > fl) fl = (size_t)world * mig_cap;
+  bool ok = true;
+  ok = ok && hipMalloc((void**)&d->w, ((size_t)c->rec_cap + 1 + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->dst, ((size_t)c->rec_cap + 1 + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->flag, (fl + 1 + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->fpos, (fl + 1 + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->nloc, 64 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->skeys, 64 * 8) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->piece_tmp, BH_DD_PIECE_CAP * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->piece_idx, BH_DD_PIECE_CAP * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->ddi, 8 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->boxes, (size_t)world * BH_DD_PIECE_CAP * sizeof(float4)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_ps, ((size_t)kTopMax + 1) * sizeof(bh_d4)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_a, (size_t)kTopMax * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_b, (size_t)kTopMax * 4) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&d->ev_let, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    bh_dd_free(c);
+    return BH_ERR_OOM;
+  }
+  d->samp_cap = samp_cap_of(world);
+  BH_HIP(c, hipMemsetAsync(d->nloc, 0, 64 * 4, c->stream));
+  // the caller's pool becomes the record pool: the COM stage writes the local tree at [0, rec_cap)
+  BH_HIP(c, hipMemsetAsync(pool, 0, (size_t)pool_records * sizeof(bh_frec), c->stream));
+  c->frec_own = c->frec;
+  c->frec = d->pool;
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  return BH_OK;
+}
+
+int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const float* z, const float* vx,
+                 const float* vy, const float* vz, const float* m, const int32_t* ids) {
+  if (!c || !c->dd || !x || !y || !z || !vx || !vy || !vz || !m || !ids) return BH_ERR_BAD_ARG;
+  const int n_cap = (c->rec_cap - 8) / 2;
+  if (n_loc < 1 || n_loc > n_cap) return BH_ERR_BAD_ARG;
+  BH_HIP(c, hipSetDevice(c->device));
+  dd_set_n(c, n_loc);
+  const size_t N = (size_t)n_loc, nb = N * sizeof(float);
+  const float* src[7] = {x, y, z, vx, vy, vz, m};
+  for (int k = 0; k < 7; k++)
+    BH_HIP(c, hipMemcpyAsync(c->stage_buf + k * N, src[k], nb, hipMemcpyHostToDevice, c->stream));
+  BH_HIP(c, hipMemcpyAsync(c->vals[0], ids, N * 4, hipMemcpyHostToDevice, c->stream));
+  c->cur = 0;
+  dd_pack_ids_kernel<<<(n_loc + 255) / 256, 256, 0, c->stream>>>(c->stage_buf, (const int*)c->vals[0], n_loc,
+                                                                  c->posm[0], c->velid[0]);
+  BH_HIP(c, hipGetLastError());
+  BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));
+  BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  c->stage = BH_ST_UPLOADED;
+  c->ever = BH_ST_UPLOADED;
+  c->steps = 0;
+  return BH_OK;
+}
+
+int bh_dd_cube_pack(bh_ctx* c, void* send_x1) {
+  if (!c || !c->dd || !send_x1) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_UPLOADED)) return BH_ERR_ORDER;
+  bh_dd_state* d = c->dd;
+  BH_HIP(c, bhk_bbox_raw(c, (float*)send_x1));
+  // stride sized so that a rank holding up to 1.34x its fair share still fits its sample slots
+  const double g = 1.34 * (double)d->n_total / (double)kSampTotal;
+  dd_x1_tail_kernel<<<(d->samp_cap + 255) / 256, 256, 0, c->stream>>>((float*)send_x1, c->n, c->posm[c->cur],
+                                                                       g > 1.0 ? g : 1.0, d->samp_cap);
+  BH_HIP(c, hipGetLastError());
+  return BH_OK;
+}
+
+int bh_dd_cube_apply(bh_ctx* c, const void* gathered_x1) {
+  if (!c || !c->dd || !gathered_x1) return BH_ERR_BAD_ARG;
+  bh_dd_state* d = c->dd;
+  const int xf = x1_floats(d->world);
+  BH_HIP(c, bhk_bounds_from_rows(c, (const float*)gathered_x1, d->world, xf));
+  dd_split_kernel<<<1, 1024, 0, c->stream>>>((const float*)gathered_x1, d->world, xf, d->samp_cap, c->bounds,
+                                             d->skeys);
+  BH_HIP(c, hipGetLastError());
+  c->stage = BH_ST_UPLOADED | BH_ST_BBOX;
+  c->ever |= BH_ST_BBOX;
+  return BH_OK;
+}
+
+int bh_dd_migrate_pack(bh_ctx* c, void* send_x2, int limit) {
+  if (!c || !c->dd || !send_x2) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_BBOX)) return BH_ERR_ORDER;
+  bh_dd_state* d = c->dd;
+  if (limit < 1 || limit > d->mig_cap) return BH_ERR_BAD_ARG;
+  const int n = c->n;
+  BH_HIP(c, bhk_keys(c));
+  const int blocks = (n + 255) / 256 > 0 ? (n + 255) / 256 : 1;
+  dd_classify_kernel<<<blocks, 256, 0, c->stream>>>(c->keys[0], n, d->skeys, d->world - 1, d->rank, d->flag);
+  BH_HIP(c, hipGetLastError());
+  BH_HIP(c, bhk_scan_i32(c, d->flag, d->fpos, n, nullptr));
+  dd_compact_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], n, d->flag, d->fpos,
+                                                   c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], (float4*)send_x2,
+                                                   limit);
+  BH_HIP(c, hipGetLastError());
+  c->cur ^= 1;
+  return BH_OK;
+}
+
+int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_loc, int* more, int* most) {
+  if (!c || !c->dd || !gathered_x2) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_BBOX)) return BH_ERR_ORDER;
+  bh_dd_state* d = c->dd;
+  if (limit < 1 || limit > d->mig_cap) return BH_ERR_BAD_ARG;
+  const float4* g = (const float4*)gathered_x2;
+  const size_t f4 = 2 + 2 * (size_t)limit;
+  const int slots = d->world * limit;
+  const int n_cap = (c->rec_cap - 8) / 2;
+  dd_nloc_init_kernel<<<1, 64, 0, c->stream>>>(g, d->world, f4, d->nloc);
+  dd_absorb_flag_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, c->bounds, d->skeys,
+                                                                    d->rank, d->flag, d->nloc);
+  BH_HIP(c, hipGetLastError());
+  BH_HIP(c, bhk_scan_i32(c, d->flag, d->fpos, slots, nullptr));
+  dd_absorb_copy_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, d->rank, d->flag,
+                                                                    d->fpos, n_cap, c->posm[c->cur],
+                                                                    c->velid[c->cur], c->info);
+  dd_migrate_result_kernel<<<1, 64, 0, c->stream>>>(g, d->world, f4, d->nloc, d->rank, c->info, d->ddi + 4);
+  BH_HIP(c, hipGetLastError());
+  BH_HIP(c, hipMemcpyAsync(d->host + 64, d->ddi + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  const int nl = d->host[64], flags = d->host[65];
+  if (n_loc) *n_loc = nl;
+  if (more) *more = d->host[66] > 0 ? 1 : 0;
+  if (most) *most = d->host[67];
+  if (flags & BH_FLAG_DD_BODIES) return BH_ERR_POOL_OVERFLOW;
+  if (nl < 2 || nl > n_cap) return BH_ERR_POOL_OVERFLOW;
+  dd_set_n(c, nl);
+  return BH_OK;
+}
+
+int bh_dd_tree(bh_ctx* c, void* send_x3) {
+  if (!c || !c->dd || !send_x3) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_BBOX)) return BH_ERR_ORDER;
+  bh_dd_state* d = c->dd;
+  BH_HIP(c, bhk_keys(c));
+  c->key_buf = 0;
+  BH_HIP(c, bhk_sort(c));
+  BH_HIP(c, bhk_build(c));
+  BH_HIP(c, bhk_com(c));
+  BH_HIP(c, hipMemsetAsync(d->ddi, 0, 8 * 4, c->stream));
+  dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->er_lo, c->er_hi, c->info, c->rec_cap,
+                                                                   c->n, d->piece_tmp, d->ddi);
+  dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, c->rec, c->er_lo, c->er_hi,
+                                                           c->keys[c->key_buf], c->P, c->posm[c->cur], c->bounds,
+                                                           d->rank, c->n, (bh_dd_piece*)send_x3, d->piece_idx,
+                                                           c->info);
+  BH_HIP(c, hipGetLastError());
+  c->stage |= BH_ST_MORTON | BH_ST_SORT | BH_ST_BUILD | BH_ST_COM;
+  c->ever |= BH_ST_MORTON | BH_ST_SORT | BH_ST_BUILD | BH_ST_COM;
+  return BH_OK;
+}
+
+int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride) {
+  if (!c || !c->dd || !gathered_x3 || !send_x4) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
+  bh_dd_state* d = c->dd;
+  if (stride < 1 + BH_DD_PIECE_CAP || stride > d->let_cap) return BH_ERR_BAD_ARG;
+  BH_HIP(c, hipMemsetAsync(d->ddi + 1, 0, 4, c->stream));
+  dd_boxes_kernel<<<(d->world * BH_DD_PIECE_CAP + 255) / 256, 256, 0, c->stream>>>(
+      (const bh_dd_piece*)gathered_x3, d->world, d->rank, c->bounds, d->boxes, d->ddi);
+  const int blocks = (c->rec_cap + 1 + 255) / 256;
+  dd_mark_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->info, c->rec_cap, d->boxes, d->ddi, c->p.eps2, d->w);
+  BH_HIP(c, hipGetLastError());
+  BH_HIP(c, bhk_scan_i32(c, d->w, d->dst, c->rec_cap, nullptr));
+  dd_export_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->posm[c->cur], c->rec_cap, d->w, d->dst,
+                                                  d->piece_idx, d->ddi, d->seg_base + d->rank * stride, stride,
+                                                  c->p.G, (bh_frec*)send_x4);
+  BH_HIP(c, hipGetLastError());
+  return BH_OK;
+}
+
+int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
+  if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
+  bh_dd_state* d = c->dd;
+  if (stride < 1 + BH_DD_PIECE_CAP || stride > d->let_cap) return BH_ERR_BAD_ARG;
+  // the segment headers (records each rank needed) go to the host for bh_dd_let_check
+  BH_HIP(c, hipMemcpy2DAsync(d->host, sizeof(int), &d->pool[d->seg_base].first, (size_t)stride * sizeof(bh_frec),
+                             sizeof(int), (size_t)d->world, hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(c, hipEventRecord(d->ev_let, c->stream));
+  d->let_copy_pending = true;
+  dd_top_kernel<<<1, 1024, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
+                                           d->top_base, d->seg_base, stride, c->bounds, c->p.G, c->p.theta,
+                                           d->top_ps, d->top_a, d->top_b, c->info);
+  BH_HIP(c, hipGetLastError());
+  return BH_OK;
+}
+
+int bh_dd_force(bh_ctx* c) {
+  if (!c || !c->dd) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
+  BH_HIP(c, bhk_force_root(c, 0, c->n, c->dd->top_base));
+  c->stage |= BH_ST_FORCE;
+  c->ever |= BH_ST_FORCE;
+  return BH_OK;
+}
+
+int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts) {
+  if (!c || !c->dd) return BH_ERR_BAD_ARG;
+  bh_dd_state* d = c->dd;
+  if (!d->let_copy_pending) return BH_ERR_ORDER;
+  BH_HIP(c, hipEventSynchronize(d->ev_let));
+  d->let_copy_pending = false;
+  int worst = 0;
+  for (int q = 0; q < d->world; q++) {
+    if (counts) counts[q] = d->host[q];
+    if (d->host[q] > worst) worst = d->host[q];
+  }
+  return worst > stride ? BH_ERR_SMALL_BUFFER : BH_OK;
+}
+
+int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc) {
+  if (!c || !c->dd) return BH_ERR_BAD_ARG;
+  const size_t nb = (size_t)c->n * sizeof(float4);
+  if (posm) BH_HIP(c, hipMemcpyAsync(posm, c->posm[c->cur], nb, hipMemcpyDeviceToHost, c->stream));
+  if (velid) BH_HIP(c, hipMemcpyAsync(velid, c->velid[c->cur], nb, hipMemcpyDeviceToHost, c->stream));
+  if (acc) BH_HIP(c, hipMemcpyAsync(acc, c->acc, nb, hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  return BH_OK;
+}
+
+}  // extern "C"

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
                                                          const float4* __restrict__ posm,
                                                          float4* __restrict__ acc, int lo, int hi, float G,
                                                          float eps2, int xcd_mode,
-                                                         bh_devinfo* __restrict__ info) {
+                                                         bh_devinfo* __restrict__ info, int root) {
   cfloat_t* frec = (cfloat_t*)frec_g;
   cfloat_t* bodies = (cfloat_t*)posm;
   const int lane = threadIdx.x & 63;
@@ -347,12 +347,20 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
 
   WaveStack st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int sp = 0;
-  ws_push(st, sp++, 0, 1, m0);  // ref:198 stack = {root}
+  ws_push(st, sp++, root, 1, m0);  // ref:198 stack = {root}
 
+  // a well-formed tree needs ~10^3 pops per wave; the budget only bounds the walk over a malformed
+  // pool (a wave that never finishes can take the whole GPU down)
+  int budget = 1 << 22;
   while (sp > 0) {
     int first, count;
     u64 mask;
     ws_pop(st, --sp, first, count, mask);
+    budget -= 1 + (count >> 2);
+    if (budget < 0 || count < 0) {
+      if (lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
+      break;
+    }
     for (int k0 = 0; k0 < count; k0 += 4) {
       // the record pool is padded, so reading up to 3 records past the block is safe
       const FRec r0 = load_frec(frec, first + k0 + 0);
@@ -688,12 +696,25 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
         int g2 = (hi - lo + tpb - 1) / tpb;
         if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
         force_fast_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                   mode, c->info);
+                                                   mode, c->info, 0);
       } else
         force_batched_kernel<<<grid, 256, 0, c->stream>>>((const float4*)c->frec, posm, c->acc, lo, hi, G, e2,
                                                         c->rec_cap, mode, c->info);
     }
   }
+  return hipGetLastError();
+}
+
+// domain-decomposed stepping: the local bodies traverse the stitched pool (local tree + imported
+// LET segments) from the top-tree root
+hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root) {
+  if (hi <= lo) return hipSuccess;
+  int tpb = c->p.force_block;
+  if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
+  const int mode = c->p.xcd_mode == 2 ? 0 : c->p.xcd_mode;
+  const int g2 = (hi - lo + tpb - 1) / tpb;
+  force_fast_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->acc, lo, hi, c->p.G,
+                                             c->p.eps2, mode, c->info, root);
   return hipGetLastError();
 }
 

@@ -72,6 +72,7 @@ struct bh_ctx {
   u64* sw_status;  // [passes][ntiles][256] look-back granules {tag|state|count}
   u32* sw_ticket;  // [8] monotonic tile tickets, one counter per pass
   u32 sort_calls;
+  u32 sort_ticket_base;  // tickets handed out per pass counter so far (the tile count may change between calls)
   int sort_tiles;
 
   // bbox
@@ -101,6 +102,10 @@ struct bh_ctx {
   hipEvent_t ev_sorted, ev_pscan;
   void* scan_tmp2;
 
+  // domain-decomposed stepping (bh_dd.hip); null until bh_dd_init
+  struct bh_dd_state* dd;
+  bh_frec* frec_own;  // the context's own record pool while frec points into a caller pool
+
   // counters (bh_force_count)
   u32 *cV, *cO, *cP;
   u64 tV, tO, tP;
@@ -121,6 +126,8 @@ struct bh_ctx {
 hipError_t bhk_pack(bh_ctx* c);                       // stage_buf SoA -> posm/velid
 hipError_t bhk_unpack(bh_ctx* c, int what);           // 0: pos+vel -> stage_buf (caller order); 1: acc
 hipError_t bhk_bbox(bh_ctx* c);
+hipError_t bhk_bbox_raw(bh_ctx* c, float* out6);  // local min/max only
+hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int stride_floats);
 hipError_t bhk_keys(bh_ctx* c);
 hipError_t bhk_sort(bh_ctx* c);                       // radix sort + gather
 hipError_t bhk_sort_onesweep(bh_ctx* c);              // default implementation (bh_sort_onesweep.hip)
@@ -128,7 +135,9 @@ hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
 hipError_t bhk_force_fast(bh_ctx* c, int lo, int hi);  // bh_force_fast.hip, default fast kernel
+hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root);  // fast kernel from pool record `root`
 hipError_t bhk_integrate(bh_ctx* c);
+void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 
 // device-wide scans (bh_scan.hip)
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);

@@ -1,0 +1,58 @@
+// bh_keys.h — Morton-key device helpers shared by the tree stages (bh_tree.hip) and the
+// domain-decomposed stepping (bh_dd.hip).  Reference: nbody_v5_bench.cu:42-63.
+#pragma once
+#include "bh_internal.h"
+
+__device__ __forceinline__ u32 expand_bits10(u32 v) {  // ref:42-49
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+__device__ __forceinline__ u64 expand_bits21(u32 q) {
+  u64 x = q & 0x1fffffu;
+  x = (x | x << 32) & 0x001f00000000ffffull;
+  x = (x | x << 16) & 0x001f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+// inverse of expand_bits21: every third bit of k, packed
+__device__ __forceinline__ u32 compact_bits21(u64 x) {
+  x &= 0x1249249249249249ull;
+  x = (x | x >> 2) & 0x10c30c30c30c30c3ull;
+  x = (x | x >> 4) & 0x100f00f00f00f00full;
+  x = (x | x >> 8) & 0x001f0000ff0000ffull;
+  x = (x | x >> 16) & 0x001f00000000ffffull;
+  x = (x | x >> 32) & 0x1fffffull;
+  return (u32)x;
+}
+
+// key of one position inside the cube `bounds` (min xyz at [0..2], edge at [6]); B = bits per axis.
+// IEEE subtract, divide, multiply in the reference's order (ref:56-58); truncating conversion.
+template <int B>
+__device__ __forceinline__ u64 morton_key(float px, float py, float pz, float minX, float minY, float minZ,
+                                          float size) {
+  constexpr float scale = (B == 10) ? 1023.0f : 2097152.0f;  // ref:56-58 (x1023) / 2^21
+  constexpr u32 qmax = (1u << B) - 1u;
+  u32 x = (u32)((px - minX) / size * scale);
+  u32 y = (u32)((py - minY) / size * scale);
+  u32 z = (u32)((pz - minZ) / size * scale);
+  x = min(x, qmax);
+  y = min(y, qmax);
+  z = min(z, qmax);
+  if (B == 10) return (u64)((expand_bits10(x) << 2) | (expand_bits10(y) << 1) | expand_bits10(z));  // ref:61
+  return (expand_bits21(x) << 2) | (expand_bits21(y) << 1) | expand_bits21(z);
+}
+
+// leading octal digits shared by two keys of B digits
+__device__ __forceinline__ int common_digits(u64 a, u64 b, int B) {
+  const u64 x = a ^ b;
+  if (x == 0) return B;
+  const int hb = 63 - __clzll((long long)x);
+  return B - 1 - hb / 3;
+}
+
+__device__ __forceinline__ u64 key_prefix(u64 k, int sh) { return (sh >= 64) ? 0ull : (k >> sh); }

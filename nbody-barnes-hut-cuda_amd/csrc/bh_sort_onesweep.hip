@@ -253,9 +253,10 @@ hipError_t bhk_sort_onesweep(bh_ctx* c) {
   for (int p = 0; p < passes; p++) {
     onesweep_pass_kernel<<<ntiles, kThreads, 0, c->stream>>>(
         c->keys[src], c->vals[src], c->keys[src ^ 1], c->vals[src ^ 1], n, 8 * p, c->sw_hist + p * 256,
-        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, call * (u32)ntiles, tag, p == 0, c->info);
+        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, c->sort_ticket_base, tag, p == 0, c->info);
     src ^= 1;
   }
+  c->sort_ticket_base += (u32)ntiles;
   c->key_buf = src;
   const int blocks = (n + 255) / 256;
   gather2_kernel<<<blocks, 256, 0, c->stream>>>(c->vals[src], c->posm[c->cur], c->velid[c->cur],

@@ -17,6 +17,7 @@
 //             a cell's sums are P[hi] - P[lo], rounded once to fp32.  Deterministic, no atomics,
 //             more accurate than any fp32 summation order (the reference's is non-deterministic).
 #include "bh_internal.h"
+#include "bh_keys.h"
 
 namespace {
 
@@ -79,18 +80,24 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float4* __restr
   }
 }
 
+// rows of 6 floats (min xyz, max xyz) `stride` floats apart; raw != 0: write the folded min/max
+// only (6 floats), else the cube of ref:148-154
 __global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict__ partial, int nparts,
+                                                         int stride, int raw,
                                                          float* __restrict__ bounds) {
   __shared__ float lds[24];
   float mn[3] = {1e10f, 1e10f, 1e10f};
   float mx[3] = {-1e10f, -1e10f, -1e10f};
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    const float* o = partial + i * 6;
+    const float* o = partial + (size_t)i * stride;
     mn[0] = fminf(mn[0], o[0]); mn[1] = fminf(mn[1], o[1]); mn[2] = fminf(mn[2], o[2]);
     mx[0] = fmaxf(mx[0], o[3]); mx[1] = fmaxf(mx[1], o[4]); mx[2] = fmaxf(mx[2], o[5]);
   }
   block_minmax(mn, mx, lds);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && raw) {
+    bounds[0] = mn[0]; bounds[1] = mn[1]; bounds[2] = mn[2];
+    bounds[3] = mx[0]; bounds[4] = mx[1]; bounds[5] = mx[2];
+  } else if (threadIdx.x == 0) {
     const float size = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));  // ref:148
     bounds[0] = mn[0];
     bounds[1] = mn[1];
@@ -104,23 +111,6 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------ keys
-__device__ __forceinline__ u32 expand_bits10(u32 v) {  // ref:42-49
-  v = (v * 0x00010001u) & 0xFF0000FFu;
-  v = (v * 0x00000101u) & 0x0F00F00Fu;
-  v = (v * 0x00000011u) & 0xC30C30C3u;
-  v = (v * 0x00000005u) & 0x49249249u;
-  return v;
-}
-__device__ __forceinline__ u64 expand_bits21(u32 q) {
-  u64 x = q & 0x1fffffu;
-  x = (x | x << 32) & 0x001f00000000ffffull;
-  x = (x | x << 16) & 0x001f0000ff0000ffull;
-  x = (x | x << 8) & 0x100f00f00f00f00full;
-  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-  x = (x | x << 2) & 0x1249249249249249ull;
-  return x;
-}
-
 template <int B>
 __global__ __launch_bounds__(256) void keys_kernel(const float4* __restrict__ posm,
                                                    const float* __restrict__ bounds, int n,
@@ -130,20 +120,7 @@ __global__ __launch_bounds__(256) void keys_kernel(const float4* __restrict__ po
   const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
   const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
   const float4 q = posm[i];
-  constexpr float scale = (B == 10) ? 1023.0f : 2097152.0f;  // ref:56-58 (x1023) / 2^21
-  constexpr u32 qmax = (1u << B) - 1u;
-  // IEEE subtract, divide, multiply in the reference's order; truncating conversion
-  u32 x = (u32)((q.x - minX) / size * scale);
-  u32 y = (u32)((q.y - minY) / size * scale);
-  u32 z = (u32)((q.z - minZ) / size * scale);
-  x = min(x, qmax);
-  y = min(y, qmax);
-  z = min(z, qmax);
-  u64 k;
-  if (B == 10)
-    k = (u64)((expand_bits10(x) << 2) | (expand_bits10(y) << 1) | expand_bits10(z));  // ref:61
-  else
-    k = (expand_bits21(x) << 2) | (expand_bits21(y) << 1) | expand_bits21(z);
+  const u64 k = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
   keys[i] = k;
 }
 
@@ -168,15 +145,6 @@ __global__ __launch_bounds__(256) void keys_kernel(const float4* __restrict__ po
 // (pairs_kernel below: LDS-window bitmask queries; key searches only for cells wider than the window).
 // One exclusive scan of nchild[] places each cell's children in one contiguous block; the
 // representative index j doubles as the cell id, so no compaction pass is needed.
-__device__ __forceinline__ int common_digits(u64 a, u64 b, int B) {
-  const u64 x = a ^ b;
-  if (x == 0) return B;
-  const int hb = 63 - __clzll((long long)x);
-  return B - 1 - hb / 3;
-}
-
-__device__ __forceinline__ u64 key_prefix(u64 k, int sh) { return (sh >= 64) ? 0ull : (k >> sh); }
-
 // Sampled lower bound for the wide-cell searches: first index i in [0, n] with (k[i] >> sh) >= T.
 // `samp` (in LDS) holds every (1 << ss)-th key, so the first ~11 bisection steps cost LDS reads and
 // the dependent GLOBAL loads drop from ~log2(n) to ~ss, all inside one 2^ss-key (32 KiB) span.
@@ -694,7 +662,24 @@ hipError_t bhk_bbox(bh_ctx* c) {
   if (blocks > BH_BBOX_BLOCKS) blocks = BH_BBOX_BLOCKS;
   if (blocks < 1) blocks = 1;
   bbox_partial_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], n, c->bbox_partial);
-  bbox_final_kernel<<<1, 256, 0, c->stream>>>(c->bbox_partial, blocks, c->bounds);
+  bbox_final_kernel<<<1, 256, 0, c->stream>>>(c->bbox_partial, blocks, 6, 0, c->bounds);
+  return hipGetLastError();
+}
+
+// min/max of the local bodies only (6 floats to out6): the per-rank half of the global cube
+hipError_t bhk_bbox_raw(bh_ctx* c, float* out6) {
+  const int n = c->n;
+  int blocks = (n + 1023) / 1024;
+  if (blocks > BH_BBOX_BLOCKS) blocks = BH_BBOX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  bbox_partial_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], n, c->bbox_partial);
+  bbox_final_kernel<<<1, 256, 0, c->stream>>>(c->bbox_partial, blocks, 6, 1, out6);
+  return hipGetLastError();
+}
+
+// cube from `nrows` rows of per-rank min/max (exact: min/max are associative)
+hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int stride_floats) {
+  bbox_final_kernel<<<1, 256, 0, c->stream>>>(rows, nrows, stride_floats, 0, c->bounds);
   return hipGetLastError();
 }
 

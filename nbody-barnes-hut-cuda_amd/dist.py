@@ -72,15 +72,179 @@ class ShardedStepper:
 
 
 def make_gpu_stepper(pkg, n, params=None, device=None, group=None, **kw):
-    """Engine on torch's current stream (so RCCL collectives and kernels are ordered by the
+    """Engine on a dedicated torch stream (so RCCL collectives and kernels are ordered by that
     stream) with its acceleration buffer bound to a torch tensor sized for the all-gather."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if device is None:
         device = torch.cuda.current_device()
+    # a non-default stream: the default stream's handle is 0, which bh_create_on_stream reads as
+    # "make your own", and kernels on that private stream would race the collectives
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
     slab = slab_size(n, world)
     acc = torch.zeros((world * slab, 4), dtype=torch.float32, device=f"cuda:{device}")
-    stream = torch.cuda.current_stream(device).cuda_stream
-    eng = pkg.Engine(n, params=params, device=device, stream=stream, **kw)
+    torch.cuda.synchronize(device)
+    eng = pkg.Engine(n, params=params, device=device, stream=stream.cuda_stream, **kw)
     eng.bind_acc(acc.data_ptr())
-    eng._acc_keepalive = acc
+    eng._acc_keepalive = (acc, stream)
     return eng, ShardedStepper(eng, acc, n, group)
+
+
+# ----------------------------------------------------------------------------------------------
+# Domain-decomposed stepping (include/bh.h bh_dd_*, csrc/bh_dd.hip; SURVEY §8e)
+# ----------------------------------------------------------------------------------------------
+class TorchComm:
+    """the four per-step all-gathers over torch.distributed (backend "nccl" = RCCL over xGMI)"""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather(self, out, send):
+        all_gather_rows(out.view(self.world, -1), send.view(1, -1), self.group)
+
+
+class LocalGroup:
+    """P ranks as P threads of one process on one device and ONE stream (tests, 1-GPU rehearsal):
+    the all-gather is P device copies; a barrier orders the ranks' enqueues on the shared stream."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class LocalComm:
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world = group, rank, group.world
+
+    def all_gather(self, out, send):
+        g = self.g
+        g.slots[self.rank] = send
+        g.barrier.wait()
+        n = send.numel()
+        o = out.view(-1)
+        for q in range(self.world):
+            o[q * n:(q + 1) * n].copy_(g.slots[q].view(-1))
+        g.barrier.wait()
+
+
+def _round_up(v, a):
+    return (int(v) + a - 1) // a * a
+
+
+def global_morton_order(pkg, ic, device, params=None, **kw):
+    """ids of the bodies in the Morton order of the global cube (one throw-away full-size engine:
+    the same deterministic sort on every rank, so all ranks agree on the initial slabs)."""
+    n = len(ic[0])
+    with pkg.Engine(n, params=params, device=device, **kw) as e:
+        e.upload(*ic)
+        e.bbox()
+        e.morton()
+        e.sort()
+        return e.download_order()
+
+
+class DomainStepper:
+    """One rank of the domain-decomposed step: this rank owns the bodies of one Morton-key range,
+    builds only their octree, imports the other ranks' locally-essential records and traverses the
+    stitched tree for its own bodies.  Four all-gathers per step, no replicated stage."""
+
+    def __init__(self, pkg, ic, comm, device, stream=None, params=None, slack=1.3, mig_frac=0.5,
+                 let_cap=None, order=None, **kw):
+        self.comm = comm
+        self.world, self.rank = comm.world, comm.rank
+        P, r = self.world, self.rank
+        n = len(ic[0])
+        self.n_total = n
+        if order is None:
+            order = global_morton_order(pkg, ic, device, params=params, **kw)
+        cuts = [q * n // P for q in range(P + 1)]
+        counts = [cuts[q + 1] - cuts[q] for q in range(P)]
+        mine = order[cuts[r]:cuts[r + 1]]
+        x, y, z, vx, vy, vz, m = [a[mine] for a in ic]
+
+        self.n_cap = max(1024, int(max(counts) * slack) + 4096)
+        # X2 buffers hold up to mig_cap emigrants per rank; a step normally sends far fewer
+        # (mig_stride follows the observed count), a larger wave goes in several rounds
+        self.mig_cap = min(max(4096, int(self.n_cap * mig_frac)), 4 * self.n_cap // P)
+        self.mig_stride = min(self.mig_cap, 4096)
+        self.mig_rounds = 0
+        self.mig_last = 0
+        e_cls = pkg.Engine
+        lmin = 1 + 512
+        self.let_cap = int(let_cap) if let_cap else lmin + self.n_cap
+        sz = e_cls.dd_query(self.n_cap, P, self.mig_cap, self.let_cap)
+        self.sz = sz
+        self.stream = stream if stream is not None else torch.cuda.Stream(device)
+        dev = f"cuda:{device}"
+        with torch.cuda.stream(self.stream):
+            u8 = dict(dtype=torch.uint8, device=dev)
+            self.x1s = torch.zeros(sz.x1_bytes, **u8)
+            self.x1r = torch.zeros(P * sz.x1_bytes, **u8)
+            self.x2s = torch.zeros(sz.x2_bytes, **u8)
+            self.x2r = torch.zeros(P * sz.x2_bytes, **u8)
+            self.x3s = torch.zeros(sz.x3_bytes, **u8)
+            self.x3r = torch.zeros(P * sz.x3_bytes, **u8)
+            self.lets = torch.zeros(self.let_cap * 32, **u8)
+            self.pool = torch.zeros(sz.pool_records * 32, **u8)
+        self.stream.synchronize()
+        self.e = e_cls(self.n_cap, params=params, device=device, stream=self.stream.cuda_stream, **kw)
+        self.e.dd_init(P, r, n, self.mig_cap, self.let_cap, self.pool.data_ptr(), sz.pool_records)
+        self.e.dd_upload(x, y, z, vx, vy, vz, m, mine.astype("int32"))
+        self.stride = min(self.let_cap, _round_up(lmin + self.n_cap // 8, 256))
+        self.let_counts = None
+        self.let_retries = 0
+        self.n_loc = len(mine)
+
+    def step(self, steps=1):
+        e, c, sz, P = self.e, self.comm, self.sz, self.world
+        with torch.cuda.stream(self.stream):
+            for _ in range(int(steps)):
+                e.dd_cube_pack(self.x1s.data_ptr())                    # X1: cube + splitters
+                c.all_gather(self.x1r, self.x1s)
+                e.dd_cube_apply(self.x1r.data_ptr())
+                limit, first = self.mig_stride, None                   # X2: bodies that changed owner
+                while True:
+                    nb = 32 + 32 * limit
+                    e.dd_migrate_pack(self.x2s.data_ptr(), limit)
+                    c.all_gather(self.x2r[:P * nb], self.x2s[:nb])
+                    self.n_loc, more, most = e.dd_migrate_apply(self.x2r.data_ptr(), limit)
+                    first = most if first is None else first
+                    if not more:
+                        break
+                    self.mig_rounds += 1                                # rare: a splitter changed octant
+                    limit = min(self.mig_cap, max(limit, _round_up(most, 256)))
+                self.mig_last = first
+                self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 1.5 + 2048, 256)))
+                e.dd_tree(self.x3s.data_ptr())                         # local sort/build/COM; X3: pieces
+                c.all_gather(self.x3r, self.x3s)
+                while True:
+                    stride = self.stride
+                    e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
+                    seg = self.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32]
+                    c.all_gather(seg, self.lets[:stride * 32])          # X4: LET records, in place
+                    e.dd_top(self.x3r.data_ptr(), stride)
+                    e.dd_force()
+                    ok, counts = e.dd_let_check(stride, P)
+                    self.let_counts = counts
+                    need = int(counts.max())
+                    if ok:
+                        break
+                    if need > self.let_cap:
+                        raise RuntimeError(f"LET of {need} records exceeds let_cap {self.let_cap}")
+                    self.let_retries += 1
+                    self.stride = min(self.let_cap, _round_up(need * 1.25, 256))
+                # every rank sees the same counts, so every rank picks the same next stride
+                self.stride = max(sz.let_min, min(self.let_cap, _round_up(need * 1.15 + 1024, 256)))
+                e.integrate()
+
+    def local_state(self):
+        """(ids, posm[n,4], vel[n,3], acc[n,3]) of this rank's bodies"""
+        posm, vel, ids, acc = self.e.dd_download()
+        return ids, posm, vel, acc
+
+    def close(self):
+        self.e.close()

@@ -3,6 +3,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _lib
 from ._lib import lib, BhParams, BhNode, BhStats
 
 KIND_BODY, KIND_INTERNAL, KIND_MULTI = 0, 1, 2
@@ -265,3 +266,73 @@ class Engine:
         nb = C.c_int64()
         self._ck(lib.bh_device_acc(self._h, C.byref(p), C.byref(nb)), "bh_device_acc")
         return p.value, nb.value
+
+    # ---- domain-decomposed multi-GPU stepping (include/bh.h bh_dd_*; driven by dist.DomainStepper) ----
+    @staticmethod
+    def dd_query(n_cap, world, mig_cap, let_cap):
+        s = _lib.BhDdSizes()
+        st = lib.bh_dd_query(int(n_cap), int(world), int(mig_cap), int(let_cap), C.byref(s))
+        if st != 0:
+            raise BhError(st, "bh_dd_query")
+        return s
+
+    def dd_init(self, world, rank, n_total, mig_cap, let_cap, pool_ptr, pool_records):
+        self._ck(lib.bh_dd_init(self._h, int(world), int(rank), int(n_total), int(mig_cap), int(let_cap),
+                                C.c_void_p(int(pool_ptr)), int(pool_records)), "bh_dd_init")
+
+    def dd_upload(self, x, y, z, vx, vy, vz, m, ids):
+        n_loc = len(x)
+        arrs = [_f32(a, n_loc) for a in (x, y, z, vx, vy, vz, m)]
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self._ck(lib.bh_dd_upload(self._h, n_loc, *[a.ctypes.data_as(_lib._F) for a in arrs],
+                                  ids.ctypes.data_as(C.POINTER(C.c_int32))), "bh_dd_upload")
+        self.n = n_loc
+
+    def dd_cube_pack(self, send_ptr):
+        self._ck(lib.bh_dd_cube_pack(self._h, C.c_void_p(int(send_ptr))), "bh_dd_cube_pack")
+
+    def dd_cube_apply(self, gathered_ptr):
+        self._ck(lib.bh_dd_cube_apply(self._h, C.c_void_p(int(gathered_ptr))), "bh_dd_cube_apply")
+
+    def dd_migrate_pack(self, send_ptr, limit):
+        self._ck(lib.bh_dd_migrate_pack(self._h, C.c_void_p(int(send_ptr)), int(limit)), "bh_dd_migrate_pack")
+
+    def dd_migrate_apply(self, gathered_ptr, limit):
+        """(bodies now held, another round needed, most emigrants found on any rank)"""
+        n_loc, more, most = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._ck(lib.bh_dd_migrate_apply(self._h, C.c_void_p(int(gathered_ptr)), int(limit), C.byref(n_loc),
+                                         C.byref(more), C.byref(most)), "bh_dd_migrate_apply")
+        self.n = n_loc.value
+        return self.n, bool(more.value), most.value
+
+    def dd_tree(self, send_ptr):
+        self._ck(lib.bh_dd_tree(self._h, C.c_void_p(int(send_ptr))), "bh_dd_tree")
+
+    def dd_let_pack(self, gathered_x3_ptr, send_ptr, stride):
+        self._ck(lib.bh_dd_let_pack(self._h, C.c_void_p(int(gathered_x3_ptr)), C.c_void_p(int(send_ptr)),
+                                    int(stride)), "bh_dd_let_pack")
+
+    def dd_top(self, gathered_x3_ptr, stride):
+        self._ck(lib.bh_dd_top(self._h, C.c_void_p(int(gathered_x3_ptr)), int(stride)), "bh_dd_top")
+
+    def dd_force(self):
+        self._ck(lib.bh_dd_force(self._h), "bh_dd_force")
+
+    def dd_let_check(self, stride, world):
+        """(fits, counts): records every rank needed in the last LET exchange."""
+        counts = np.zeros(world, np.int32)
+        st = lib.bh_dd_let_check(self._h, int(stride), counts.ctypes.data_as(C.POINTER(C.c_int32)))
+        if st not in (0, -7):
+            raise BhError(st, "bh_dd_let_check")
+        return st == 0, counts
+
+    def dd_download(self):
+        """local bodies in local Morton order: posm [n,4], vel [n,3], ids [n], acc [n,3]"""
+        n = self.n
+        posm = np.empty((n, 4), np.float32)
+        velid = np.empty((n, 4), np.float32)
+        acc = np.empty((n, 4), np.float32)
+        self._ck(lib.bh_dd_download(self._h, posm.ctypes.data_as(_lib._F), velid.ctypes.data_as(_lib._F),
+                                    acc.ctypes.data_as(_lib._F)), "bh_dd_download")
+        ids = velid[:, 3].copy().view(np.int32)
+        return posm, velid[:, :3].copy(), ids, acc[:, :3].copy()

@@ -1,0 +1,124 @@
+"""Domain-decomposed multi-GPU stepping (bh_dd_* of include/bh.h, dist.DomainStepper) on ONE GPU:
+P ranks run as P threads of this process (dist.LocalComm: the all-gathers are device copies), each
+with its own context, owning one Morton-key range.  The stitched tree (local octree + top tree +
+imported LET segments) must reproduce the single-context run: same canonical octree, so forces
+agree up to summation order / the last bit of cell sums."""
+import threading
+
+import numpy as np
+import pytest
+
+import bhpkg
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(world, ic, steps, **kw):
+    import torch
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    order = bhdist.global_morton_order(pkg, ic, 0)
+    group = bhdist.LocalGroup(world)
+    stream = torch.cuda.Stream(0)
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            st = bhdist.DomainStepper(pkg, ic, bhdist.LocalComm(group, r), 0, stream=stream, order=order, **kw)
+            group.barrier.wait()
+            st.step(steps)
+            assert st.e.stats().status_flags == 0
+            out[r] = st.local_state() + (st.let_counts.copy(), st.let_retries, st.n_loc)
+            group.barrier.wait()
+            st.close()
+        except BaseException as ex:  # noqa: BLE001 - report from the main thread
+            errs.append((r, ex))
+            group.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0][1]
+    return out
+
+
+def merge(out, n):
+    pos = np.zeros((n, 3), np.float32)
+    vel = np.zeros((n, 3), np.float32)
+    acc = np.zeros((n, 3), np.float32)
+    seen = np.zeros(n, np.int32)
+    for ids, posm, v, a, *_ in out:
+        pos[ids] = posm[:, :3]
+        vel[ids] = v
+        acc[ids] = a
+        seen[ids] += 1
+    assert (seen == 1).all(), "every body must be owned by exactly one rank"
+    return pos, vel, acc
+
+
+def single(ic, steps):
+    pkg = bhpkg.load()
+    n = len(ic[0])
+    with pkg.Engine(n) as e:
+        e.upload(*ic)
+        e.step(steps)
+        x, y, z, vx, vy, vz = e.download()
+        ax, ay, az = e.download_acc()
+        assert e.stats().status_flags == 0
+    return np.stack([x, y, z], 1), np.stack([vx, vy, vz], 1), np.stack([ax, ay, az], 1)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_dd_first_step_matches_single_context(world):
+    pkg = bhpkg.load()
+    n = 60000
+    ic = pkg.plummer(n, seed=7)
+    p1, v1, a1 = single(ic, 1)
+    out = run_ranks(world, ic, 1)
+    p, v, a = merge(out, n)
+    e = rel(a, a1)
+    # same accepted sets; fp32 summation order differs (top tree first, segments interleaved)
+    assert np.median(e) < 2e-6, np.median(e)
+    assert np.quantile(e, 0.9999) < 1e-4, np.quantile(e, 0.9999)
+    assert e.max() < 2e-3, e.max()
+    assert np.abs(p - p1).max() < 1e-3
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dd_many_steps_conserve_and_track(world):
+    pkg = bhpkg.load()
+    n = 40000
+    ic = pkg.plummer(n, seed=11)
+    steps = 12
+    p1, v1, a1 = single(ic, steps)
+    out = run_ranks(world, ic, steps)
+    p, v, a = merge(out, n)     # also checks that migration lost / duplicated nobody
+    assert sum(o[-1] for o in out) == n
+    assert np.abs(p - p1).max() < 5e-2, np.abs(p - p1).max()
+    e = rel(a, a1)
+    assert np.median(e) < 1e-4, np.median(e)
+
+
+def test_dd_migration_across_ranks():
+    """a fast cold stream crossing the domain boundaries: bodies must change owner"""
+    pkg = bhpkg.load()
+    n = 32768
+    x, y, z, vx, vy, vz, m = [a.copy() for a in pkg.plummer(n, seed=3)]
+    vx += 400.0  # everything drifts 8 units per step in +x while the slabs' splitters follow
+    vx[: n // 2] -= 800.0
+    ic = (x, y, z, vx, vy, vz, m)
+    steps = 10
+    p1, v1, a1 = single(ic, steps)
+    out = run_ranks(4, ic, steps)
+    p, v, a = merge(out, n)
+    assert np.abs(p - p1).max() < 5e-2
+    e = rel(a, a1)
+    assert np.median(e) < 1e-4
