@@ -114,10 +114,19 @@ def main():
     ic = pkg.plummer(n_total, seed=args.seed)  # identical on every rank (counter-based RNG)
 
     from nbody_barnes_hut_cuda_amd import dist as bhdist
-    eng, stepper = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
-                                           force_variant=args.variant, xcd_mode=args.xcd_mode,
-                                           leaf_cap=args.leaf_cap, force_block=args.force_block)
-    eng.upload(*ic)
+    # N > 1: domain-decomposed stepping (each rank owns one Morton-key range, builds only its own
+    # octree and imports locally-essential records).  BH_DIST_MODE=replicated selects the
+    # round-1 scheme (replicated tree, sharded traversal, acc all-gather) for A/B.
+    dist_mode = os.environ.get("BH_DIST_MODE", "domain") if multi else "single"
+    if dist_mode == "domain":
+        stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
+                                       force_variant=0, xcd_mode=args.xcd_mode, force_block=args.force_block)
+        eng = stepper.e
+    else:
+        eng, stepper = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
+                                               force_variant=args.variant, xcd_mode=args.xcd_mode,
+                                               leaf_cap=args.leaf_cap, force_block=args.force_block)
+        eng.upload(*ic)
 
     def barrier():
         if dist is not None:
@@ -129,7 +138,7 @@ def main():
 
     # algorithmic bytes of one force launch on the tree the timed region starts from
     counts0 = None
-    if rank == 0:
+    if rank == 0 and not multi:
         eng.tree_stages()
         eng.force_count()
         s = eng.stats()
@@ -199,14 +208,21 @@ def main():
                             f"theta={args.theta}, G=0.5 eps2=50 dt=0.02, fp32, leaf_cap=1, 63-bit keys "
                             "(BASELINE.json configs[2]; x8 = configs[3])",
                 "n_total": n_total,
-                "parallelism": "1 GPU" if not multi else
-                               f"{world} ranks: replicated tree, Morton-slab sharded traversal, acc all-gather (RCCL)",
+                "parallelism": "1 GPU" if not multi else (
+                    f"{world} ranks, domain decomposition: per-rank octree of one Morton-key range, top tree + "
+                    "locally-essential records by 4 all-gathers per step (RCCL)" if dist_mode == "domain" else
+                    f"{world} ranks: replicated tree, Morton-slab sharded traversal, acc all-gather (RCCL)"),
                 "tree": {"cells": st.n_internal, "records": st.n_entries, "max_level": st.max_level},
             },
             "roofline": roofline,
         }
         if stages:
             out["stages"] = stages
+        if dist_mode == "domain":
+            out["config"]["domain"] = {
+                "bodies_rank0": int(stepper.n_loc), "let_records_per_rank": [int(v) for v in stepper.let_counts],
+                "let_stride": int(stepper.stride), "emigrants_last_step_max": int(stepper.mig_last),
+                "let_retries": int(stepper.let_retries), "extra_migration_rounds": int(stepper.mig_rounds)}
         assert st.status_flags == 0, st.status_flags
     if dist is not None:
         dist.barrier()

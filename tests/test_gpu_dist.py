@@ -23,9 +23,11 @@ def _free_port():
     return p
 
 
-def test_bench_distributed_path_world1():
+@pytest.mark.parametrize("mode,word", [("domain", "domain decomposition"), ("replicated", "sharded")])
+def test_bench_distributed_path_world1(mode, word):
     env = dict(os.environ)
     env["BH_FORCE_DIST"] = "1"
+    env["BH_DIST_MODE"] = mode
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -37,7 +39,26 @@ def test_bench_distributed_path_world1():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
     assert out["scaling"] == "weak" and out["config"]["n_total"] == 200000
-    assert "sharded" in out["config"]["parallelism"]
+    assert word in out["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_domain_stepper_multiprocess_one_gpu(world, tmp_path):
+    """the real multi-process flow of the domain-decomposed step (torch.distributed, one process and
+    one stream per rank) with `world` ranks sharing this one GPU over the gloo backend; rank 0
+    compares the gathered state with a single-context run (tests/dd_gpu_worker.py)"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = tmp_path / "dd.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dd_gpu_worker.py"), str(out), "60000", "6"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(out.read_text())
+    assert res["world"] == world and res["owned_once"] and res["flags"] == 0
+    assert res["max_dpos"] < 5e-2, res
+    assert res["acc_rel_median"] < 1e-4, res
 
 
 def test_sharded_stepper_equals_bh_step(pkg):
