@@ -64,9 +64,10 @@ struct bh_dd_state {
   int* piece_idx;  // [BH_DD_PIECE_CAP] pieces in body order
   int* ddi;        // [8] device scalars: 0 pieces found, 1 remote boxes, 4..6 migration results
   float4* boxes;   // [world * BH_DD_PIECE_CAP] remote piece boxes (corner, edge), margin applied
+  float4* rbox;    // [2 * world] bounding box of each remote rank's pieces + its range in boxes[]
   bh_d4* top_ps;   // [kTopMax + 1] fp64 prefix of the piece sums
-  int* top_a;      // [kTopMax]
-  int* top_b;      // [kTopMax]
+  int* top_a;      // [2 kTopMax] first piece of every top-tree child
+  int* top_b;      // [2 kTopMax] end piece of every top-tree child
   int* host;       // pinned: [world] LET counts, [world .. world+3] migration results
   hipEvent_t ev_let;
   bool let_copy_pending;
@@ -367,64 +368,133 @@ __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
 }
 
 // ------------------------------------------------------------------ X4: LET
-// dense list of the other ranks' piece boxes, grown by a margin that covers the fp32 fuzz of the
-// key quantisation (<= 0.25 key units) and of the box arithmetic
+// piece boxes of the other ranks, rank by rank, grown by a margin that covers the fp32 fuzz of the
+// key quantisation (<= 0.25 key units) and of the box arithmetic; plus each rank's bounding box.
+// One block per rank.  rbox[2q], rbox[2q+1] = min / max corner (w of the min corner = first box,
+// w of the max corner = end box of that rank).
 __global__ __launch_bounds__(256) void dd_boxes_kernel(const bh_dd_piece* __restrict__ g, int world, int me,
                                                        const float* __restrict__ bounds,
-                                                       float4* __restrict__ boxes, int* __restrict__ ddi) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= world * BH_DD_PIECE_CAP) return;
-  const int q = t / BH_DD_PIECE_CAP, k = t - q * BH_DD_PIECE_CAP;
-  if (q == me) return;
-  const int np = min(reinterpret_cast<const int*>(g + (size_t)q * kDescPerRank)[0], BH_DD_PIECE_CAP);
-  if (k >= np) return;
-  const bh_dd_piece d = g[(size_t)q * kDescPerRank + 1 + k];
+                                                       float4* __restrict__ boxes, float4* __restrict__ rbox,
+                                                       int* __restrict__ ddi) {
+  __shared__ float red[4][6];
+  __shared__ int s_off, s_np;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int r = 0; r < q; r++)
+      if (r != me) off += min(reinterpret_cast<const int*>(g + (size_t)r * kDescPerRank)[0], BH_DD_PIECE_CAP);
+    s_off = off;
+    s_np = (q == me) ? 0 : min(reinterpret_cast<const int*>(g + (size_t)q * kDescPerRank)[0], BH_DD_PIECE_CAP);
+  }
+  __syncthreads();
+  const int off = s_off, np = s_np;
   const float mg = 1e-5f * bounds[6];
-  boxes[atomicAdd(&ddi[1], 1)] = make_float4(d.bx - mg, d.by - mg, d.bz - mg, d.bs + 2.0f * mg);
+  float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+  for (int k = threadIdx.x; k < np; k += 256) {
+    const bh_dd_piece d = g[(size_t)q * kDescPerRank + 1 + k];
+    const float4 b = make_float4(d.bx - mg, d.by - mg, d.bz - mg, d.bs + 2.0f * mg);
+    boxes[off + k] = b;
+    mn[0] = fminf(mn[0], b.x); mn[1] = fminf(mn[1], b.y); mn[2] = fminf(mn[2], b.z);
+    mx[0] = fmaxf(mx[0], b.x + b.w); mx[1] = fmaxf(mx[1], b.y + b.w); mx[2] = fmaxf(mx[2], b.z + b.w);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], dd, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], dd, 64));
+    }
+    if (lane == 0) {
+      red[wv][a] = mn[a];
+      red[wv][3 + a] = mx[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int u = 1; u < 4; u++)
+      for (int a = 0; a < 3; a++) {
+        red[0][a] = fminf(red[0][a], red[u][a]);
+        red[0][3 + a] = fmaxf(red[0][3 + a], red[u][3 + a]);
+      }
+    rbox[2 * q] = make_float4(red[0][0], red[0][1], red[0][2], __int_as_float(off));
+    rbox[2 * q + 1] = make_float4(red[0][3], red[0][4], red[0][5], __int_as_float(off + np));
+    if (q == world - 1) ddi[1] = off + np;
+  }
 }
 
 // w[e] = records cell e must export = its child count when some remote body could open it:
-// min over the remote boxes of |com - box|^2 + eps2 <= (s/theta)^2, with slack on both sides
+// min over the remote boxes of |com - box|^2 + eps2 <= (s/theta)^2, with slack on both sides.
+// A cell with (s/theta)^2 < eps2 is accepted at any distance, so it is never a candidate.  Each block
+// compacts the candidates of its 1024 records in LDS and tests them densely: first against each
+// rank's bounding box, then against that rank's piece boxes.
+constexpr int kMarkChunk = 1024;
+constexpr int kMarkBoxes = 1024;  // remote boxes staged in LDS (more are read from memory)
 __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict__ frec,
                                                       const bh_devinfo* __restrict__ info, int rec_cap,
                                                       const float4* __restrict__ boxes,
+                                                      const float4* __restrict__ rbox, int world,
                                                       const int* __restrict__ ddi, float eps2,
                                                       int* __restrict__ w) {
-  __shared__ float4 sb[1024];
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float4 sb[kMarkBoxes];
+  __shared__ float4 srb[128];
+  __shared__ float4 cxyz[kMarkChunk];  // candidate: com, threshold
+  __shared__ int cidx[kMarkChunk];     // candidate: record index
+  __shared__ int ccnt[kMarkChunk];     // candidate: child count
+  __shared__ int ncand;
   const int E = min(info->n_entries, rec_cap);
   const int NB = ddi[1];
-  bool cand = false;
-  float x = 0.f, y = 0.f, z = 0.f, thr = 0.f;
-  int cnt = 0;
-  if (e < E) {
-    const bh_frec r = frec[e];
-    cand = r.thr2 >= 0.0f;
-    x = r.x; y = r.y; z = r.z;
-    thr = r.thr2 * 1.0001f;
-    cnt = r.meta & 0x7fffffff;
+  const int e0 = blockIdx.x * kMarkChunk;
+  if (threadIdx.x == 0) ncand = 0;
+  for (int i = threadIdx.x; i < 2 * world; i += 256) srb[i] = rbox[i];
+  for (int i = threadIdx.x; i < min(NB, kMarkBoxes); i += 256) sb[i] = boxes[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < kMarkChunk; i += 256) {
+    const int e = e0 + i;
+    if (e > rec_cap) break;
+    bool cand = false;
+    bh_frec r;
+    if (e < E) {
+      r = frec[e];
+      cand = r.thr2 * 1.0001f >= eps2;  // implies thr2 >= 0: an openable, massive cell
+    }
+    if (cand) {
+      const int k = atomicAdd(&ncand, 1);
+      cxyz[k] = make_float4(r.x, r.y, r.z, r.thr2 * 1.0001f);
+      cidx[k] = e;
+      ccnt[k] = r.meta & 0x7fffffff;
+    } else {
+      w[e] = 0;
+    }
   }
-  bool open = false;
-  for (int base = 0; base < NB; base += 1024) {
-    const int m = min(1024, NB - base);
-    __syncthreads();
-    for (int i = threadIdx.x; i < m; i += 256) sb[i] = boxes[base + i];
-    __syncthreads();
-    if (cand && !open) {
-      for (int i = 0; i < m; i++) {
-        const float4 b = sb[i];
-        const float dx = fmaxf(fmaxf(b.x - x, x - (b.x + b.w)), 0.0f);
-        const float dy = fmaxf(fmaxf(b.y - y, y - (b.y + b.w)), 0.0f);
-        const float dz = fmaxf(fmaxf(b.z - z, z - (b.z + b.w)), 0.0f);
-        const float d2 = (dx * dx + dy * dy + dz * dz) * 0.9999f + eps2;
-        if (d2 <= thr) {
+  __syncthreads();
+  const int nc = ncand;
+  for (int c = threadIdx.x; c < nc; c += 256) {
+    const float4 q = cxyz[c];
+    bool open = false;
+    for (int r = 0; r < world && !open; r++) {
+      const float4 lo = srb[2 * r], hi = srb[2 * r + 1];
+      const int b0 = __float_as_int(lo.w), b1 = __float_as_int(hi.w);
+      if (b1 <= b0) continue;
+      {
+        const float dx = fmaxf(fmaxf(lo.x - q.x, q.x - hi.x), 0.0f);
+        const float dy = fmaxf(fmaxf(lo.y - q.y, q.y - hi.y), 0.0f);
+        const float dz = fmaxf(fmaxf(lo.z - q.z, q.z - hi.z), 0.0f);
+        if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 > q.w) continue;  // the whole rank is too far
+      }
+      for (int i = b0; i < b1; i++) {
+        const float4 b = i < kMarkBoxes ? sb[i] : boxes[i];
+        const float dx = fmaxf(fmaxf(b.x - q.x, q.x - (b.x + b.w)), 0.0f);
+        const float dy = fmaxf(fmaxf(b.y - q.y, q.y - (b.y + b.w)), 0.0f);
+        const float dz = fmaxf(fmaxf(b.z - q.z, q.z - (b.z + b.w)), 0.0f);
+        if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 <= q.w) {
           open = true;
           break;
         }
       }
     }
+    w[cidx[c]] = open ? ccnt[c] : 0;
   }
-  if (e <= rec_cap) w[e] = (cand && open) ? cnt : 0;
 }
 
 __device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restrict__ w,
@@ -580,8 +650,8 @@ __device__ __forceinline__ bh_frec top_child(const bh_dd_piece* __restrict__ g, 
 __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restrict__ g, int world, int me,
                                                       bh_frec* __restrict__ pool, int top_base, int seg_base,
                                                       int stride, const float* __restrict__ bounds, float G,
-                                                      float theta, bh_d4* __restrict__ ps, int* __restrict__ ta,
-                                                      int* __restrict__ tb, bh_devinfo* __restrict__ info) {
+                                                      float theta, bh_d4* __restrict__ ps, int* __restrict__ cc0,
+                                                      int* __restrict__ cc1, bh_devinfo* __restrict__ info) {
   __shared__ int offs[65];
   __shared__ int tslot[kTopMax];
   __shared__ signed char d[kTopMax + 1];
@@ -590,11 +660,14 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
   __shared__ int wsum[16];
   __shared__ bh_d4 wsum4[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < world)
+    offs[tid + 1] = min(reinterpret_cast<const int*>(g + (size_t)tid * kDescPerRank)[0], BH_DD_PIECE_CAP);
+  __syncthreads();
   if (tid == 0) {
     int o = 0;
     offs[0] = 0;
     for (int q = 0; q < world; q++) {
-      o += min(reinterpret_cast<const int*>(g + (size_t)q * kDescPerRank)[0], BH_DD_PIECE_CAP);
+      o += offs[q + 1];
       offs[q + 1] = o;
     }
     if (o > kTopMax) atomicOr(&info->flags, BH_FLAG_DD_PIECES);
@@ -648,45 +721,60 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
   }
   __syncthreads();
   // cells: pair j at level L = d[j] names the cell [a, b); representative = its first boundary
-  for (int j = tid; j < T; j += 1024) {
+  int ra[kTopMax / 1024], rb[kTopMax / 1024];
+#pragma unroll
+  for (int r = 0; r < kTopMax / 1024; r++) {
+    const int j = tid + r * 1024;
     int nc = 0;
-    if (j >= 1) {
+    ra[r] = rb[r] = 0;
+    if (j >= 1 && j < T) {
       const int L = d[j];
       int i = j - 1;
       while (d[i] > L) i--;
       if (d[i] < L) {  // no earlier boundary of the same level inside the cell
-        const int a = i;
+        ra[r] = i;
         nc = 2;
         i = j + 1;
         while (d[i] >= L) {
           if (d[i] == L) nc++;
           i++;
         }
-        ta[j] = a;
-        tb[j] = i;
+        rb[r] = i;
       }
     }
-    pn[j] = nc;
+    if (j < T) {
+      pn[j] = nc;
+      cb[j] = nc;
+    }
   }
   __syncthreads();
-  for (int j = tid; j < T; j += 1024) cb[j] = pn[j];
-  __syncthreads();
-  (void)top_scan_i32(cb, T, wsum);
-  const float s0 = bounds[6];
-  if (tid == 0)
-    pool[top_base] = top_child(g, tslot, d, pn, cb, ps, 0, T, me, pool, top_base, seg_base, stride, s0, G, theta);
-  for (int j = tid; j < T; j += 1024) {
-    if (pn[j] == 0) continue;
-    const int L = d[j], b = tb[j];
-    int e = top_base + 1 + cb[j];
-    int c0 = ta[j], c1 = j;
+  const int nchild = top_scan_i32(cb, T, wsum);
+  // every representative lists the piece ranges of its children; then ONE THREAD PER CHILD builds the
+  // record, so the dependent global loads (descriptor -> piece record) of all children overlap
+#pragma unroll
+  for (int r = 0; r < kTopMax / 1024; r++) {
+    const int j = tid + r * 1024;
+    if (j >= T || pn[j] == 0) continue;
+    const int L = d[j], b = rb[r];
+    int e = cb[j];
+    int c0 = ra[r], c1 = j;
     for (;;) {
-      pool[e++] = top_child(g, tslot, d, pn, cb, ps, c0, c1, me, pool, top_base, seg_base, stride, s0, G, theta);
+      cc0[e] = c0;
+      cc1[e] = c1;
+      e++;
       if (c1 >= b) break;
       c0 = c1;
       c1 = c0 + 1;
       while (c1 < b && d[c1] != L) c1++;
     }
+  }
+  __syncthreads();
+  const float s0 = bounds[6];
+  for (int e = tid; e <= nchild; e += 1024) {  // record 0 = the root, record 1 + k = child k
+    const int c0 = e == 0 ? 0 : cc0[e - 1];
+    const int c1 = e == 0 ? T : cc1[e - 1];
+    pool[top_base + e] =
+        top_child(g, tslot, d, pn, cb, ps, c0, c1, me, pool, top_base, seg_base, stride, s0, G, theta);
   }
 }
 
@@ -722,7 +810,7 @@ void bh_dd_free(bh_ctx* c) {
   bh_dd_state* d = c->dd;
   if (!d) return;
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
-                  d->piece_idx, d->ddi, d->boxes, d->top_ps, d->top_a, d->top_b};
+                  d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->host) (void)hipHostFree(d->host);
@@ -788,9 +876,10 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->piece_idx, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->ddi, 8 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->boxes, (size_t)world * BH_DD_PIECE_CAP * sizeof(float4)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->rbox, (size_t)2 * 64 * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->top_ps, ((size_t)kTopMax + 1) * sizeof(bh_d4)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_a, (size_t)kTopMax * 4) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_b, (size_t)kTopMax * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_a, ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_b, ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_let, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -936,10 +1025,11 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
   bh_dd_state* d = c->dd;
   if (stride < 1 + BH_DD_PIECE_CAP || stride > d->let_cap) return BH_ERR_BAD_ARG;
   BH_HIP(c, hipMemsetAsync(d->ddi + 1, 0, 4, c->stream));
-  dd_boxes_kernel<<<(d->world * BH_DD_PIECE_CAP + 255) / 256, 256, 0, c->stream>>>(
-      (const bh_dd_piece*)gathered_x3, d->world, d->rank, c->bounds, d->boxes, d->ddi);
+  dd_boxes_kernel<<<d->world, 256, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, c->bounds,
+                                                   d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;
-  dd_mark_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->info, c->rec_cap, d->boxes, d->ddi, c->p.eps2, d->w);
+  dd_mark_kernel<<<(c->rec_cap + kMarkChunk) / kMarkChunk, 256, 0, c->stream>>>(
+      c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w);
   BH_HIP(c, hipGetLastError());
   BH_HIP(c, bhk_scan_i32(c, d->w, d->dst, c->rec_cap, nullptr));
   dd_export_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->posm[c->cur], c->rec_cap, d->w, d->dst,

@@ -63,3 +63,13 @@ def test_sharded_step_equals_single_rank(orc, tmp_path, world):
     o.upload(*pkg.plummer(n, seed=42))
     o.step(steps, order=orc.ORDER_PREORDER)
     assert np.array_equal(np.stack(o.download(), 1), ref["state"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_torchcomm_all_gather(world):
+    """the all-gather wrapper of the domain-decomposed stepper on sliced byte buffers (gloo)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "comm_worker.py")]
+    r = subprocess.run(cmd, timeout=300, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]

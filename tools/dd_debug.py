@@ -54,6 +54,8 @@ def main():
                 flags = st.e.stats().status_flags
                 group.barrier.wait()
                 if r == 0:
+                    hdr = st.x3r.cpu().numpy().view(np.int32).reshape(P, -1)[:, 0]
+                    log(f"   pieces per rank {hdr.tolist()}")
                     log(f"step {s}: n_loc={[x.n_loc for x in steppers]} stride={st.stride} "
                         f"let={st.let_counts.tolist()} retries={st.let_retries} emig={st.mig_last} "
                         f"mig_rounds={st.mig_rounds} flags={flags} "
