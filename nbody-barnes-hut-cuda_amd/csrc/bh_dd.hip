@@ -835,7 +835,7 @@ int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) 
   o->pool_records = o->seg_base + (long long)world * let_cap + 8;
   o->let_min = let_min;
   o->let_cap = let_cap;
-  if (o->pool_records >= (1LL << 31)) return BH_ERR_BAD_ARG;
+  if (o->pool_records >= (1LL << 27)) return BH_ERR_BAD_ARG;  // fast kernel: 32-bit byte offsets
   return BH_OK;
 }
 

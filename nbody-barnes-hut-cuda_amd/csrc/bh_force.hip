@@ -25,6 +25,8 @@
 //     a few back-to-back scalar loads and up to 8 independent MAC evaluations (ILP);
 //   * blockIdx is remapped so that each XCD walks a contiguous slab of the Morton order and
 //     its private L2 keeps that slab's part of the tree.
+#include <stdlib.h>
+
 #include "bh_internal.h"
 
 namespace {
@@ -88,11 +90,12 @@ __device__ __forceinline__ void writelane4(int& f, int& c, int& l, int& h, int l
       : "m0");
 }
 
+template <int SETS = 3>
 __device__ __forceinline__ void ws_push(WaveStack& s, int sp, int first, int count, u64 mask) {
   const int ln = sp & 63;
   const int lo = (int)(u32)mask, hi = (int)(u32)(mask >> 32);
   const int set = sp >> 6;
-  if (set == 0)
+  if (SETS == 1 || set == 0)
     writelane4(s.f0, s.c0, s.l0, s.h0, ln, first, count, lo, hi);
   else if (set == 1)
     writelane4(s.f1, s.c1, s.l1, s.h1, ln, first, count, lo, hi);
@@ -100,11 +103,12 @@ __device__ __forceinline__ void ws_push(WaveStack& s, int sp, int first, int cou
     writelane4(s.f2, s.c2, s.l2, s.h2, ln, first, count, lo, hi);
 }
 
+template <int SETS = 3>
 __device__ __forceinline__ void ws_pop(const WaveStack& s, int sp, int& first, int& count, u64& mask) {
   const int ln = sp & 63;
   const int set = sp >> 6;
   int lo, hi;
-  if (set == 0) {
+  if (SETS == 1 || set == 0) {
     first = __builtin_amdgcn_readlane(s.f0, ln);
     count = __builtin_amdgcn_readlane(s.c0, ln);
     lo = __builtin_amdgcn_readlane(s.l0, ln);
@@ -284,6 +288,24 @@ __device__ __forceinline__ FRec load_frec(cfloat_t* base, int e) {
   return r;
 }
 
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(4))) const float16_t cfloat16_t;
+
+// two consecutive records with one s_load_dwordx16
+typedef __attribute__((address_space(4))) const char cchar_t;
+__device__ __forceinline__ void load_frec2(cfloat_t* base, int e, FRec& a, FRec& b) {
+  // 32-bit unsigned byte offset: selects the SGPR-offset form of s_load (no 64-bit address
+  // arithmetic per block); the launcher guarantees pool bytes < 4 GiB for this kernel
+  const u32 off = (u32)e << 5;
+  const float16_t v = *(cfloat16_t*)((cchar_t*)base + off);
+  a.x = v[0]; a.y = v[1]; a.z = v[2]; a.gm = v[3]; a.thr2 = v[4];
+  a.first = __float_as_int(v[5]);
+  a.meta = __float_as_int(v[6]);
+  b.x = v[8]; b.y = v[9]; b.z = v[10]; b.gm = v[11]; b.thr2 = v[12];
+  b.first = __float_as_int(v[13]);
+  b.meta = __float_as_int(v[14]);
+}
+
 #define BH_FAST_EVAL(R)                                                                  \
   {                                                                                      \
     const float dx = (R).x - px, dy = (R).y - py, dz = (R).z - pz;                       \
@@ -298,10 +320,11 @@ __device__ __forceinline__ FRec load_frec(cfloat_t* base, int e) {
     az = fmaf(fm, dz, az);                                                               \
     if (openm != 0ull) {                                                                 \
       if ((R).meta >= 0) {                                                               \
-        if (sp < kStackCap) {                                                            \
-          ws_push(st, sp++, (R).first, (R).meta, openm);                                 \
-        } else if (lane == 0) {                                                          \
-          atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);                                \
+        if (sp < 64 * SETS) {                                                            \
+          ws_push<SETS>(st, sp++, (R).first, (R).meta, openm);                           \
+        } else {                                                                         \
+          overflow = true; /* the caller redoes this wave with the large stack */        \
+          sp = 0;          /* drain quickly: the loop tests sp only */                   \
         }                                                                                \
       } else {                                                                           \
         const int b0 = (R).first, b1 = b0 + ((R).meta & 0x7fffffff);                     \
@@ -320,6 +343,41 @@ __device__ __forceinline__ FRec load_frec(cfloat_t* base, int e) {
       }                                                                                  \
     }                                                                                    \
   }
+
+// One wave's traversal from record `root` for the lanes of m0; returns false if the cross-lane stack
+// (64 * SETS entries) overflowed, in which case ax..az are incomplete.
+template <int SETS>
+__device__ __forceinline__ bool fast_traverse(cfloat_t* frec, cfloat_t* bodies, int root, u64 m0, float px,
+                                              float py, float pz, float Gv, float eps2, float& ax, float& ay,
+                                              float& az) {
+  WaveStack st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int sp = 0;
+  bool overflow = false;
+  ws_push<SETS>(st, sp++, root, 1, m0);  // ref:198 stack = {root}
+  while (sp > 0) {
+    int first, count;
+    u64 mask;
+    ws_pop<SETS>(st, --sp, first, count, mask);
+    int k0 = 0;
+    do {  // count >= 1 for every stack entry
+      // the record pool is padded, so reading up to 3 records past the block is safe
+      FRec r0, r1, r2, r3;
+      load_frec2(frec, first + k0, r0, r1);
+      load_frec2(frec, first + k0 + 2, r2, r3);
+      const int nk = count - k0;
+      BH_FAST_EVAL(r0);
+      if (nk > 1) {
+        BH_FAST_EVAL(r1);
+        if (nk > 2) {
+          BH_FAST_EVAL(r2);
+          if (nk > 3) BH_FAST_EVAL(r3);
+        }
+      }
+      k0 += 4;
+    } while (k0 < count);
+  }
+  return !overflow;
+}
 
 __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict__ frec_g,
                                                          const float4* __restrict__ posm,
@@ -341,42 +399,14 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
     px = p.x; py = p.y; pz = p.z;
   }
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
-  const float Gv = G;
   const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
   if (m0 == 0) return;
-
-  WaveStack st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int sp = 0;
-  ws_push(st, sp++, root, 1, m0);  // ref:198 stack = {root}
-
-  // a well-formed tree needs ~10^3 pops per wave; the budget only bounds the walk over a malformed
-  // pool (a wave that never finishes can take the whole GPU down)
-  int budget = 1 << 22;
-  while (sp > 0) {
-    int first, count;
-    u64 mask;
-    ws_pop(st, --sp, first, count, mask);
-    budget -= 1 + (count >> 2);
-    if (budget < 0 || count < 0) {
-      if (lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
-      break;
-    }
-    for (int k0 = 0; k0 < count; k0 += 4) {
-      // the record pool is padded, so reading up to 3 records past the block is safe
-      const FRec r0 = load_frec(frec, first + k0 + 0);
-      const FRec r1 = load_frec(frec, first + k0 + 1);
-      const FRec r2 = load_frec(frec, first + k0 + 2);
-      const FRec r3 = load_frec(frec, first + k0 + 3);
-      const int nk = count - k0;
-      BH_FAST_EVAL(r0);
-      if (nk > 1) {
-        BH_FAST_EVAL(r1);
-        if (nk > 2) {
-          BH_FAST_EVAL(r2);
-          if (nk > 3) BH_FAST_EVAL(r3);
-        }
-      }
-    }
+  // 64 stack entries (one VGPR set, no set-select branches) cover every tree seen in practice; the
+  // rare wave that needs more redoes its walk with the 192-entry stack (>= the 7*21+1 bound)
+  if (!fast_traverse<1>(frec, bodies, root, m0, px, py, pz, G, eps2, ax, ay, az)) {
+    ax = ay = az = 0.0f;
+    if (!fast_traverse<3>(frec, bodies, root, m0, px, py, pz, G, eps2, ax, ay, az) && lane == 0)
+      atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
   }
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
 }
@@ -688,6 +718,12 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       const int mode = c->p.xcd_mode;
       int grid = blocks;
       if (mode == 2) grid = (blocks + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+      if (c->rec_cap >= (1 << 27)) {
+        // the fast kernels address records with 32-bit byte offsets (pool < 4 GiB = 64M bodies):
+        // beyond that the generic kernel does the same arithmetic on the canonical records
+        force_kernel<false, false><<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, th, e2, nullptr, nullptr, nullptr, c->info);
+        return hipGetLastError();
+      }
       if (c->p.force_variant == 3 && c->rec_cap < (1 << 28))
         return bhk_force_fast(c, lo, hi);  // bh_force_fast.hip (scalar overhead trimmed; measured 4 % slower)
       if (c->p.force_variant != 1 || c->rec_cap >= (1 << 28)) {
