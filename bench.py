@@ -118,22 +118,38 @@ def main():
     # octree and imports locally-essential records).  BH_DIST_MODE=replicated selects the
     # round-1 scheme (replicated tree, sharded traversal, acc all-gather) for A/B.
     dist_mode = os.environ.get("BH_DIST_MODE", "domain") if multi else "single"
-    if dist_mode == "domain":
-        stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
-                                       force_variant=0, xcd_mode=args.xcd_mode, force_block=args.force_block)
-        eng = stepper.e
-    else:
-        eng, stepper = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
-                                               force_variant=args.variant, xcd_mode=args.xcd_mode,
-                                               leaf_cap=args.leaf_cap, force_block=args.force_block)
-        eng.upload(*ic)
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    stepper.step(args.warmup)
+    def replicated():
+        e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
+                                        force_variant=args.variant, xcd_mode=args.xcd_mode,
+                                        leaf_cap=args.leaf_cap, force_block=args.force_block)
+        e.upload(*ic)
+        return e, st
+
+    fallback_reason = None
+    if dist_mode == "domain":
+        # A failure every rank hits alike (the size negotiations are functions of all-gathered data, so
+        # capacity errors are) drops all ranks to the replicated scheme together instead of losing the run.
+        try:
+            stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
+                                           force_variant=0, xcd_mode=args.xcd_mode,
+                                           force_block=args.force_block)
+            eng = stepper.e
+            stepper.step(args.warmup)
+        except Exception as ex:  # noqa: BLE001
+            fallback_reason = repr(ex)
+            print(f"[bench rank {rank}] domain-decomposed stepping failed ({fallback_reason}); "
+                  "falling back to the replicated scheme", file=sys.stderr, flush=True)
+            dist_mode = "replicated"
+            eng, stepper = replicated()
+            stepper.step(args.warmup)
+    else:
+        eng, stepper = replicated()
+        stepper.step(args.warmup)
     barrier()
 
     # algorithmic bytes of one force launch on the tree the timed region starts from
@@ -218,6 +234,8 @@ def main():
         }
         if stages:
             out["stages"] = stages
+        if fallback_reason:
+            out["config"]["domain_fallback"] = fallback_reason
         if dist_mode == "domain":
             out["config"]["domain"] = {
                 "bodies_rank0": int(stepper.n_loc), "let_records_per_rank": [int(v) for v in stepper.let_counts],
