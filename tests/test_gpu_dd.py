@@ -122,3 +122,41 @@ def test_dd_migration_across_ranks():
     assert np.abs(p - p1).max() < 5e-2
     e = rel(a, a1)
     assert np.median(e) < 1e-4
+
+
+def _check(ic, world, steps, tol_pos=5e-2, tol_med=1e-4):
+    n = len(ic[0])
+    p1, v1, a1 = single(ic, steps)
+    out = run_ranks(world, ic, steps)
+    p, v, a = merge(out, n)
+    assert np.abs(p - p1).max() < tol_pos, np.abs(p - p1).max()
+    e = rel(a, a1)
+    assert np.median(e) < tol_med, np.median(e)
+    return e
+
+
+def test_dd_disc_initial_conditions():
+    """the reference's thin rotating disc (ref:297-307): strongly anisotropic domains"""
+    pkg = bhpkg.load()
+    _check(pkg.disc(50000, seed=5), 4, 5)
+
+
+def test_dd_coincident_bodies_and_zero_masses():
+    """bodies at identical positions form unsplit multi-body cells (exported as blocks of body
+    records), zero-mass bodies form records every traversal skips; both must survive the LET path"""
+    pkg = bhpkg.load()
+    n = 30000
+    x, y, z, vx, vy, vz, m = [a.copy() for a in pkg.plummer(n, seed=9)]
+    for lo, cnt in ((1000, 40), (17000, 150)):       # two clumps of identical positions
+        x[lo:lo + cnt] = x[lo]
+        y[lo:lo + cnt] = y[lo]
+        z[lo:lo + cnt] = z[lo]
+        vx[lo:lo + cnt] = vy[lo:lo + cnt] = vz[lo:lo + cnt] = 0.0
+    m[5000:5200] = 0.0
+    e = _check((x, y, z, vx, vy, vz, m), 3, 3)
+    assert e.max() < 5e-3, e.max()
+
+
+def test_dd_small_system_many_ranks():
+    pkg = bhpkg.load()
+    _check(pkg.plummer(8 * 1500, seed=2), 8, 4)
