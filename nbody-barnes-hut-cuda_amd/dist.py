@@ -207,11 +207,22 @@ class DomainStepper:
                 c.all_gather(self.x1r, self.x1s)
                 e.dd_cube_apply(self.x1r.data_ptr())
                 limit, first = self.mig_stride, None                   # X2: bodies that changed owner
-                while True:
+                failed = None   # a rank-local failure must not strand the others inside a collective: the
+                while True:     # failing rank keeps taking part with empty payloads and marks its LET segment
                     nb = 32 + 32 * limit
-                    e.dd_migrate_pack(self.x2s.data_ptr(), limit)
+                    if failed is None:
+                        e.dd_migrate_pack(self.x2s.data_ptr(), limit)
+                    else:
+                        self.x2s[:32].zero_()
                     c.all_gather(self.x2r[:P * nb], self.x2s[:nb])
-                    self.n_loc, more, most = e.dd_migrate_apply(self.x2r.data_ptr(), limit)
+                    if failed is None:
+                        try:
+                            self.n_loc, more, most = e.dd_migrate_apply(self.x2r.data_ptr(), limit)
+                        except Exception as ex:  # noqa: BLE001 - e.g. more bodies than this context can hold
+                            failed = ex
+                    if failed is not None:
+                        h = self.x2r[:P * nb].view(P, nb)[:, :16].contiguous().view(torch.int32).cpu().view(P, 4)
+                        more, most = bool(((h[:, 0] - h[:, 2]) > 0).any()), int(h[:, 0].max())
                     first = most if first is None else first
                     if not more:
                         break
@@ -219,17 +230,27 @@ class DomainStepper:
                     limit = min(self.mig_cap, max(limit, _round_up(most, 256)))
                 self.mig_last = first
                 self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 1.5 + 2048, 256)))
-                e.dd_tree(self.x3s.data_ptr())                         # local sort/build/COM; X3: pieces
+                if failed is None:
+                    e.dd_tree(self.x3s.data_ptr())                     # local sort/build/COM; X3: pieces
+                else:
+                    self.x3s.zero_()
                 c.all_gather(self.x3r, self.x3s)
                 while True:
                     stride = self.stride
-                    e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
                     seg = self.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32]
+                    if failed is not None:
+                        self.lets[:stride * 32].zero_()
+                        self.lets[:32].view(torch.int32)[5] = -1        # header count < 0: "this rank failed"
+                        c.all_gather(seg, self.lets[:stride * 32])
+                        raise RuntimeError(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
+                    e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
                     c.all_gather(seg, self.lets[:stride * 32])          # X4: LET records, in place
                     e.dd_top(self.x3r.data_ptr(), stride)
                     e.dd_force()
                     ok, counts = e.dd_let_check(stride, P)
                     self.let_counts = counts
+                    if int(counts.min()) < 0:
+                        raise RuntimeError(f"rank {int(counts.argmin())} left the domain-decomposed step")
                     need = int(counts.max())
                     if ok:
                         break

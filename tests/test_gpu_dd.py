@@ -160,3 +160,14 @@ def test_dd_coincident_bodies_and_zero_masses():
 def test_dd_small_system_many_ranks():
     pkg = bhpkg.load()
     _check(pkg.plummer(8 * 1500, seed=2), 8, 4)
+
+
+def test_dd_rank_failure_is_collective():
+    """a rank whose context cannot hold its bodies after migration must not strand the other ranks in
+    an all-gather: it keeps exchanging empty payloads, marks its LET segment, and every rank raises"""
+    pkg = bhpkg.load()
+    n = 200000
+    ic = pkg.plummer(n, seed=4)
+    with pytest.raises(Exception) as ei:
+        run_ranks(4, ic, 6, slack=0.92)   # capacity 50,096 bodies per rank for ~50,000 +- 1 %
+    assert "left the domain-decomposed step" in str(ei.value) or "overflow" in str(ei.value)
