@@ -183,6 +183,7 @@ int bh_n(const bh_ctx* c);
  *   bh_dd_cube_pack      -> all-gather X1 -> bh_dd_cube_apply      global cube (exact) + splitters
  *   bh_dd_migrate_pack   -> all-gather X2 -> bh_dd_migrate_apply   bodies that left the key range
  *   bh_dd_tree           -> all-gather X3                          local octree; piece descriptors
+ *   bh_dd_force_local (optional: own pieces, side stream, overlaps the next two lines)
  *   bh_dd_let_pack       -> all-gather X4 (into the record pool)   locally-essential records
  *   bh_dd_top, bh_dd_force, bh_dd_let_check, bh_integrate
  *
@@ -233,6 +234,12 @@ int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_lo
 int bh_dd_tree(bh_ctx* c, void* send_x3);
 /* stride = records per LET segment in this step's X4 (let_min <= stride <= let_cap) */
 int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride);
+/* optional, right after the X3 all-gather: walk the rank's OWN pieces on a side stream while the LET
+   marking, export and the X4 all-gather run on the main stream.  bh_dd_top / bh_dd_force then cover
+   only the other ranks' pieces and bh_integrate adds the two partial accelerations.  The split is
+   exact: both passes apply the same MAC to the same cells, a top cell accepted as a whole contributes
+   each pass's share of its mass at the cell's centre. */
+int bh_dd_force_local(bh_ctx* c, const void* gathered_x3);
 int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride);
 int bh_dd_force(bh_ctx* c);
 /* synchronises up to the end of X4 only; counts[world] = records each rank needed.  Returns

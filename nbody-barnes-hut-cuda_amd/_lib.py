@@ -104,6 +104,7 @@ SYMBOLS = [
     ("bh_dd_migrate_apply", C.c_int, [_P, _P, C.c_int] + [C.POINTER(C.c_int)] * 3),
     ("bh_dd_tree", C.c_int, [_P, _P]),
     ("bh_dd_let_pack", C.c_int, [_P, _P, _P, C.c_int]),
+    ("bh_dd_force_local", C.c_int, [_P, _P]),
     ("bh_dd_top", C.c_int, [_P, _P, C.c_int]),
     ("bh_dd_force", C.c_int, [_P]),
     ("bh_dd_let_check", C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),

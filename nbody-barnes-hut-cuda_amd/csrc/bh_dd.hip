@@ -46,13 +46,18 @@ struct bh_dd_piece {  // X3 descriptor, 80 B
 };
 static_assert(sizeof(bh_dd_piece) == 80, "descriptor layout");
 
+// piece sums of the top tree: (m, m x, m y, m z) of all bodies and o = the mass owned by this rank
+struct top5 {
+  double m, x, y, z, o;
+};
+
 struct bh_dd_state {
   int world, rank;
   long long n_total;
   int mig_cap, let_cap;
   bh_frec* pool;
   long long pool_records;
-  int top_base, seg_base;
+  int top_base, top_base2, seg_base;  // top tree of the remote pass (or the whole tree) / of the own pass
   int* w;          // [rec_cap + 1] records a cell exports (0: not needed by any other rank)
   int* dst;        // [rec_cap + 1] exclusive scan of w
   int* flag;       // [max(n_cap, world*mig_cap) + 1]
@@ -65,9 +70,12 @@ struct bh_dd_state {
   int* ddi;        // [8] device scalars: 0 pieces found, 1 remote boxes, 4..6 migration results
   float4* boxes;   // [world * BH_DD_PIECE_CAP] remote piece boxes (corner, edge), margin applied
   float4* rbox;    // [2 * world] bounding box of each remote rank's pieces + its range in boxes[]
-  bh_d4* top_ps;   // [kTopMax + 1] fp64 prefix of the piece sums
+  top5* top_ps;    // [2][kTopMax + 1] fp64 prefix of the piece sums (one per pass: the passes overlap)
   int* top_a;      // [2 kTopMax] first piece of every top-tree child
   int* top_b;      // [2 kTopMax] end piece of every top-tree child
+  float4* acc2;    // [n_cap] accelerations of the remote pass (the own pass writes the context's acc)
+  hipEvent_t ev_x3, ev_own;
+  bool split;      // two-pass force: own pieces while X4 is in flight, remote pieces after it
   int* host;       // pinned: [world] LET counts, [world .. world+3] migration results
   hipEvent_t ev_let;
   bool let_copy_pending;
@@ -596,14 +604,29 @@ __device__ __forceinline__ int top_scan_i32(int* v /* LDS [kTopMax+1] */, int T,
   return tot;
 }
 
-__device__ __forceinline__ bh_d4 d4_add(bh_d4 a, bh_d4 b) { return bh_d4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ bh_d4 d4_shfl_up(bh_d4 v, int d) {
-  return bh_d4{__shfl_up(v.m, d, 64), __shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64)};
+__device__ __forceinline__ top5 t5_add(top5 a, top5 b) {
+  return top5{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z, a.o + b.o};
+}
+__device__ __forceinline__ top5 t5_shfl_up(top5 v, int d) {
+  return top5{__shfl_up(v.m, d, 64), __shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64),
+              __shfl_up(v.o, d, 64)};
 }
 
+// side 0: every piece; side 1: only this rank's pieces, the others become null records (zero force,
+// never opened); side 2: the reverse
 __device__ __forceinline__ bh_frec top_piece_record(const bh_dd_piece* __restrict__ g, int slot, int me,
-                                                    const bh_frec* __restrict__ pool, int seg_base, int stride) {
+                                                    const bh_frec* __restrict__ pool, int seg_base, int stride,
+                                                    int side) {
   const bh_dd_piece d = g[slot];
+  if ((side == 1 && d.owner != me) || (side == 2 && d.owner == me)) {
+    bh_frec z;
+    z.x = z.y = z.z = z.gm = 0.0f;
+    z.thr2 = -1.0f;
+    z.first = 0;
+    z.meta = 1;
+    z.pad = 0;
+    return z;
+  }
   if (d.owner == me) return pool[d.rec_idx];
   const int k = slot - d.owner * kDescPerRank - 1;
   return pool[(size_t)seg_base + (size_t)d.owner * stride + 1 + k];
@@ -613,17 +636,17 @@ __device__ __forceinline__ bh_frec top_piece_record(const bh_dd_piece* __restric
 // first lowest boundary strictly inside the range
 __device__ __forceinline__ bh_frec top_child(const bh_dd_piece* __restrict__ g, const int* tslot,
                                              const signed char* d, const int* pn, const int* cb,
-                                             const bh_d4* __restrict__ ps, int c0, int c1, int me,
+                                             const top5* __restrict__ ps, int c0, int c1, int me,
                                              const bh_frec* __restrict__ pool, int top_base, int seg_base,
-                                             int stride, float s0, float G, float theta) {
-  if (c1 - c0 == 1) return top_piece_record(g, tslot[c0], me, pool, seg_base, stride);
+                                             int stride, float s0, float G, float theta, int side) {
+  if (c1 - c0 == 1) return top_piece_record(g, tslot[c0], me, pool, seg_base, stride, side);
   int l = c0 + 1, Lb = d[c0 + 1];
   for (int i = c0 + 2; i < c1; i++)
     if (d[i] < Lb) {
       Lb = d[i];
       l = i;
     }
-  const bh_d4 p1 = ps[c1], p0 = ps[c0];
+  const top5 p1 = ps[c1], p0 = ps[c0];
   const double M = p1.m - p0.m;
   const double sx = p1.x - p0.x, sy = p1.y - p0.y, sz = p1.z - p0.z;
   bh_frec fr;
@@ -634,7 +657,11 @@ __device__ __forceinline__ bh_frec top_child(const bh_dd_piece* __restrict__ g, 
     fr.x = (float)sx; fr.y = (float)sy; fr.z = (float)sz;
   }
   const bool massive = mass > 0.0f;
-  fr.gm = massive ? G * mass : 0.0f;
+  // the MAC sees the whole cell (position, size); in the two-pass split an accepted cell contributes
+  // the monopole of this pass's share of its mass at the same centre, so the two passes add up to it
+  const double Mo = p1.o - p0.o;
+  const float share = side == 0 ? mass : (float)(side == 1 ? Mo : M - Mo);
+  fr.gm = (massive && share > 0.0f) ? G * share : 0.0f;
   if (massive) {
     const float t = ldexpf(s0, -Lb) / theta;
     fr.thr2 = t * t;
@@ -650,15 +677,16 @@ __device__ __forceinline__ bh_frec top_child(const bh_dd_piece* __restrict__ g, 
 __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restrict__ g, int world, int me,
                                                       bh_frec* __restrict__ pool, int top_base, int seg_base,
                                                       int stride, const float* __restrict__ bounds, float G,
-                                                      float theta, bh_d4* __restrict__ ps, int* __restrict__ cc0,
-                                                      int* __restrict__ cc1, bh_devinfo* __restrict__ info) {
+                                                      float theta, top5* __restrict__ ps, int* __restrict__ cc0,
+                                                      int* __restrict__ cc1, bh_devinfo* __restrict__ info,
+                                                      int side) {
   __shared__ int offs[65];
   __shared__ int tslot[kTopMax];
   __shared__ signed char d[kTopMax + 1];
   __shared__ int pn[kTopMax + 1];
   __shared__ int cb[kTopMax + 1];
   __shared__ int wsum[16];
-  __shared__ bh_d4 wsum4[16];
+  __shared__ top5 wsum4[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid < world)
     offs[tid + 1] = min(reinterpret_cast<const int*>(g + (size_t)tid * kDescPerRank)[0], BH_DD_PIECE_CAP);
@@ -686,36 +714,37 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
                               : (signed char)common_digits(g[tslot[t - 1]].key, g[tslot[t]].key, kB);
   // fp64 exclusive prefix of the piece sums (fixed association: identical on every rank)
   {
-    bh_d4 x[4], s = bh_d4{0.0, 0.0, 0.0, 0.0};
+    const top5 zero = top5{0.0, 0.0, 0.0, 0.0, 0.0};
+    top5 x[4], s = zero;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int t = 4 * tid + i;
       if (t < T) {
         const bh_dd_piece p = g[tslot[t]];
-        x[i] = bh_d4{p.sm, p.sx, p.sy, p.sz};
+        x[i] = top5{p.sm, p.sx, p.sy, p.sz, p.owner == me ? p.sm : 0.0};
       } else {
-        x[i] = bh_d4{0.0, 0.0, 0.0, 0.0};
+        x[i] = zero;
       }
-      s = d4_add(s, x[i]);
+      s = t5_add(s, x[i]);
     }
-    bh_d4 inc = s;
+    top5 inc = s;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
-      const bh_d4 u = d4_shfl_up(inc, dd);
-      if (lane >= dd) inc = d4_add(u, inc);
+      const top5 u = t5_shfl_up(inc, dd);
+      if (lane >= dd) inc = t5_add(u, inc);
     }
     if (lane == 63) wsum4[wv] = inc;
     __syncthreads();
-    bh_d4 pre = bh_d4{0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < wv; i++) pre = d4_add(pre, wsum4[i]);
-    bh_d4 excl = d4_shfl_up(inc, 1);
-    if (lane == 0) excl = bh_d4{0.0, 0.0, 0.0, 0.0};
-    bh_d4 run = d4_add(pre, excl);
+    top5 pre = zero;
+    for (int i = 0; i < wv; i++) pre = t5_add(pre, wsum4[i]);
+    top5 excl = t5_shfl_up(inc, 1);
+    if (lane == 0) excl = zero;
+    top5 run = t5_add(pre, excl);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int t = 4 * tid + i;
       if (t < T) ps[t] = run;
-      run = d4_add(run, x[i]);
+      run = t5_add(run, x[i]);
       if (t == T - 1) ps[T] = run;
     }
   }
@@ -774,7 +803,7 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
     const int c0 = e == 0 ? 0 : cc0[e - 1];
     const int c1 = e == 0 ? T : cc1[e - 1];
     pool[top_base + e] =
-        top_child(g, tslot, d, pn, cb, ps, c0, c1, me, pool, top_base, seg_base, stride, s0, G, theta);
+        top_child(g, tslot, d, pn, cb, ps, c0, c1, me, pool, top_base, seg_base, stride, s0, G, theta, side);
   }
 }
 
@@ -810,11 +839,14 @@ void bh_dd_free(bh_ctx* c) {
   bh_dd_state* d = c->dd;
   if (!d) return;
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
-                  d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b};
+                  d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->acc2};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->host) (void)hipHostFree(d->host);
   if (d->ev_let) (void)hipEventDestroy(d->ev_let);
+  if (d->ev_x3) (void)hipEventDestroy(d->ev_x3);
+  if (d->ev_own) (void)hipEventDestroy(d->ev_own);
+  c->acc2 = nullptr;
   free(d);
   c->dd = nullptr;
 }
@@ -831,7 +863,7 @@ int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) 
   o->x2_bytes = 32 + 32LL * mig_cap;
   o->x3_bytes = (int64_t)sizeof(bh_dd_piece) * kDescPerRank;
   o->top_base = rec_cap;
-  o->seg_base = rec_cap + top_cap;
+  o->seg_base = rec_cap + 2 * top_cap;  // two top trees: remote pass (or the whole tree), own pass
   o->pool_records = o->seg_base + (long long)world * let_cap + 8;
   o->let_min = let_min;
   o->let_cap = let_cap;
@@ -862,6 +894,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   d->pool = (bh_frec*)pool;
   d->pool_records = pool_records;
   d->top_base = (int)sz.top_base;
+  d->top_base2 = (int)sz.top_base + 2 * kTopMax + 8;
   d->seg_base = (int)sz.seg_base;
   size_t fl = (size_t)n_cap;
   if ((size_t)world * mig_cap > fl) fl = (size_t)world * mig_cap;
@@ -877,9 +910,12 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->ddi, 8 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->boxes, (size_t)world * BH_DD_PIECE_CAP * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->rbox, (size_t)2 * 64 * sizeof(float4)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_ps, ((size_t)kTopMax + 1) * sizeof(bh_d4)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_a, ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_b, ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_ps, 2 * ((size_t)kTopMax + 1) * sizeof(top5)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_a, 2 * ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_b, 2 * ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->acc2, ((size_t)n_cap + 64) * sizeof(float4)) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&d->ev_x3, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&d->ev_own, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_let, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -1039,6 +1075,27 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
   return BH_OK;
 }
 
+// Own pass of the two-pass force, on the side stream: it needs only the gathered piece descriptors and
+// the local tree, so it runs while the LET marking/export kernels and the X4 all-gather occupy the main
+// stream.  Top tree of this pass: other ranks' pieces are null records, top cells carry this rank's
+// share of their mass (bh_dd_top builds the mirror image for the remote pass).
+int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
+  if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
+  bh_dd_state* d = c->dd;
+  d->split = true;
+  BH_HIP(c, hipEventRecord(d->ev_x3, c->stream));  // the X3 gather and the local tree are complete here
+  BH_HIP(c, hipStreamWaitEvent(c->stream2, d->ev_x3, 0));
+  dd_top_kernel<<<1, 1024, 0, c->stream2>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
+                                            d->top_base2, d->seg_base, 1 + BH_DD_PIECE_CAP, c->bounds, c->p.G,
+                                            c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + (2 * kTopMax + 8),
+                                            d->top_b + (2 * kTopMax + 8), c->info, 1);
+  BH_HIP(c, hipGetLastError());
+  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, c->stream2, c->acc));
+  BH_HIP(c, hipEventRecord(d->ev_own, c->stream2));
+  return BH_OK;
+}
+
 int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
   if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
@@ -1051,7 +1108,7 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
   d->let_copy_pending = true;
   dd_top_kernel<<<1, 1024, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
                                            d->top_base, d->seg_base, stride, c->bounds, c->p.G, c->p.theta,
-                                           d->top_ps, d->top_a, d->top_b, c->info);
+                                           d->top_ps, d->top_a, d->top_b, c->info, d->split ? 2 : 0);
   BH_HIP(c, hipGetLastError());
   return BH_OK;
 }
@@ -1059,7 +1116,15 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
 int bh_dd_force(bh_ctx* c) {
   if (!c || !c->dd) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
-  BH_HIP(c, bhk_force_root(c, 0, c->n, c->dd->top_base));
+  bh_dd_state* d = c->dd;
+  if (d->split) {  // remote pass -> acc2; integrate adds the two once the own pass has finished too
+    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, d->acc2));
+    BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_own, 0));
+    c->acc2 = d->acc2;
+  } else {
+    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, c->acc));
+    c->acc2 = nullptr;
+  }
   c->stage |= BH_ST_FORCE;
   c->ever |= BH_ST_FORCE;
   return BH_OK;
@@ -1081,11 +1146,23 @@ int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts) {
 
 int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc) {
   if (!c || !c->dd) return BH_ERR_BAD_ARG;
-  const size_t nb = (size_t)c->n * sizeof(float4);
+  const size_t n = (size_t)c->n, nb = n * sizeof(float4);
   if (posm) BH_HIP(c, hipMemcpyAsync(posm, c->posm[c->cur], nb, hipMemcpyDeviceToHost, c->stream));
   if (velid) BH_HIP(c, hipMemcpyAsync(velid, c->velid[c->cur], nb, hipMemcpyDeviceToHost, c->stream));
   if (acc) BH_HIP(c, hipMemcpyAsync(acc, c->acc, nb, hipMemcpyDeviceToHost, c->stream));
   BH_HIP(c, hipStreamSynchronize(c->stream));
+  if (acc && c->acc2) {  // two-pass force: own pass + remote pass
+    float* tmp = (float*)malloc(nb);
+    if (!tmp) return BH_ERR_OOM;
+    hipError_t e = hipMemcpy(tmp, c->acc2, nb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+      for (size_t i = 0; i < 4 * n; i++) acc[i] += tmp[i];
+    free(tmp);
+    if (e != hipSuccess) {
+      c->last_hip = (int)e;
+      return BH_ERR_HIP;
+    }
+  }
   return BH_OK;
 }
 

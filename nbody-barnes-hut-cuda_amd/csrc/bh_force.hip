@@ -580,13 +580,18 @@ __global__ __launch_bounds__(256) void force_batched_kernel(const float4* __rest
 // ref:227-249, source text, no contraction: v += a dt; clamp |v| to max_speed; p += v dt
 __global__ __launch_bounds__(256) void integrate_kernel(float4* __restrict__ posm,
                                                         float4* __restrict__ velid,
-                                                        const float4* __restrict__ acc, int n, float DT,
+                                                        const float4* __restrict__ acc,
+                                                        const float4* __restrict__ acc2, int n, float DT,
                                                         float MAX_SPEED) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = posm[i];
   float4 v = velid[i];
-  const float4 a = acc[i];
+  float4 a = acc[i];
+  if (acc2) {  // two-pass force of the domain-decomposed step: own pass + remote pass
+    const float4 b = acc2[i];
+    a.x += b.x; a.y += b.y; a.z += b.z;
+  }
   float vx = v.x + a.x * DT;
   float vy = v.y + a.y * DT;
   float vz = v.z + a.z * DT;
@@ -743,20 +748,20 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
 
 // domain-decomposed stepping: the local bodies traverse the stitched pool (local tree + imported
 // LET segments) from the top-tree root
-hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root) {
+hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream, float4* acc) {
   if (hi <= lo) return hipSuccess;
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
   const int mode = c->p.xcd_mode == 2 ? 0 : c->p.xcd_mode;
   const int g2 = (hi - lo + tpb - 1) / tpb;
-  force_fast_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->acc, lo, hi, c->p.G,
-                                             c->p.eps2, mode, c->info, root);
+  force_fast_kernel<<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
+                                          c->p.eps2, mode, c->info, root);
   return hipGetLastError();
 }
 
 hipError_t bhk_integrate(bh_ctx* c) {
   const int n = c->n;
-  integrate_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, n,
+  integrate_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2, n,
                                                            c->p.dt, c->p.max_speed);
   return hipGetLastError();
 }

@@ -60,6 +60,7 @@ struct bh_ctx {
   int cur;
   float4* acc;       // (ax,ay,az,0) — engine-owned or caller-bound (bh_bind_acc)
   float4* acc_own;
+  float4* acc2;      // second addend of the accelerations (two-pass force of bh_dd.hip), or null
   float* stage_buf;  // 7n floats: SoA staging for upload/download
 
   // keys
@@ -135,7 +136,8 @@ hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
 hipError_t bhk_force_fast(bh_ctx* c, int lo, int hi);  // bh_force_fast.hip, default fast kernel
-hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root);  // fast kernel from pool record `root`
+hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream,
+                          float4* acc);  // fast kernel from pool record `root`
 hipError_t bhk_integrate(bh_ctx* c);
 void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 

@@ -153,8 +153,9 @@ class DomainStepper:
     stitched tree for its own bodies.  Four all-gathers per step, no replicated stage."""
 
     def __init__(self, pkg, ic, comm, device, stream=None, params=None, slack=1.3, mig_frac=0.5,
-                 let_cap=None, order=None, **kw):
+                 let_cap=None, order=None, split=True, **kw):
         self.comm = comm
+        self.split = bool(split)
         self.world, self.rank = comm.world, comm.rank
         P, r = self.world, self.rank
         n = len(ic[0])
@@ -235,6 +236,8 @@ class DomainStepper:
                 else:
                     self.x3s.zero_()
                 c.all_gather(self.x3r, self.x3s)
+                if failed is None and self.split:
+                    e.dd_force_local(self.x3r.data_ptr())              # own pieces, side stream, overlaps X4
                 while True:
                     stride = self.stride
                     seg = self.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32]

@@ -312,6 +312,9 @@ class Engine:
         self._ck(lib.bh_dd_let_pack(self._h, C.c_void_p(int(gathered_x3_ptr)), C.c_void_p(int(send_ptr)),
                                     int(stride)), "bh_dd_let_pack")
 
+    def dd_force_local(self, gathered_x3_ptr):
+        self._ck(lib.bh_dd_force_local(self._h, C.c_void_p(int(gathered_x3_ptr))), "bh_dd_force_local")
+
     def dd_top(self, gathered_x3_ptr, stride):
         self._ck(lib.bh_dd_top(self._h, C.c_void_p(int(gathered_x3_ptr)), int(stride)), "bh_dd_top")
 

@@ -92,14 +92,15 @@ def test_dd_first_step_matches_single_context(world):
     assert np.abs(p - p1).max() < 1e-3
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_dd_many_steps_conserve_and_track(world):
+@pytest.mark.parametrize("world,split", [(2, True), (4, True), (4, False)])
+def test_dd_many_steps_conserve_and_track(world, split):
+    """split: two-pass force (own pieces on a side stream while X4 is in flight + remote pieces)"""
     pkg = bhpkg.load()
     n = 40000
     ic = pkg.plummer(n, seed=11)
     steps = 12
     p1, v1, a1 = single(ic, steps)
-    out = run_ranks(world, ic, steps)
+    out = run_ranks(world, ic, steps, split=split)
     p, v, a = merge(out, n)     # also checks that migration lost / duplicated nobody
     assert sum(o[-1] for o in out) == n
     assert np.abs(p - p1).max() < 5e-2, np.abs(p - p1).max()

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--stream-ic", action="store_true", help="two counter-streaming halves (heavy migration)")
     ap.add_argument("--mig-frac", type=float, default=0.5)
     ap.add_argument("--check", action="store_true", help="compare with a single context")
+    ap.add_argument("--no-split", action="store_true", help="one force pass after X4 instead of own + remote passes")
     args = ap.parse_args()
     import torch
     pkg = bhpkg.load()
@@ -45,7 +46,7 @@ def main():
         try:
             torch.cuda.set_device(0)
             st = bhdist.DomainStepper(pkg, ic, bhdist.LocalComm(group, r), 0, stream=stream, order=order,
-                                      mig_frac=args.mig_frac)
+                                      mig_frac=args.mig_frac, split=not args.no_split)
             steppers[r] = st
             group.barrier.wait()
             for s in range(args.steps):
