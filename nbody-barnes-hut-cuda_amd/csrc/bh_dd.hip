@@ -73,8 +73,9 @@ struct bh_dd_state {
   top5* top_ps;    // [2][kTopMax + 1] fp64 prefix of the piece sums (one per pass: the passes overlap)
   int* top_a;      // [2 kTopMax] first piece of every top-tree child
   int* top_b;      // [2 kTopMax] end piece of every top-tree child
+  int4* top_ci;    // [2][2 kTopMax + 8] per top record: branching level (-1: piece), child offset / slot, count
   float4* acc2;    // [n_cap] accelerations of the remote pass (the own pass writes the context's acc)
-  hipEvent_t ev_x3, ev_own;
+  hipEvent_t ev_x3, ev_top1, ev_own;
   bool split;      // two-pass force: own pieces while X4 is in flight, remote pieces after it
   int* host;       // pinned: [world] LET counts, [world .. world+3] migration results
   hipEvent_t ev_let;
@@ -632,20 +633,9 @@ __device__ __forceinline__ bh_frec top_piece_record(const bh_dd_piece* __restric
   return pool[(size_t)seg_base + (size_t)d.owner * stride + 1 + k];
 }
 
-// record of the top-tree child [c0, c1) (piece positions): a piece, or the cell branching at the
-// first lowest boundary strictly inside the range
-__device__ __forceinline__ bh_frec top_child(const bh_dd_piece* __restrict__ g, const int* tslot,
-                                             const signed char* d, const int* pn, const int* cb,
-                                             const top5* __restrict__ ps, int c0, int c1, int me,
-                                             const bh_frec* __restrict__ pool, int top_base, int seg_base,
-                                             int stride, float s0, float G, float theta, int side) {
-  if (c1 - c0 == 1) return top_piece_record(g, tslot[c0], me, pool, seg_base, stride, side);
-  int l = c0 + 1, Lb = d[c0 + 1];
-  for (int i = c0 + 2; i < c1; i++)
-    if (d[i] < Lb) {
-      Lb = d[i];
-      l = i;
-    }
+// record of the top cell covering pieces [c0, c1), branching at level Lb, children at pool index `first`
+__device__ __forceinline__ bh_frec top_cell_record(const top5* __restrict__ ps, int c0, int c1, int Lb, int first,
+                                                   int meta, float s0, float G, float theta, int side) {
   const top5 p1 = ps[c1], p0 = ps[c0];
   const double M = p1.m - p0.m;
   const double sx = p1.x - p0.x, sy = p1.y - p0.y, sz = p1.z - p0.z;
@@ -668,17 +658,39 @@ __device__ __forceinline__ bh_frec top_child(const bh_dd_piece* __restrict__ g, 
   } else {
     fr.thr2 = -1.0f;
   }
-  fr.first = top_base + 1 + cb[l];
-  fr.meta = pn[l];
+  fr.first = first;
+  fr.meta = meta;
   fr.pad = 0;
   return fr;
+}
+
+// Top tree of the remote pass from the structure the own pass left in scratch (child ranges, branching
+// levels, child-block offsets, prefix sums): one thread per record, no rebuild.
+__global__ __launch_bounds__(256) void dd_top_emit_kernel(const bh_dd_piece* __restrict__ g, int me,
+                                                          bh_frec* __restrict__ pool, int top_base, int seg_base,
+                                                          int stride, const float* __restrict__ bounds, float G,
+                                                          float theta, const top5* __restrict__ ps,
+                                                          const int* __restrict__ cc0, const int* __restrict__ cc1,
+                                                          const int4* __restrict__ ci, const int* __restrict__ ddi,
+                                                          int side) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e > ddi[3]) return;
+  const int4 c = ci[e];
+  bh_frec fr;
+  if (c.x < 0)
+    fr = top_piece_record(g, c.y, me, pool, seg_base, stride, side);
+  else
+    fr = top_cell_record(ps, e == 0 ? 0 : cc0[e - 1], e == 0 ? ddi[2] : cc1[e - 1], c.x, top_base + c.y, c.z,
+                         bounds[6], G, theta, side);
+  pool[top_base + e] = fr;
 }
 
 __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restrict__ g, int world, int me,
                                                       bh_frec* __restrict__ pool, int top_base, int seg_base,
                                                       int stride, const float* __restrict__ bounds, float G,
                                                       float theta, top5* __restrict__ ps, int* __restrict__ cc0,
-                                                      int* __restrict__ cc1, bh_devinfo* __restrict__ info,
+                                                      int* __restrict__ cc1, int4* __restrict__ ci,
+                                                      int* __restrict__ ddi, bh_devinfo* __restrict__ info,
                                                       int side) {
   __shared__ int offs[65];
   __shared__ int tslot[kTopMax];
@@ -799,11 +811,30 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
   }
   __syncthreads();
   const float s0 = bounds[6];
+  if (tid == 0) {
+    ddi[2] = T;
+    ddi[3] = nchild;
+  }
   for (int e = tid; e <= nchild; e += 1024) {  // record 0 = the root, record 1 + k = child k
     const int c0 = e == 0 ? 0 : cc0[e - 1];
     const int c1 = e == 0 ? T : cc1[e - 1];
-    pool[top_base + e] =
-        top_child(g, tslot, d, pn, cb, ps, c0, c1, me, pool, top_base, seg_base, stride, s0, G, theta, side);
+    bh_frec fr;
+    int4 info4;
+    if (c1 - c0 == 1) {
+      fr = top_piece_record(g, tslot[c0], me, pool, seg_base, stride, side);
+      info4 = make_int4(-1, tslot[c0], 0, 0);
+    } else {  // the cell branches at the first lowest boundary strictly inside the range
+      int l = c0 + 1, Lb = d[c0 + 1];
+      for (int i = c0 + 2; i < c1; i++)
+        if (d[i] < Lb) {
+          Lb = d[i];
+          l = i;
+        }
+      fr = top_cell_record(ps, c0, c1, Lb, top_base + 1 + cb[l], pn[l], s0, G, theta, side);
+      info4 = make_int4(Lb, 1 + cb[l], pn[l], 0);
+    }
+    pool[top_base + e] = fr;
+    ci[e] = info4;
   }
 }
 
@@ -839,13 +870,14 @@ void bh_dd_free(bh_ctx* c) {
   bh_dd_state* d = c->dd;
   if (!d) return;
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
-                  d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->acc2};
+                  d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->host) (void)hipHostFree(d->host);
   if (d->ev_let) (void)hipEventDestroy(d->ev_let);
   if (d->ev_x3) (void)hipEventDestroy(d->ev_x3);
   if (d->ev_own) (void)hipEventDestroy(d->ev_own);
+  if (d->ev_top1) (void)hipEventDestroy(d->ev_top1);
   c->acc2 = nullptr;
   free(d);
   c->dd = nullptr;
@@ -913,9 +945,11 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->top_ps, 2 * ((size_t)kTopMax + 1) * sizeof(top5)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->top_a, 2 * ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->top_b, 2 * ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_ci, 2 * ((size_t)2 * kTopMax + 8) * sizeof(int4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->acc2, ((size_t)n_cap + 64) * sizeof(float4)) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_x3, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_own, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&d->ev_top1, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_let, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -1089,8 +1123,10 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
   dd_top_kernel<<<1, 1024, 0, c->stream2>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
                                             d->top_base2, d->seg_base, 1 + BH_DD_PIECE_CAP, c->bounds, c->p.G,
                                             c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + (2 * kTopMax + 8),
-                                            d->top_b + (2 * kTopMax + 8), c->info, 1);
+                                            d->top_b + (2 * kTopMax + 8), d->top_ci + (2 * kTopMax + 8), d->ddi,
+                                            c->info, 1);
   BH_HIP(c, hipGetLastError());
+  BH_HIP(c, hipEventRecord(d->ev_top1, c->stream2));  // the remote pass re-emits from this tree's scratch
   BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, c->stream2, c->acc));
   BH_HIP(c, hipEventRecord(d->ev_own, c->stream2));
   return BH_OK;
@@ -1106,9 +1142,17 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
                              sizeof(int), (size_t)d->world, hipMemcpyDeviceToHost, c->stream));
   BH_HIP(c, hipEventRecord(d->ev_let, c->stream));
   d->let_copy_pending = true;
-  dd_top_kernel<<<1, 1024, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
-                                           d->top_base, d->seg_base, stride, c->bounds, c->p.G, c->p.theta,
-                                           d->top_ps, d->top_a, d->top_b, c->info, d->split ? 2 : 0);
+  if (d->split) {  // same structure as the own pass's tree: re-emit the records only
+    BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_top1, 0));
+    dd_top_emit_kernel<<<(2 * kTopMax + 1 + 255) / 256, 256, 0, c->stream>>>(
+        (const bh_dd_piece*)gathered_x3, d->rank, d->pool, d->top_base, d->seg_base, stride, c->bounds, c->p.G,
+        c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + (2 * kTopMax + 8), d->top_b + (2 * kTopMax + 8),
+        d->top_ci + (2 * kTopMax + 8), d->ddi, 2);
+  } else {
+    dd_top_kernel<<<1, 1024, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
+                                             d->top_base, d->seg_base, stride, c->bounds, c->p.G, c->p.theta,
+                                             d->top_ps, d->top_a, d->top_b, d->top_ci, d->ddi, c->info, 0);
+  }
   BH_HIP(c, hipGetLastError());
   return BH_OK;
 }
