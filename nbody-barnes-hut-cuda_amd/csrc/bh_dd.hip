@@ -633,6 +633,32 @@ __device__ __forceinline__ bh_frec top_piece_record(const bh_dd_piece* __restric
   return pool[(size_t)seg_base + (size_t)d.owner * stride + 1 + k];
 }
 
+// Per-level bitmasks over the piece boundaries (row v+1: bit p set iff d[p] <= v): nearest-smaller
+// queries become a masked word, a short word scan and clz / ctz / popcount instead of byte-by-byte LDS
+// scans (same device as pairs_kernel of bh_tree.hip).  nw = words in use.
+constexpr int kTopWords = kTopMax / 64;
+__device__ __forceinline__ int tm_prev(const u64* row, int p) {  // highest set bit below p, or -1
+  int w = p >> 6;
+  u64 bits = row[w] & ((1ull << (p & 63)) - 1ull);
+  while (bits == 0ull && w > 0) bits = row[--w];
+  return bits ? w * 64 + 63 - __clzll((long long)bits) : -1;
+}
+__device__ __forceinline__ int tm_next(const u64* row, int p, int nw) {  // lowest set bit above p, or -1
+  int w = p >> 6;
+  u64 bits = row[w] & ~((2ull << (p & 63)) - 1ull);
+  while (bits == 0ull && w < nw - 1) bits = row[++w];
+  return bits ? w * 64 + __ffsll((long long)bits) - 1 : -1;
+}
+__device__ __forceinline__ int tm_count(const u64* row, int p, int q) {  // set bits in (p, q)
+  const int w0 = p >> 6, w1 = q >> 6;
+  const u64 above_p = ~((2ull << (p & 63)) - 1ull);
+  const u64 below_q = (1ull << (q & 63)) - 1ull;
+  if (w0 == w1) return __popcll(row[w0] & above_p & below_q);
+  int c = __popcll(row[w0] & above_p) + __popcll(row[w1] & below_q);
+  for (int w = w0 + 1; w < w1; w++) c += __popcll(row[w]);
+  return c;
+}
+
 // record of the top cell covering pieces [c0, c1), branching at level Lb, children at pool index `first`
 __device__ __forceinline__ bh_frec top_cell_record(const top5* __restrict__ ps, int c0, int c1, int Lb, int first,
                                                    int meta, float s0, float G, float theta, int side) {
@@ -694,9 +720,10 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
                                                       int side) {
   __shared__ int offs[65];
   __shared__ int tslot[kTopMax];
-  __shared__ signed char d[kTopMax + 1];
-  __shared__ int pn[kTopMax + 1];
+  __shared__ signed char d[kTopMax + 64];
+  __shared__ unsigned char pn[kTopMax + 1];  // children of the cell represented by boundary j (<= 8)
   __shared__ int cb[kTopMax + 1];
+  __shared__ u64 lm[kB + 2][kTopWords];      // lm[v + 1]: boundaries with d <= v, v = -1 .. kB
   __shared__ int wsum[16];
   __shared__ top5 wsum4[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -761,6 +788,18 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
     }
   }
   __syncthreads();
+  // level masks; positions past T count as sentinels (d = -1)
+  const int nw = (T >> 6) + 1;
+  for (int w = wv; w < nw; w += 16) {
+    const int pos = w * 64 + lane;
+    const int dv = pos < T ? (int)d[pos] : -1;
+#pragma unroll
+    for (int v = -1; v <= kB; v++) {
+      const u64 bb = __ballot(dv <= v);
+      if (lane == 0) lm[v + 1][w] = bb;
+    }
+  }
+  __syncthreads();
   // cells: pair j at level L = d[j] names the cell [a, b); representative = its first boundary
   int ra[kTopMax / 1024], rb[kTopMax / 1024];
 #pragma unroll
@@ -770,21 +809,17 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
     ra[r] = rb[r] = 0;
     if (j >= 1 && j < T) {
       const int L = d[j];
-      int i = j - 1;
-      while (d[i] > L) i--;
-      if (d[i] < L) {  // no earlier boundary of the same level inside the cell
-        ra[r] = i;
-        nc = 2;
-        i = j + 1;
-        while (d[i] >= L) {
-          if (d[i] == L) nc++;
-          i++;
-        }
-        rb[r] = i;
+      const u64* mle = lm[L + 1];
+      const int q = tm_prev(mle, j);  // >= 0: d[0] = -1
+      if (d[q] < L) {  // no earlier boundary of the same level inside the cell
+        ra[r] = q;
+        const int b = tm_next(lm[L], j, nw);  // exists: d[T] = -1
+        rb[r] = b;
+        nc = 2 + tm_count(mle, j, b);
       }
     }
     if (j < T) {
-      pn[j] = nc;
+      pn[j] = (unsigned char)nc;
       cb[j] = nc;
     }
   }
@@ -797,6 +832,7 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
     const int j = tid + r * 1024;
     if (j >= T || pn[j] == 0) continue;
     const int L = d[j], b = rb[r];
+    const u64* mle = lm[L + 1];  // inside the cell every d >= L, so d <= L means d == L
     int e = cb[j];
     int c0 = ra[r], c1 = j;
     for (;;) {
@@ -805,8 +841,8 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
       e++;
       if (c1 >= b) break;
       c0 = c1;
-      c1 = c0 + 1;
-      while (c1 < b && d[c1] != L) c1++;
+      const int nx = tm_next(mle, c0, nw);
+      c1 = (nx < 0 || nx > b) ? b : nx;
     }
   }
   __syncthreads();
@@ -823,15 +859,19 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
     if (c1 - c0 == 1) {
       fr = top_piece_record(g, tslot[c0], me, pool, seg_base, stride, side);
       info4 = make_int4(-1, tslot[c0], 0, 0);
-    } else {  // the cell branches at the first lowest boundary strictly inside the range
-      int l = c0 + 1, Lb = d[c0 + 1];
-      for (int i = c0 + 2; i < c1; i++)
-        if (d[i] < Lb) {
-          Lb = d[i];
-          l = i;
+    } else {  // the cell branches at the first lowest boundary strictly inside the range: the smallest
+      // level above the parent's (= the larger of the two end boundaries) with a boundary inside
+      int l = c0 + 1, Lb = kB;
+      for (int v = max((int)d[c0], (int)d[c1]) + 1; v < kB; v++) {
+        const int sx = tm_next(lm[v + 1], c0, nw);
+        if (sx >= 0 && sx < c1) {
+          Lb = v;
+          l = sx;
+          break;
         }
-      fr = top_cell_record(ps, c0, c1, Lb, top_base + 1 + cb[l], pn[l], s0, G, theta, side);
-      info4 = make_int4(Lb, 1 + cb[l], pn[l], 0);
+      }
+      fr = top_cell_record(ps, c0, c1, Lb, top_base + 1 + cb[l], (int)pn[l], s0, G, theta, side);
+      info4 = make_int4(Lb, 1 + cb[l], (int)pn[l], 0);
     }
     pool[top_base + e] = fr;
     ci[e] = info4;
