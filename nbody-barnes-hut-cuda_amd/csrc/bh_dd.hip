@@ -76,6 +76,7 @@ struct bh_dd_state {
   int4* top_ci;    // [2][2 kTopMax + 8] per top record: branching level (-1: piece), child offset / slot, count
   float4* acc2;    // [n_cap] accelerations of the remote pass (the own pass writes the context's acc)
   hipEvent_t ev_x3, ev_top1, ev_own;
+  hipStream_t stream_own;  // lowest priority: the own pass is background work behind the LET export and X4
   bool split;      // two-pass force: own pieces while X4 is in flight, remote pieces after it
   int* host;       // pinned: [world] LET counts, [world .. world+3] migration results
   hipEvent_t ev_let;
@@ -909,6 +910,10 @@ static void dd_set_n(bh_ctx* c, int n) {
 void bh_dd_free(bh_ctx* c) {
   bh_dd_state* d = c->dd;
   if (!d) return;
+  if (d->stream_own) {  // the own pass may still be reading the arrays freed below
+    (void)hipStreamSynchronize(d->stream_own);
+    (void)hipStreamDestroy(d->stream_own);
+  }
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
                   d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2};
   for (void* p : ptrs)
@@ -918,6 +923,7 @@ void bh_dd_free(bh_ctx* c) {
   if (d->ev_x3) (void)hipEventDestroy(d->ev_x3);
   if (d->ev_own) (void)hipEventDestroy(d->ev_own);
   if (d->ev_top1) (void)hipEventDestroy(d->ev_top1);
+
   c->acc2 = nullptr;
   free(d);
   c->dd = nullptr;
@@ -990,6 +996,11 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipEventCreateWithFlags(&d->ev_x3, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_own, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_top1, hipEventDisableTiming) == hipSuccess;
+  {
+    int least = 0, greatest = 0;
+    ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&d->stream_own, hipStreamNonBlocking, least) == hipSuccess;
+  }
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_let, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
@@ -1159,16 +1170,16 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
   bh_dd_state* d = c->dd;
   d->split = true;
   BH_HIP(c, hipEventRecord(d->ev_x3, c->stream));  // the X3 gather and the local tree are complete here
-  BH_HIP(c, hipStreamWaitEvent(c->stream2, d->ev_x3, 0));
-  dd_top_kernel<<<1, 1024, 0, c->stream2>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
+  BH_HIP(c, hipStreamWaitEvent(d->stream_own, d->ev_x3, 0));
+  dd_top_kernel<<<1, 1024, 0, d->stream_own>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
                                             d->top_base2, d->seg_base, 1 + BH_DD_PIECE_CAP, c->bounds, c->p.G,
                                             c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + (2 * kTopMax + 8),
                                             d->top_b + (2 * kTopMax + 8), d->top_ci + (2 * kTopMax + 8), d->ddi,
                                             c->info, 1);
   BH_HIP(c, hipGetLastError());
-  BH_HIP(c, hipEventRecord(d->ev_top1, c->stream2));  // the remote pass re-emits from this tree's scratch
-  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, c->stream2, c->acc));
-  BH_HIP(c, hipEventRecord(d->ev_own, c->stream2));
+  BH_HIP(c, hipEventRecord(d->ev_top1, d->stream_own));  // the remote pass re-emits from this tree's scratch
+  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, d->stream_own, c->acc));
+  BH_HIP(c, hipEventRecord(d->ev_own, d->stream_own));
   return BH_OK;
 }
 
