@@ -98,6 +98,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a one-GPU box (tests/test_gpu_dist.py): all ranks on GPU 0, gloo
+    # standing in for RCCL.  Never set by the driver; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("BH_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -108,7 +113,10 @@ def main():
     multi = world > 1 or os.environ.get("BH_FORCE_DIST") == "1"
     if multi:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     n_total = args.n * world  # weak scaling: fixed bodies per GPU
     ic = pkg.plummer(n_total, seed=args.seed)  # identical on every rank (counter-based RNG)
@@ -170,7 +178,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

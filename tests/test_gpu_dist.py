@@ -42,6 +42,29 @@ def test_bench_distributed_path_world1(mode, word):
     assert word in out["config"]["parallelism"]
 
 
+@pytest.mark.parametrize("mode", ["domain", "replicated"])
+def test_bench_two_ranks_rehearsal(mode):
+    """bench.py end to end with WORLD_SIZE=2 (both ranks on this one GPU, gloo instead of RCCL): the
+    N > 1 code path of the benchmark itself — IC generation for 2 x bodies, stepper, timing reduction,
+    JSON assembly.  The throughput of such a run is meaningless and not checked."""
+    env = dict(os.environ)
+    env["BH_BENCH_REHEARSAL"] = "1"
+    env["BH_DIST_MODE"] = mode
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--bodies", "150000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["n_total"] == 300000 and out["value"] > 0
+    assert "domain_fallback" not in out["config"]
+    if mode == "domain":
+        assert len(out["config"]["domain"]["let_records_per_rank"]) == 2
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_domain_stepper_multiprocess_one_gpu(world, tmp_path):
     """the real multi-process flow of the domain-decomposed step (torch.distributed, one process and
