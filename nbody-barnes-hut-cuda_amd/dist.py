@@ -200,9 +200,38 @@ class DomainStepper:
         self.let_retries = 0
         self.n_loc = len(mine)
 
+    @classmethod
+    def with_engine(cls, engine, sz, comm, n_cap, mig_cap, let_cap, tensor_device="cpu", split=True):
+        """The per-step protocol (exchanges, size negotiation, failure handling) around ANY object with
+        the dd_* methods of Engine — tests/dd_cpu_worker.py drives it on CPU tensors over gloo."""
+        self = cls.__new__(cls)
+        self.comm, self.split = comm, bool(split)
+        self.world, self.rank = comm.world, comm.rank
+        self.e, self.sz, self.stream = engine, sz, None
+        self.n_cap, self.mig_cap, self.let_cap = int(n_cap), int(mig_cap), int(let_cap)
+        self.mig_stride = min(self.mig_cap, 4096)
+        self.mig_rounds = self.mig_last = self.let_retries = self.n_loc = 0
+        self.let_counts = None
+        P = self.world
+        u8 = dict(dtype=torch.uint8, device=tensor_device)
+        self.x1s = torch.zeros(sz.x1_bytes, **u8)
+        self.x1r = torch.zeros(P * sz.x1_bytes, **u8)
+        self.x2s = torch.zeros(sz.x2_bytes, **u8)
+        self.x2r = torch.zeros(P * sz.x2_bytes, **u8)
+        self.x3s = torch.zeros(sz.x3_bytes, **u8)
+        self.x3r = torch.zeros(P * sz.x3_bytes, **u8)
+        self.lets = torch.zeros(self.let_cap * 32, **u8)
+        self.pool = torch.zeros(sz.pool_records * 32, **u8)
+        self.stride = min(self.let_cap, _round_up(sz.let_min + self.n_cap // 8, 256))
+        return self
+
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def step(self, steps=1):
         e, c, sz, P = self.e, self.comm, self.sz, self.world
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             for _ in range(int(steps)):
                 e.dd_cube_pack(self.x1s.data_ptr())                    # X1: cube + splitters
                 c.all_gather(self.x1r, self.x1s)

@@ -73,3 +73,36 @@ def test_torchcomm_all_gather(world):
            os.path.join(ROOT, "tests", "comm_worker.py")]
     r = subprocess.run(cmd, timeout=300, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("scenario", ["normal", "failure"])
+def test_domain_stepper_protocol(world, scenario, tmp_path):
+    """the per-step protocol of the domain-decomposed multi-GPU step (dist.DomainStepper.step) on CPU
+    tensors over gloo with a scripted engine: adaptive exchange sizes, extra migration rounds when a
+    wave of emigrants exceeds this step's X2 size, the LET retry when a segment outgrows the stride,
+    and a rank-local failure that every rank must leave together (no rank stranded in a collective)"""
+    import json
+    out = str(tmp_path / "proto.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dd_cpu_worker.py"), out, scenario]
+    r = subprocess.run(cmd, timeout=300, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    res = json.load(open(out))
+    assert len(res) == world
+    # every rank took the same decisions
+    for k in ("mig_rounds", "let_retries", "stride", "mig_stride", "integrates"):
+        assert len({x[k] for x in res}) == 1, (k, res)
+    if scenario == "normal":
+        assert all(x["error"] is None and x["integrates"] == 4 and x["force_local"] == 4 for x in res)
+        # step 1: 6000 emigrants against the initial X2 size of 4096 -> one extra round, after which
+        # the size follows the observed count (capped by the buffer) and step 2's 9000 fit at once
+        assert res[0]["mig_rounds"] == 1 and res[0]["mig_stride"] >= 2048
+        # step 1 needs 4700 records against the first stride; step 2 jumps to 15000 -> retries
+        assert res[0]["let_retries"] == 2
+        assert res[0]["stride"] >= 15500
+    else:
+        # the failing rank and all others raise in step 2, after the same number of collectives
+        assert all(x["error"] and "left the domain-decomposed step" in x["error"] for x in res), res
+        assert all(x["integrates"] == 2 for x in res)
