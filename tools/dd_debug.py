@@ -22,13 +22,16 @@ def main():
     ap.add_argument("--stream-ic", action="store_true", help="two counter-streaming halves (heavy migration)")
     ap.add_argument("--mig-frac", type=float, default=0.5)
     ap.add_argument("--check", action="store_true", help="compare with a single context")
+    ap.add_argument("--theta", type=float, default=0.5)
+    ap.add_argument("--ic", default="plummer", choices=["plummer", "disc"])
+    ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="one force pass after X4 instead of own + remote passes")
     args = ap.parse_args()
     import torch
     pkg = bhpkg.load()
     from nbody_barnes_hut_cuda_amd import dist as bhdist
     n, P = args.n, args.world
-    ic = [a.copy() for a in pkg.plummer(n, seed=args.seed)]
+    ic = [a.copy() for a in (pkg.plummer if args.ic == "plummer" else pkg.disc)(n, seed=args.seed)]
     if args.stream_ic:
         ic[3] += 400.0
         ic[3][: n // 2] -= 800.0
@@ -46,7 +49,7 @@ def main():
         try:
             torch.cuda.set_device(0)
             st = bhdist.DomainStepper(pkg, ic, bhdist.LocalComm(group, r), 0, stream=stream, order=order,
-                                      mig_frac=args.mig_frac, split=not args.no_split)
+                                      mig_frac=args.mig_frac, split=not args.no_split, theta=args.theta)
             steppers[r] = st
             group.barrier.wait()
             for s in range(args.steps):
@@ -54,7 +57,7 @@ def main():
                 st.step(1)
                 flags = st.e.stats().status_flags
                 group.barrier.wait()
-                if r == 0:
+                if r == 0 and not args.quiet:
                     hdr = st.x3r.cpu().numpy().view(np.int32).reshape(P, -1)[:, 0]
                     log(f"   pieces per rank {hdr.tolist()}")
                     log(f"step {s}: n_loc={[x.n_loc for x in steppers]} stride={st.stride} "
@@ -81,7 +84,7 @@ def main():
             ids, posm, vel, a = st.local_state()
             pos[ids] = posm[:, :3]
             acc[ids] = a
-        with pkg.Engine(n) as e:
+        with pkg.Engine(n, theta=args.theta) as e:
             e.upload(*ic)
             e.step(args.steps)
             x, y, z, *_ = e.download()
@@ -89,7 +92,8 @@ def main():
         p1 = np.stack([x, y, z], 1)
         a1 = np.stack([ax, ay, az], 1)
         rel = np.linalg.norm(acc - a1, axis=1) / np.maximum(np.linalg.norm(a1, axis=1), 1e-30)
-        log(f"check: max |dpos| {np.abs(pos - p1).max():.3e}  acc rel err median {np.median(rel):.3e} "
+        bad = rel.max() > 5e-3 or np.median(rel) > 1e-5
+        log(f"{'FAIL' if bad else 'ok  '} world {P} n {n} seed {args.seed} theta {args.theta} {args.ic}: max |dpos| {np.abs(pos - p1).max():.3e}  acc rel err median {np.median(rel):.3e} "
             f"p99.99 {np.quantile(rel, 0.9999):.3e} max {rel.max():.3e}")
 
 
