@@ -84,7 +84,6 @@ def main():
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="fast force kernel: 0 scalar DFS (default), 1 batched")
     ap.add_argument("--xcd-mode", type=int, default=0, help="tuning: block->chunk placement (bh_params.xcd_mode)")
     ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
     ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
@@ -133,7 +132,7 @@ def main():
 
     def replicated():
         e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
-                                        force_variant=args.variant, xcd_mode=args.xcd_mode,
+                                        xcd_mode=args.xcd_mode,
                                         leaf_cap=args.leaf_cap, force_block=args.force_block)
         e.upload(*ic)
         return e, st
@@ -144,7 +143,7 @@ def main():
         # capacity errors are) drops all ranks to the replicated scheme together instead of losing the run.
         try:
             stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
-                                           force_variant=0, xcd_mode=args.xcd_mode,
+                                           xcd_mode=args.xcd_mode,
                                            force_block=args.force_block)
             eng = stepper.e
             stepper.step(args.warmup)
@@ -204,7 +203,7 @@ def main():
             roofline = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "force_fast_kernel" if args.variant != 1 else "force_batched_kernel",
+                "kernel": "force_fast_kernel",
                 "avg_launch_ms": avg_force_ms,
                 "launches_timed": int(len(f_ms)),
                 "algorithmic_bytes_per_launch": bytes_alg,

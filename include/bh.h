@@ -57,10 +57,9 @@ typedef struct bh_params {
   int32_t strict_fp;  /* 0: fast force kernel (fma + v_rsq_f32);
                          1: force arithmetic exactly as the reference source text
                             in IEEE fp32 (sqrtf, '/', no contraction; ref:203-213) */
-  int32_t force_variant; /* fast force kernel: 0 = scalar-load depth-first kernel (default,
-                            fastest measured), 1 = batched kernel (LDS work list, prefetched
-                            vector loads), 3 = depth-first kernel with the scalar/branch overhead
-                            restructured; 1 and 3 measured slower, kept for A/B — DESIGN.md    */
+  int32_t force_variant; /* reserved, must be 0.  (Two alternative fast kernels — an LDS work-list kernel with
+                            batched vector loads and a restructured scalar-overhead kernel — were measured
+                            22 % and 4 % slower and removed)                              */
   int32_t xcd_mode;      /* fast force kernels, block -> body-chunk placement (speed only):
                             0 = one contiguous eighth of the Morton order per XCD, 1 = identity,
                             2 = runs of 16 chunks per XCD dealt round-robin                       */

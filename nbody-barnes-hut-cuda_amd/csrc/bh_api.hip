@@ -102,7 +102,8 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   if (pin) p = *pin; else bh_default_params(&p);
   if (n < 1 || n > (1 << 30) / 2) return BH_ERR_BAD_ARG;
   if (p.key_bits != 63 && p.key_bits != 30) return BH_ERR_BAD_ARG;
-  if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0)
+  if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0 ||
+      p.force_variant != 0)
     return BH_ERR_BAD_ARG;
 
   int ndev = 0;
@@ -165,7 +166,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->cb, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->rec, (size_t)c->rec_cap) == hipSuccess;
-  ok = ok && dalloc(&c->frec, (size_t)c->rec_cap) == hipSuccess;
+  ok = ok && dalloc(&c->frec, (size_t)c->rec_cap + N + 8) == hipSuccess;  // tree digests + body digests
   ok = ok && dalloc(&c->er_lo, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->er_hi, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->P, N + 1) == hipSuccess;
@@ -183,7 +184,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   }
   // the record pool is read up to 3 records past a child block (force kernel): keep it defined
   if (hipMemsetAsync(c->rec, 0, (size_t)c->rec_cap * sizeof(bh_node), c->stream) != hipSuccess ||
-      hipMemsetAsync(c->frec, 0, (size_t)c->rec_cap * sizeof(bh_frec), c->stream) != hipSuccess ||
+      hipMemsetAsync(c->frec, 0, ((size_t)c->rec_cap + N + 8) * sizeof(bh_frec), c->stream) != hipSuccess ||
       hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream) != hipSuccess ||
       hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream) != hipSuccess) {
     free_all(c);

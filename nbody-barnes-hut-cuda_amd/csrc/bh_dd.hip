@@ -508,11 +508,12 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
 }
 
 __device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restrict__ w,
-                                         const int* __restrict__ dst, int blocks0) {
+                                         const int* __restrict__ dst, int blocks0, int rec_cap) {
+  if (c >= rec_cap) return fr;  // a body digest (child of an unsplit multi-body cell): no children
   const int wc = w[c];
   if (wc > 0) {
     fr.first = blocks0 + dst[c];
-    fr.meta = wc;  // an exported unsplit cell becomes a block of body records
+    fr.meta = wc;
   } else if (fr.thr2 >= 0.0f) {
     fr.first = 0;  // never opened by a remote body (conservative test): index unused
   }
@@ -522,11 +523,11 @@ __device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restric
 // send[0] header, send[1 .. PIECE_CAP] the pieces' own records, then the child blocks in scan order.
 // Child indices are pool indices of the receiving side: seg0 = pool index of this rank's segment.
 __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restrict__ frec,
-                                                        const float4* __restrict__ posm, int rec_cap,
+                                                        int rec_cap,
                                                         const int* __restrict__ w, const int* __restrict__ dst,
                                                         const int* __restrict__ piece_idx,
                                                         const int* __restrict__ ddi, int seg0, int stride,
-                                                        float G, bh_frec* __restrict__ send) {
+                                                        bh_frec* __restrict__ send) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int blocks0 = seg0 + 1 + BH_DD_PIECE_CAP;
   const int np = min(ddi[0], BH_DD_PIECE_CAP);
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
   if (e < BH_DD_PIECE_CAP) {
     bh_frec fr;
     memset(&fr, 0, sizeof(fr));
-    if (e < np) fr = reloc(frec[piece_idx[e]], piece_idx[e], w, dst, blocks0);
+    if (e < np) fr = reloc(frec[piece_idx[e]], piece_idx[e], w, dst, blocks0, rec_cap);
     if (!fits) fr.thr2 = -1.0f;
     send[1 + e] = fr;
   }
@@ -553,21 +554,8 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
   const int off = 1 + BH_DD_PIECE_CAP + dst[e];
   if (off + wv > stride) return;  // does not fit: the header tells the host to repeat with more room
   const bh_frec fr = frec[e];
-  if (fr.meta < 0) {  // unsplit multi-body cell: its bodies travel as body records
-    for (int k = 0; k < wv; k++) {
-      const float4 q = posm[fr.first + k];
-      bh_frec o;
-      o.x = q.x; o.y = q.y; o.z = q.z;
-      o.gm = q.w > 0.0f ? G * q.w : 0.0f;
-      o.thr2 = -1.0f;
-      o.first = 0;
-      o.meta = 1;
-      o.pad = 0;
-      send[off + k] = o;
-    }
-  } else {
-    for (int k = 0; k < wv; k++) send[off + k] = reloc(frec[fr.first + k], fr.first + k, w, dst, blocks0);
-  }
+  // children of a cell, or the body digests of an unsplit multi-body cell: one kind of block
+  for (int k = 0; k < wv; k++) send[off + k] = reloc(frec[fr.first + k], fr.first + k, w, dst, blocks0, rec_cap);
 }
 
 // ------------------------------------------------------------------ top tree
@@ -935,7 +923,7 @@ int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) 
   if (!o || n_cap < 1 || world < 1 || world > 64 || mig_cap < 1) return BH_ERR_BAD_ARG;
   const long long let_min = 1 + BH_DD_PIECE_CAP;
   if (let_cap < let_min) return BH_ERR_BAD_ARG;
-  const long long rec_cap = 2LL * n_cap + 8;
+  const long long rec_cap = 2LL * n_cap + 8 + n_cap + 8;  // tree digests + body digests (bh_internal.h)
   const long long top_cap = 2LL * kTopMax + 8;
   o->x1_bytes = (int64_t)x1_floats(world) * 4;
   o->x2_bytes = 32 + 32LL * mig_cap;
@@ -1153,9 +1141,9 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
       c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w);
   BH_HIP(c, hipGetLastError());
   BH_HIP(c, bhk_scan_i32(c, d->w, d->dst, c->rec_cap, nullptr));
-  dd_export_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->posm[c->cur], c->rec_cap, d->w, d->dst,
+  dd_export_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->rec_cap, d->w, d->dst,
                                                   d->piece_idx, d->ddi, d->seg_base + d->rank * stride, stride,
-                                                  c->p.G, (bh_frec*)send_x4);
+                                                  (bh_frec*)send_x4);
   BH_HIP(c, hipGetLastError());
   return BH_OK;
 }

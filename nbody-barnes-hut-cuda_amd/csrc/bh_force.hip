@@ -266,12 +266,14 @@ __global__ __launch_bounds__(256) void force_kernel(const bh_node* __restrict__ 
 //   thr2 = (s/theta)^2, -1 for a body or a mass<=0 record
 //          -> accept  <=>  d2 + eps2 > thr2   (== s/dist < theta; one v_cmp, independent of the rsq)
 //          a mass<=0 record is "accepted" with zero force, i.e. skipped like ref:203, branch-free
+//   an unsplit multi-body cell is a cell whose children are its bodies' digests (COM stage), so the
+//   loop has one kind of record and no body-array path
 // Lane masks stay in SGPR pairs: accept = v_cmp into an SGPR pair, take/open = s_and/s_andn2
 // with the stack entry's mask, the take mask drives one v_cndmask (inverse ballot).
 // 15 VALU per (record, wave): 3 sub, 3 fma, cmp, rsq, 3 mul, cndmask, 3 fma.
 struct FRec {
   float x, y, z, gm, thr2;
-  int first, meta;  // meta = count | (multi-body leaf ? 1<<31 : 0)
+  int first, meta;  // child block and child count
 };
 
 typedef float float8_t __attribute__((ext_vector_type(8)));
@@ -319,26 +321,12 @@ __device__ __forceinline__ void load_frec2(cfloat_t* base, int e, FRec& a, FRec&
     ay = fmaf(fm, dy, ay);                                                               \
     az = fmaf(fm, dz, az);                                                               \
     if (openm != 0ull) {                                                                 \
-      if ((R).meta >= 0) {                                                               \
+      {                                                                                  \
         if (sp < 64 * SETS) {                                                            \
           ws_push<SETS>(st, sp++, (R).first, (R).meta, openm);                           \
         } else {                                                                         \
           overflow = true; /* the caller redoes this wave with the large stack */        \
           sp = 0;          /* drain quickly: the loop tests sp only */                   \
-        }                                                                                \
-      } else {                                                                           \
-        const int b0 = (R).first, b1 = b0 + ((R).meta & 0x7fffffff);                     \
-        const bool wantl = __builtin_amdgcn_inverse_ballot_w64(openm);                   \
-        for (int bb = b0; bb < b1; bb++) {                                               \
-          const float4 qb = load_body(bodies, bb);                                       \
-          if (!(qb.w > 0.0f)) continue;                                                  \
-          const float ex = qb.x - px, ey = qb.y - py, ez = qb.z - pz;                    \
-          const float e2 = fmaf(ez, ez, fmaf(ey, ey, fmaf(ex, ex, eps2)));               \
-          const float ri = __builtin_amdgcn_rsqf(e2);                                    \
-          const float ff = wantl ? (Gv * qb.w) * ri * (ri * ri) : 0.0f;                  \
-          ax = fmaf(ff, ex, ax);                                                         \
-          ay = fmaf(ff, ey, ay);                                                         \
-          az = fmaf(ff, ez, az);                                                         \
         }                                                                                \
       }                                                                                  \
     }                                                                                    \
@@ -347,9 +335,8 @@ __device__ __forceinline__ void load_frec2(cfloat_t* base, int e, FRec& a, FRec&
 // One wave's traversal from record `root` for the lanes of m0; returns false if the cross-lane stack
 // (64 * SETS entries) overflowed, in which case ax..az are incomplete.
 template <int SETS>
-__device__ __forceinline__ bool fast_traverse(cfloat_t* frec, cfloat_t* bodies, int root, u64 m0, float px,
-                                              float py, float pz, float Gv, float eps2, float& ax, float& ay,
-                                              float& az) {
+__device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, float px, float py, float pz,
+                                              float eps2, float& ax, float& ay, float& az) {
   WaveStack st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int sp = 0;
   bool overflow = false;
@@ -385,7 +372,6 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
                                                          float eps2, int xcd_mode,
                                                          bh_devinfo* __restrict__ info, int root) {
   cfloat_t* frec = (cfloat_t*)frec_g;
-  cfloat_t* bodies = (cfloat_t*)posm;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int chunk = block_chunk(xcd_mode);
@@ -403,177 +389,12 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   if (m0 == 0) return;
   // 64 stack entries (one VGPR set, no set-select branches) cover every tree seen in practice; the
   // rare wave that needs more redoes its walk with the 192-entry stack (>= the 7*21+1 bound)
-  if (!fast_traverse<1>(frec, bodies, root, m0, px, py, pz, G, eps2, ax, ay, az)) {
+  if (!fast_traverse<1>(frec, root, m0, px, py, pz, eps2, ax, ay, az)) {
     ax = ay = az = 0.0f;
-    if (!fast_traverse<3>(frec, bodies, root, m0, px, py, pz, G, eps2, ax, ay, az) && lane == 0)
+    if (!fast_traverse<3>(frec, root, m0, px, py, pz, eps2, ax, ay, az) && lane == 0)
       atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
   }
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
-}
-
-// ------------------------------------------------------------------ batched kernel (default)
-// The scalar-load kernel above pays one dependent memory round trip (~1000 cycles: the tree is
-// far larger than a 4 MiB per-XCD L2) per popped cell, ~600 per wave at theta = 0.5.  Here the
-// wave's work list lives in LDS and is consumed in BATCHES:
-//   * pop the top E <= 8 entries at once; lane l fetches record (l & 7) of entry (l >> 3) with two
-//     global_load_dwordx4 — up to 64 records (2 KiB) in flight per wave, 8x fewer round trips;
-//   * double buffering: the loads of batch t+1 are issued BEFORE batch t is evaluated (the entries
-//     are independent work items, any deterministic order is a valid traversal), so the round trip
-//     hides under ~50 records x 15 VALU of evaluation;
-//   * the fetched records are staged through LDS (each lane writes its 32 B once, every lane
-//     reads the record under evaluation from one address = a broadcast), which keeps the VALU
-//     count at 15 per record (v_readlane broadcasting would add 5);
-//   * lane masks of the entries stay in SGPR pairs exactly as in the scalar kernel.
-// Stack bound: batched mode only while sp <= kBatchSp; above it one entry per batch (pure
-// depth-first, growth <= 7 per level <= 148).  Worst case kBatchSp + 56 + 148 < kStackEntries.
-constexpr int kStackEntries = 512;  // per wave, 12 B each
-constexpr int kBatchSp = 300;
-
-#define BH_BATCH_EVAL(A, B2, SLOT)                                                         \
-  {                                                                                        \
-    const float dx = (A).x - px, dy = (A).y - py, dz = (A).z - pz;                         \
-    const float d2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));                       \
-    const u64 accm = __builtin_amdgcn_ballot_w64(d2 > (B2).x);                             \
-    const u64 takem = mask & accm, openm = mask & ~accm;                                   \
-    const float rinv = __builtin_amdgcn_rsqf(d2);                                          \
-    const float f = ((A).w * rinv) * (rinv * rinv);                                        \
-    const float fm = __builtin_amdgcn_inverse_ballot_w64(takem) ? f : 0.0f;                \
-    ax = fmaf(fm, dx, ax);                                                                 \
-    ay = fmaf(fm, dy, ay);                                                                 \
-    az = fmaf(fm, dz, az);                                                                 \
-    if (openm != 0ull) {                                                                   \
-      const int cfirst = rfl(__float_as_int((B2).y));                                      \
-      const int cmeta = rfl(__float_as_int(rbuf[(SLOT) * 8 + 6]));                         \
-      if (cmeta >= 0) {                                                                    \
-        if (sp < kStackEntries) {                                                          \
-          if (lane == 0) {                                                                 \
-            stk[sp * 3 + 0] = (u32)cfirst | ((u32)(cmeta - 1) << 28);                      \
-            stk[sp * 3 + 1] = (u32)openm;                                                  \
-            stk[sp * 3 + 2] = (u32)(openm >> 32);                                          \
-          }                                                                                \
-          sp++;                                                                            \
-        } else {                                                                           \
-          overflow = 1; /* reported after the loop: a VMEM op in here makes hipcc flush */ \
-        }                 /* vmcnt before the loop and serialises the prefetch          */ \
-      } else {                                                                             \
-        const int b0 = cfirst, b1 = b0 + (cmeta & 0x7fffffff);                             \
-        const bool wantl = __builtin_amdgcn_inverse_ballot_w64(openm);                     \
-        for (int bb = b0; bb < b1; bb++) {                                                 \
-          const float4 qb = load_body(bodies, bb);                                         \
-          if (!(qb.w > 0.0f)) continue;                                                    \
-          const float ex = qb.x - px, ey = qb.y - py, ez = qb.z - pz;                      \
-          const float e2 = fmaf(ez, ez, fmaf(ey, ey, fmaf(ex, ex, eps2)));                 \
-          const float ri = __builtin_amdgcn_rsqf(e2);                                      \
-          const float ff = wantl ? (Gv * qb.w) * ri * (ri * ri) : 0.0f;                    \
-          ax = fmaf(ff, ex, ax);                                                           \
-          ay = fmaf(ff, ey, ay);                                                           \
-          az = fmaf(ff, ez, az);                                                           \
-        }                                                                                  \
-      }                                                                                    \
-    }                                                                                      \
-  }
-
-__global__ __launch_bounds__(256) void force_batched_kernel(const float4* __restrict__ frec4,
-                                                            const float4* __restrict__ posm,
-                                                            float4* __restrict__ acc, int lo, int hi, float G,
-                                                            float eps2, int rec_cap, int xcd_mode,
-                                                            bh_devinfo* __restrict__ info) {
-  __shared__ u32 s_stack[4][kStackEntries * 3];
-  __shared__ __attribute__((aligned(16))) float s_rec[4][64 * 8];
-  cfloat_t* bodies = (cfloat_t*)posm;
-  const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  u32* stk = s_stack[wib];
-  float* rbuf = s_rec[wib];
-  const int chunk = block_chunk(xcd_mode);
-  const int i = lo + (chunk * 4 + wib) * 64 + lane;
-  const bool valid = i < hi;
-  float px, py, pz;
-  {
-    const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
-    px = p.x; py = p.y; pz = p.z;
-  }
-  float ax = 0.0f, ay = 0.0f, az = 0.0f;
-  const float Gv = G;
-  const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
-  if (m0 == 0) return;
-
-  // consume the position load here: its first use would otherwise sit inside the batch loop and
-  // hipcc would cover it with s_waitcnt vmcnt(0) there, draining the prefetch every iteration
-  asm volatile("" ::"v"(px), "v"(py), "v"(pz));
-  int sp = 0;  // wave-uniform
-  int overflow = 0;
-  if (lane == 0) {  // ref:198 stack = {root}
-    stk[0] = 0u;    // first 0, count 1
-    stk[1] = (u32)m0;
-    stk[2] = (u32)(m0 >> 32);
-  }
-  sp = 1;
-
-  // prefetched batch: entry info per lane (same in the 8 lanes of an entry) + one record per lane
-  int preE = 0;
-  u32 pre_fc = 0, pre_ml = 0, pre_mh = 0;
-  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-  const int ej = lane >> 3, ek = lane & 7;
-
-  for (;;) {
-    // current batch := prefetched batch; stage its records in LDS
-    const int curE = preE;
-    const u32 cur_fc = pre_fc, cur_ml = pre_ml, cur_mh = pre_mh;
-    if (curE > 0) {
-      *(float4*)&rbuf[lane * 8] = ra;
-      *(float4*)&rbuf[lane * 8 + 4] = rb;
-    }
-    // pop the next batch and issue its loads (consumed one iteration later)
-    preE = (sp > kBatchSp) ? 1 : (sp < 8 ? sp : 8);
-    if (preE > 0) {
-      const bool has = ej < preE;
-      const int idx = has ? (sp - 1 - ej) : 0;
-      pre_fc = stk[idx * 3 + 0];
-      pre_ml = stk[idx * 3 + 1];
-      pre_mh = stk[idx * 3 + 2];
-      const int cnt = has ? (int)((pre_fc >> 28) & 7u) + 1 : 0;
-      int e = (int)(pre_fc & 0x0fffffffu) + ek;
-      if (ek < cnt && e < rec_cap) {
-        ra = frec4[(size_t)e * 2];
-        rb = frec4[(size_t)e * 2 + 1];
-      }
-      sp -= preE;
-    }
-    if (curE == 0) {
-      if (preE == 0) break;
-      continue;
-    }
-    // evaluate the current batch
-    for (int e = 0; e < curE; e++) {
-      const u32 fc = (u32)__builtin_amdgcn_readlane((int)cur_fc, e * 8);
-      const u64 mask = ((u64)(u32)__builtin_amdgcn_readlane((int)cur_mh, e * 8) << 32) |
-                       (u64)(u32)__builtin_amdgcn_readlane((int)cur_ml, e * 8);
-      const int cnt = (int)((fc >> 28) & 7u) + 1;
-      for (int k0 = 0; k0 < cnt; k0 += 4) {
-        const int s0 = e * 8 + k0;
-        const float4 a0 = *(const float4*)&rbuf[(s0 + 0) * 8];
-        const float2 b0 = *(const float2*)&rbuf[(s0 + 0) * 8 + 4];
-        const float4 a1 = *(const float4*)&rbuf[(s0 + 1) * 8];
-        const float2 b1 = *(const float2*)&rbuf[(s0 + 1) * 8 + 4];
-        const float4 a2 = *(const float4*)&rbuf[(s0 + 2) * 8];
-        const float2 b2 = *(const float2*)&rbuf[(s0 + 2) * 8 + 4];
-        const float4 a3 = *(const float4*)&rbuf[(s0 + 3) * 8];
-        const float2 b3 = *(const float2*)&rbuf[(s0 + 3) * 8 + 4];
-        const int nk = cnt - k0;
-        BH_BATCH_EVAL(a0, b0, s0 + 0);
-        if (nk > 1) {
-          BH_BATCH_EVAL(a1, b1, s0 + 1);
-          if (nk > 2) {
-            BH_BATCH_EVAL(a2, b2, s0 + 2);
-            if (nk > 3) BH_BATCH_EVAL(a3, b3, s0 + 3);
-          }
-        }
-      }
-    }
-  }
-  if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
-  if (overflow && lane == 0) atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
 }
 
 // ------------------------------------------------------------------ integrate
@@ -721,26 +542,19 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       force_kernel<true, false><<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, th, e2, nullptr, nullptr, nullptr, c->info);
     else {
       const int mode = c->p.xcd_mode;
-      int grid = blocks;
-      if (mode == 2) grid = (blocks + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
-      if (c->rec_cap >= (1 << 27)) {
-        // the fast kernels address records with 32-bit byte offsets (pool < 4 GiB = 64M bodies):
+      // the frec pool = tree digests + one digest slot per body (bh_internal.h)
+      if ((long long)c->rec_cap + c->n + 8 >= (1ll << 27)) {
+        // the fast kernel addresses records with 32-bit byte offsets (pool < 4 GiB, ~44M bodies):
         // beyond that the generic kernel does the same arithmetic on the canonical records
         force_kernel<false, false><<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, th, e2, nullptr, nullptr, nullptr, c->info);
         return hipGetLastError();
       }
-      if (c->p.force_variant == 3 && c->rec_cap < (1 << 28))
-        return bhk_force_fast(c, lo, hi);  // bh_force_fast.hip (scalar overhead trimmed; measured 4 % slower)
-      if (c->p.force_variant != 1 || c->rec_cap >= (1 << 28)) {
-        int tpb = c->p.force_block;  // 64, 128 or 256 threads per workgroup (0 = default)
-        if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
-        int g2 = (hi - lo + tpb - 1) / tpb;
-        if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
-        force_fast_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                   mode, c->info, 0);
-      } else
-        force_batched_kernel<<<grid, 256, 0, c->stream>>>((const float4*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                        c->rec_cap, mode, c->info);
+      int tpb = c->p.force_block;  // 64, 128 or 256 threads per workgroup (0 = default)
+      if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
+      int g2 = (hi - lo + tpb - 1) / tpb;
+      if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+      force_fast_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2, mode, c->info,
+                                                 0);
     }
   }
   return hipGetLastError();

@@ -14,8 +14,8 @@ struct bh_frec {
   float x, y, z;  // centre of mass
   float gm;       // G*m, 0 when m <= 0
   float thr2;     // (s/theta)^2; -1 for a body or a mass<=0 record (always accepted)
-  int first;
-  int meta;       // count | (multi-body leaf ? 1<<31 : 0)
+  int first;      // child block; body index for a body; rec_cap + first body for an unsplit multi-body cell
+  int meta;       // child count (bodies of an unsplit cell count as its children)
   int pad;
 };
 
@@ -88,7 +88,8 @@ struct bh_ctx {
   int* pn;        // [n] its child count (0: j represents no emitted cell)
   int* cb;        // [n+1] exclusive scan of pn; cb[n] = records - 1
   bh_node* rec;   // [rec_cap] tree records (canonical: ABI download, strict/counting kernels)
-  bh_frec* frec;  // [rec_cap] pre-digested records for the fast force kernel (written by COM)
+  bh_frec* frec;  // [rec_cap + n] digests for the fast force kernel (written by COM): tree records, then
+                  // one slot per sorted body (used only for the bodies of unsplit multi-body cells)
   int* er_lo;     // [rec_cap] body range of each record
   int* er_hi;
   int rec_cap;
@@ -135,7 +136,6 @@ hipError_t bhk_sort_onesweep(bh_ctx* c);              // default implementation 
 hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
-hipError_t bhk_force_fast(bh_ctx* c, int lo, int hi);  // bh_force_fast.hip, default fast kernel
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream,
                           float4* acc);  // fast kernel from pool record `root`
 hipError_t bhk_integrate(bh_ctx* c);

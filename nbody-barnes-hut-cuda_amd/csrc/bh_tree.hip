@@ -649,8 +649,25 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
     fr.thr2 = t * t;
   }
   fr.first = r.first;
-  fr.meta = r.count | (r.kind == BH_KIND_MULTI ? (int)0x80000000 : 0);
+  fr.meta = r.count;
   fr.pad = 0;
+  if (r.kind == BH_KIND_MULTI) {
+    // an unsplit multi-body cell is, for the fast kernel, a cell whose children are its bodies: body b's
+    // digest lives at rec_cap + b (bodies of a cell are consecutive, so the block is contiguous); only
+    // the slots of such bodies are ever written or read
+    fr.first = rec_cap + lo;
+    for (int b = lo; b < hi; b++) {
+      const float4 q = posm[b];
+      bh_frec br;
+      br.x = q.x; br.y = q.y; br.z = q.z;
+      br.gm = q.w > 0.0f ? G * q.w : 0.0f;
+      br.thr2 = -1.0f;
+      br.first = b;
+      br.meta = 1;
+      br.pad = 0;
+      frec[rec_cap + b] = br;
+    }
+  }
   frec[e] = fr;
 }
 
