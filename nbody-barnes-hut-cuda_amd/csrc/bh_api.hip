@@ -358,21 +358,14 @@ int bh_step(bh_ctx* c) {
   BH_MARK(3);
   // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan
   // on the side stream while the main stream builds the tree (both are small, latency-bound grids)
-  static const bool overlap = getenv("BH_NO_OVERLAP") == nullptr;  // A/B switch
-  if (overlap) {
-    BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
-    BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
-    BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, true));
-    BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
-    BH_HIP(c, bhk_build(c));                     // ref:266-275
-    BH_MARK(4);
-    BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
-    BH_HIP(c, bhk_com_records(c));               // ref:279-280
-  } else {
-    BH_HIP(c, bhk_build(c));
-    BH_MARK(4);
-    BH_HIP(c, bhk_com(c));
-  }
+  BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
+  BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
+  BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, true));
+  BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
+  BH_HIP(c, bhk_build(c));                     // ref:266-275
+  BH_MARK(4);
+  BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
+  BH_HIP(c, bhk_com_records(c));               // ref:279-280
   BH_MARK(5);
   BH_HIP(c, bhk_force(c, 0, c->n, false));     // ref:281
   BH_MARK(6);
