@@ -172,3 +172,26 @@ def test_dd_rank_failure_is_collective():
     with pytest.raises(Exception) as ei:
         run_ranks(4, ic, 6, slack=0.92)   # capacity 50,096 bodies per rank for ~50,000 +- 1 %
     assert "left the domain-decomposed step" in str(ei.value) or "overflow" in str(ei.value)
+
+
+def test_dd_config4_full_size_8_ranks_x_1M():
+    """BASELINE config 4 (8,000,000 bodies on 8 GPUs) rehearsed on this one GPU: 8 ranks x 1M bodies in
+    one process against a single 8M-body context, 2 steps.  Same canonical octree, so the forces agree to
+    summation order (the two-pass force adds the own and the remote part separately)."""
+    pkg = bhpkg.load()
+    n = 8_000_000
+    ic = pkg.plummer(n, seed=42)
+    p1, v1, a1 = single(ic, 2)
+    out = run_ranks(8, ic, 2)
+    p, v, a = merge(out, n)
+    assert sum(o[-1] for o in out) == n
+    e = rel(a, a1)
+    assert np.median(e) < 2e-6, np.median(e)
+    assert np.quantile(e, 0.9999) < 1e-4, np.quantile(e, 0.9999)
+    assert e.max() < 2e-3, e.max()
+    assert np.abs(p - p1).max() < 1e-3
+    # every rank ends within 2 % of its fair share and exports well under a third of its tree
+    counts = np.array([o[-1] for o in out])
+    assert np.abs(counts - n / 8).max() < 0.02 * n / 8, counts
+    let = out[0][4]
+    assert let.max() < 0.35 * 2 * n / 8, let
