@@ -1,0 +1,54 @@
+"""Long-run soak: many steps, device-side status flags and finiteness checked along the way.
+python tools/soak.py single 1000000 3000 | python tools/soak.py dd 4 1000000 600"""
+import os, sys, threading, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bhpkg
+pkg = bhpkg.load()
+mode = sys.argv[1]
+if mode == "single":
+    n, steps = int(sys.argv[2]), int(sys.argv[3])
+    e = pkg.Engine(n)
+    e.upload(*pkg.plummer(n, seed=17))
+    t0 = time.time()
+    for s in range(0, steps, 250):
+        e.step(min(250, steps - s))
+        st = e.stats()
+        assert st.status_flags == 0, (s, st.status_flags)
+        print(f"step {s + 250}: flags 0, cells {st.n_internal}, max level {st.max_level}", flush=True)
+    x, y, z, vx, vy, vz = e.download()
+    assert np.isfinite(x).all() and np.isfinite(vx).all()
+    print(f"single {n} x {steps} steps ok, {time.time() - t0:.1f} s, |x|max {np.abs(x).max():.1f}")
+else:
+    import torch
+    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    P, n, steps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    ic = pkg.plummer(n, seed=17)
+    order = bhdist.global_morton_order(pkg, ic, 0)
+    group = bhdist.LocalGroup(P)
+    stream = torch.cuda.Stream(0)
+    errs, sts = [], [None] * P
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            st = bhdist.DomainStepper(pkg, ic, bhdist.LocalComm(group, r), 0, stream=stream, order=order)
+            sts[r] = st
+            group.barrier.wait()
+            for s in range(0, steps, 100):
+                st.step(min(100, steps - s))
+                fl = st.e.stats().status_flags
+                assert fl == 0, (r, s, fl)
+                group.barrier.wait()
+                if r == 0:
+                    print(f"step {s + 100}: n_loc {[x.n_loc for x in sts]} let {st.let_counts.tolist()} emig {st.mig_last} "
+                          f"mig_rounds {st.mig_rounds} let_retries {st.let_retries}", flush=True)
+                group.barrier.wait()
+        except BaseException as ex:
+            errs.append((r, ex)); print("rank", r, repr(ex), flush=True); group.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]; [t.join() for t in th]
+    if errs: raise SystemExit(1)
+    tot = sum(s.n_loc for s in sts)
+    assert tot == n, tot
+    print(f"dd {P} ranks x {n // P} x {steps} steps ok")
