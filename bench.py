@@ -209,7 +209,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_alg,
                 "per_body": {"V": V / n_total, "O": O / n_total, "P": P / n_total,
                              "bytes": bytes_alg / n_total},
-                "limiter": "instruction issue: 27 instructions (16 VALU) per (record, wave), 57.8M such pairs on "
+                "limiter": "instruction issue: 26 instructions (16 VALU) per (record, wave), 57.8M such pairs on "
                            "1024 SIMDs vs a 21-29 ns memory-free microbenchmark floor of the 15-VALU body "
                            "(DESIGN.md §4, tools/ubench_valu.hip); HBM is ~0.4 % utilised",
                 "note": "algorithmic = per-lane no-reuse bytes of the recurrence (SURVEY 8d); the "
