@@ -195,3 +195,44 @@ def test_dd_config4_full_size_8_ranks_x_1M():
     assert np.abs(counts - n / 8).max() < 0.02 * n / 8, counts
     let = out[0][4]
     assert let.max() < 0.35 * 2 * n / 8, let
+
+
+def test_dd_abi_argument_and_order_checks():
+    """error behaviour of the bh_dd_* entry points: bad sizes, unsupported parameters, calls out of order"""
+    import ctypes as C
+    import torch
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd._lib import lib, BhDdSizes
+    from nbody_barnes_hut_cuda_amd.engine import BhError
+    sz = BhDdSizes()
+    assert lib.bh_dd_query(50000, 4, 4096, 100, C.byref(sz)) == -1          # let_cap below header + piece slots
+    assert lib.bh_dd_query(50000, 65, 4096, 60000, C.byref(sz)) == -1       # more than 64 ranks
+    assert lib.bh_dd_query(50000, 4, 4096, 60000, C.byref(sz)) == 0
+    assert sz.seg_base > sz.top_base > 2 * 50000 and sz.pool_records > sz.seg_base + 4 * 60000
+    pool = torch.zeros(sz.pool_records * 32, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    for bad in (dict(leaf_cap=4), dict(key_bits=30, max_depth=10), dict(strict_fp=1)):
+        with pkg.Engine(50000, **bad) as e:                                 # needs 63-bit keys, leaf_cap 1, fast kernel
+            with pytest.raises(BhError):
+                e.dd_init(4, 0, 200000, 4096, 60000, pool.data_ptr(), sz.pool_records)
+    with pkg.Engine(50000) as e:
+        with pytest.raises(BhError):
+            e.dd_init(4, 4, 200000, 4096, 60000, pool.data_ptr(), sz.pool_records)      # rank out of range
+        with pytest.raises(BhError):
+            e.dd_init(4, 0, 200000, 4096, 60000, pool.data_ptr(), sz.pool_records - 1)  # pool too small
+        e.dd_init(4, 0, 200000, 4096, 60000, pool.data_ptr(), sz.pool_records)
+        with pytest.raises(BhError):
+            e.dd_init(4, 0, 200000, 4096, 60000, pool.data_ptr(), sz.pool_records)      # already initialised
+        buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(BhError):
+            e.dd_cube_pack(buf.data_ptr())                                  # nothing uploaded yet
+        ic = pkg.plummer(40000, seed=1)
+        e.dd_upload(*ic, np.arange(40000, dtype=np.int32))
+        with pytest.raises(BhError):
+            e.dd_migrate_pack(buf.data_ptr(), 1024)                         # before the cube exchange
+        with pytest.raises(BhError):
+            e.dd_let_pack(buf.data_ptr(), buf.data_ptr(), 1024)             # before the local tree
+        with pytest.raises(BhError):
+            e.dd_force()
+        with pytest.raises(BhError):
+            e.dd_upload(*pkg.plummer(60000, seed=1), np.arange(60000, dtype=np.int32))  # above the capacity
