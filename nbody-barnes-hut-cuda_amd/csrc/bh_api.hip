@@ -158,6 +158,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   // (granules carry the sort-call tag, tickets are monotonic)
   ok = ok && hipMemset(c->sw_status, 0, (size_t)8 * c->sort_tiles * 256 * sizeof(u64)) == hipSuccess;
   ok = ok && hipMemset(c->sw_ticket, 0, 8 * sizeof(u32)) == hipSuccess;
+  ok = ok && hipMemset(c->sw_hist, 0, 8 * 256 * sizeof(u32)) == hipSuccess;
   ok = ok && dalloc(&c->bbox_partial, (size_t)BH_BBOX_BLOCKS * 6) == hipSuccess;
   ok = ok && dalloc(&c->bounds, 8) == hipSuccess;
   ok = ok && dalloc(&c->d8, N + 1) == hipSuccess;

@@ -67,7 +67,8 @@ struct bh_dd_state {
   u64* skeys;      // [world-1] splitter keys under the current cube, ascending
   int* piece_tmp;  // [BH_DD_PIECE_CAP] unsorted piece records
   int* piece_idx;  // [BH_DD_PIECE_CAP] pieces in body order
-  int* ddi;        // [8] device scalars: 0 pieces found, 1 remote boxes, 4..6 migration results
+  int* ddi;        // [16] device scalars: 0 piece counter, 1 remote boxes, 2 top pieces, 3 top children,
+                   //      4..7 migration results, 8 pieces of this step
   float4* boxes;   // [world * BH_DD_PIECE_CAP] remote piece boxes (corner, edge), margin applied
   float4* rbox;    // [2 * world] bounding box of each remote rank's pieces + its range in boxes[]
   top5* top_ps;    // [2][kTopMax + 1] fp64 prefix of the piece sums (one per pass: the passes overlap)
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void dd_spine_kernel(const bh_node* __restrict
 }
 
 __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
-    const int* __restrict__ piece_tmp, const int* __restrict__ ddi, const bh_node* __restrict__ rec,
+    const int* __restrict__ piece_tmp, const int* ddi, int* ddi_w, const bh_node* __restrict__ rec,
     const int* __restrict__ er_lo, const int* __restrict__ er_hi, const u64* __restrict__ keys,
     const bh_d4* __restrict__ P, const float4* __restrict__ posm, const float* __restrict__ bounds, int me,
     int n_loc, bh_dd_piece* __restrict__ out, int* __restrict__ piece_idx, bh_devinfo* __restrict__ info) {
@@ -342,6 +343,10 @@ __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
     lo[t] = er_lo[idx[t]];
   }
   __syncthreads();
+  if (t == 0) {
+    ddi_w[8] = np;  // for the export kernel
+    ddi_w[0] = 0;   // every thread has read the count: cleared for the next step's spine kernel
+  }
   if (t >= np) return;
   int rank = 0;
   for (int u = 0; u < np; u++) rank += (lo[u] < lo[t]) ? 1 : 0;  // pieces are disjoint: distinct starts
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
                                                         bh_frec* __restrict__ send) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int blocks0 = seg0 + 1 + BH_DD_PIECE_CAP;
-  const int np = min(ddi[0], BH_DD_PIECE_CAP);
+  const int np = ddi[8];
   if (e == 0) {
     bh_frec h;
     memset(&h, 0, sizeof(h));
@@ -973,7 +978,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->skeys, 64 * 8) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_tmp, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_idx, BH_DD_PIECE_CAP * 4) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->ddi, 8 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->ddi, 16 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->boxes, (size_t)world * BH_DD_PIECE_CAP * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->rbox, (size_t)2 * 64 * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->top_ps, 2 * ((size_t)kTopMax + 1) * sizeof(top5)) == hipSuccess;
@@ -997,6 +1002,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   }
   d->samp_cap = samp_cap_of(world);
   BH_HIP(c, hipMemsetAsync(d->nloc, 0, 64 * 4, c->stream));
+  BH_HIP(c, hipMemsetAsync(d->ddi, 0, 16 * 4, c->stream));  // piece counter: re-cleared by dd_describe_kernel
   // the caller's pool becomes the record pool: the COM stage writes the local tree at [0, rec_cap)
   BH_HIP(c, hipMemsetAsync(pool, 0, (size_t)pool_records * sizeof(bh_frec), c->stream));
   c->frec_own = c->frec;
@@ -1115,10 +1121,9 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
   BH_HIP(c, bhk_sort(c));
   BH_HIP(c, bhk_build(c));
   BH_HIP(c, bhk_com(c));
-  BH_HIP(c, hipMemsetAsync(d->ddi, 0, 8 * 4, c->stream));
   dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->er_lo, c->er_hi, c->info, c->rec_cap,
                                                                    c->n, d->piece_tmp, d->ddi);
-  dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, c->rec, c->er_lo, c->er_hi,
+  dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, d->ddi, c->rec, c->er_lo, c->er_hi,
                                                            c->keys[c->key_buf], c->P, c->posm[c->cur], c->bounds,
                                                            d->rank, c->n, (bh_dd_piece*)send_x3, d->piece_idx,
                                                            c->info);
@@ -1133,7 +1138,6 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
   if (stride < 1 + BH_DD_PIECE_CAP || stride > d->let_cap) return BH_ERR_BAD_ARG;
-  BH_HIP(c, hipMemsetAsync(d->ddi + 1, 0, 4, c->stream));
   dd_boxes_kernel<<<d->world, 256, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, c->bounds,
                                                    d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;

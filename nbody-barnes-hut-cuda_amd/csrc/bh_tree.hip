@@ -227,8 +227,13 @@ __device__ __forceinline__ void child_bounds(const u64* __restrict__ k, int a, i
 
 // d[j] = leading octal digits shared by keys j-1 and j (0..B); d[0] = d[n] = -1 (sentinels)
 __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int n, int B,
-                                                  signed char* __restrict__ d) {
+                                                  signed char* __restrict__ d, bh_devinfo* __restrict__ info) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) {  // first kernel of the build: tree statistics restart; the sticky flags (4th word) survive
+    info->n_internal = 0;
+    info->n_entries = 0;
+    info->max_level = 0;
+  }
   if (j > n) return;
   d[j] = (j == 0 || j == n) ? (signed char)-1 : (signed char)common_digits(k[j - 1], k[j], B);
 }
@@ -713,10 +718,7 @@ hipError_t bhk_keys(bh_ctx* c) {
 hipError_t bhk_build(bh_ctx* c) {
   const int n = c->n;
   const u64* k = c->keys[c->key_buf];
-  // tree statistics restart every build; the sticky error flags (4th word) survive until upload
-  hipError_t e = hipMemsetAsync(c->info, 0, 3 * sizeof(int), c->stream);
-  if (e != hipSuccess) return e;
-  lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8);
+  lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8, c->info);
   // every 2^ss-th key, at most kSampMax of them: bisection seeds of the wide-cell searches
   int ss = 12;
   while (((n + (1 << ss) - 1) >> ss) > kSampMax) ss++;
@@ -725,7 +727,7 @@ hipError_t bhk_build(bh_ctx* c) {
   pairs_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
                                                                         c->ksamp, ns, ss, c->pa, c->pb, c->pn,
                                                                         c->info);
-  e = bhk_scan_i32(c, c->pn, c->cb, n, nullptr);  // child-block offsets; cb[n] = total children
+  const hipError_t e = bhk_scan_i32(c, c->pn, c->cb, n, nullptr);  // child-block offsets; cb[n] = total children
   if (e != hipSuccess) return e;
   emit_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
                                                                        c->ksamp, ns, ss, c->pa,
