@@ -147,15 +147,15 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
   __syncthreads();
   for (int size = 2; size <= kSampTotal; size <<= 1) {
     for (int j = size >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < kSampTotal; i += 1024) {
-        const int partner = i ^ j;
-        if (partner > i) {
-          const u64 a = k[i], b = k[partner];
-          const bool up = (i & size) == 0;
-          if ((a > b) == up) {
-            k[i] = b;
-            k[partner] = a;
-          }
+      // kSampTotal / 2 compare-exchanges per stage, two per thread: pair p -> (i, i | j)
+      for (int p = tid; p < kSampTotal / 2; p += 1024) {
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+        const int partner = i | j;
+        const u64 a = k[i], b = k[partner];
+        const bool up = (i & size) == 0;
+        if ((a > b) == up) {
+          k[i] = b;
+          k[partner] = a;
         }
       }
       __syncthreads();
