@@ -259,7 +259,7 @@ class DomainStepper:
                     self.mig_rounds += 1                                # rare: a splitter changed octant
                     limit = min(self.mig_cap, max(limit, _round_up(most, 256)))
                 self.mig_last = first
-                self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 1.5 + 2048, 256)))
+                self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 2.0 + 4096, 256)))
                 if failed is None:
                     e.dd_tree(self.x3s.data_ptr())                     # local sort/build/COM; X3: pieces
                 else:
