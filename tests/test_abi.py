@@ -103,3 +103,24 @@ def test_ic_disc_matches_reference_formulae(pkg):
 def test_ic_bad_args(pkg):
     with pytest.raises(ValueError):
         pkg.plummer(0)
+
+
+def test_dd_query_sizes_are_host_side_and_consistent():
+    """bh_dd_query needs no GPU: buffer sizes of the domain-decomposed multi-GPU step"""
+    import ctypes as C
+    import bhpkg
+    bhpkg.load()
+    from nbody_barnes_hut_cuda_amd._lib import lib, BhDdSizes, BH_DD_PIECE_CAP
+    sz = BhDdSizes()
+    n_cap, world, mig_cap, let_cap = 1_304_096, 8, 652_048, 1 + BH_DD_PIECE_CAP + 1_304_096
+    assert lib.bh_dd_query(n_cap, world, mig_cap, let_cap, C.byref(sz)) == 0
+    assert sz.x2_bytes == 32 + 32 * mig_cap and sz.x3_bytes == 80 * (1 + BH_DD_PIECE_CAP)
+    assert sz.x1_bytes == 4 * (8 + 4 * (4096 // world))
+    assert sz.let_min == 1 + BH_DD_PIECE_CAP and sz.let_cap == let_cap
+    # pool = local tree + body digests | two top trees | world LET segments (+ read-ahead padding)
+    assert sz.top_base >= 3 * n_cap and sz.seg_base > sz.top_base
+    assert sz.pool_records >= sz.seg_base + world * let_cap
+    assert sz.pool_records < (1 << 27)            # the force kernel addresses records with 32-bit byte offsets
+    assert lib.bh_dd_query(n_cap, world, mig_cap, BH_DD_PIECE_CAP, C.byref(sz)) == -1      # stride below the minimum
+    assert lib.bh_dd_query(20_000_000, 8, 1 << 20, 30_000_000, C.byref(sz)) == -1          # pool beyond 4 GiB
+    assert lib.bh_dd_query(0, 8, 1024, 4096, C.byref(sz)) == -1
