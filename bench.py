@@ -179,6 +179,8 @@ def main():
         counts0 = (s.count_V, s.count_O, s.count_P)
     eng.set_timing(not multi)  # per-step hipEvent pairs on the engine's stream (1-GPU path)
 
+    if dist_mode == "domain" and rank == 0:
+        stepper.set_profile(True)   # per-phase event pairs on rank 0's stream (a few microseconds per step)
     barrier()
     t0 = time.perf_counter()
     if not multi:
@@ -262,7 +264,8 @@ def main():
             out["config"]["domain"] = {
                 "bodies_rank0": int(stepper.n_loc), "let_records_per_rank": [int(v) for v in stepper.let_counts],
                 "let_stride": int(stepper.stride), "emigrants_last_step_max": int(stepper.mig_last),
-                "let_retries": int(stepper.let_retries), "extra_migration_rounds": int(stepper.mig_rounds)}
+                "let_retries": int(stepper.let_retries), "extra_migration_rounds": int(stepper.mig_rounds),
+                "phase_ms_rank0": stepper.phase_ms()}
         assert st.status_flags == 0, st.status_flags
     if dist is not None:
         dist.barrier()

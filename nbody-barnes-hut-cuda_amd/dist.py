@@ -225,6 +225,38 @@ class DomainStepper:
         self.stride = min(self.let_cap, _round_up(sz.let_min + self.n_cap // 8, 256))
         return self
 
+    # ---- optional per-phase device timing (events on the main stream; bench.py reports the means) ----
+    PHASES = ("x1_cube_splitters", "x2_migration", "local_tree_x3", "let_export_x4", "top_remote_force",
+              "integrate")
+
+    def set_profile(self, on=True):
+        self._prof = [] if on and self.stream is not None else None
+
+    def _mark(self, k):
+        if getattr(self, "_prof", None) is None:
+            return
+        if k == 0:
+            self._cur = [None] * 7
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(self.stream)
+        self._cur[k] = ev          # a repeated phase (LET retry) keeps its last mark
+
+    def _close_marks(self):
+        if getattr(self, "_prof", None) is not None:
+            self._prof.append(self._cur)
+
+    def phase_ms(self):
+        """mean device time per phase over the profiled steps (the own force pass overlaps the LET phase
+        on its own stream and is waited for inside 'top_remote_force')"""
+        if not getattr(self, "_prof", None):
+            return None
+        torch.cuda.synchronize()
+        acc = [0.0] * 6
+        for evs in self._prof:
+            for k in range(6):
+                acc[k] += evs[k].elapsed_time(evs[k + 1])
+        return {name: acc[k] / len(self._prof) for k, name in enumerate(self.PHASES)}
+
     def _on_stream(self):
         import contextlib
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
@@ -233,9 +265,11 @@ class DomainStepper:
         e, c, sz, P = self.e, self.comm, self.sz, self.world
         with self._on_stream():
             for _ in range(int(steps)):
+                self._mark(0)
                 e.dd_cube_pack(self.x1s.data_ptr())                    # X1: cube + splitters
                 c.all_gather(self.x1r, self.x1s)
                 e.dd_cube_apply(self.x1r.data_ptr())
+                self._mark(1)
                 limit, first = self.mig_stride, None                   # X2: bodies that changed owner
                 failed = None   # a rank-local failure must not strand the others inside a collective: the
                 while True:     # failing rank keeps taking part with empty payloads and marks its LET segment
@@ -260,11 +294,13 @@ class DomainStepper:
                     limit = min(self.mig_cap, max(limit, _round_up(most, 256)))
                 self.mig_last = first
                 self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 2.0 + 4096, 256)))
+                self._mark(2)
                 if failed is None:
                     e.dd_tree(self.x3s.data_ptr())                     # local sort/build/COM; X3: pieces
                 else:
                     self.x3s.zero_()
                 c.all_gather(self.x3r, self.x3s)
+                self._mark(3)
                 if failed is None and self.split:
                     e.dd_force_local(self.x3r.data_ptr())              # own pieces, side stream, overlaps X4
                 while True:
@@ -277,6 +313,7 @@ class DomainStepper:
                         raise RuntimeError(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
                     e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
                     c.all_gather(seg, self.lets[:stride * 32])          # X4: LET records, in place
+                    self._mark(4)
                     e.dd_top(self.x3r.data_ptr(), stride)
                     e.dd_force()
                     ok, counts = e.dd_let_check(stride, P)
@@ -292,7 +329,10 @@ class DomainStepper:
                     self.stride = min(self.let_cap, _round_up(need * 1.25, 256))
                 # every rank sees the same counts, so every rank picks the same next stride
                 self.stride = max(sz.let_min, min(self.let_cap, _round_up(need * 1.15 + 1024, 256)))
+                self._mark(5)
                 e.integrate()
+                self._mark(6)
+                self._close_marks()
 
     def local_state(self):
         """(ids, posm[n,4], vel[n,3], acc[n,3]) of this rank's bodies"""
