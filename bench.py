@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bodies", "--n", dest="n", type=int, default=1_000_000,
                     help="bodies per GPU (weak scaling); use --bodies under torch.distributed.run")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --bodies is the TOTAL over all GPUs (default: weak, bodies per GPU)")
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,7 +130,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    n_total = args.n * world  # weak scaling: fixed bodies per GPU
+    n_total = args.n if args.strong else args.n * world  # default weak scaling: fixed bodies per GPU
     ic = pkg.plummer(n_total, seed=args.seed)  # identical on every rank (counter-based RNG)
 
     from nbody_barnes_hut_cuda_amd import dist as bhdist
@@ -241,10 +243,10 @@ def main():
             "metric": "particles/sec/step (1M bodies per GPU, theta=0.5)",
             "value": value, "unit": "particles/s/step",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.n:,} bodies per GPU ({n_total:,} total), Plummer sphere a=400 seed {args.seed}, "
+                "workload": f"{n_total // world:,} bodies per GPU ({n_total:,} total), Plummer sphere a=400 seed {args.seed}, "
                             f"theta={args.theta}, G=0.5 eps2=50 dt=0.02, fp32, leaf_cap=1, 63-bit keys "
                             "(BASELINE.json configs[2]; x8 = configs[3])",
                 "n_total": n_total,
