@@ -197,7 +197,6 @@ int bh_n(const bh_ctx* c);
 #define BH_DD_PIECE_CAP 512          /* pieces per rank: <= 2 spines x 21 levels x 7 = 294      */
 #define BH_FLAG_DD_BODIES 16         /* local body count exceeded the context's capacity         */
 #define BH_FLAG_DD_PIECES 32         /* more than BH_DD_PIECE_CAP pieces                          */
-#define BH_FLAG_DD_LET 64            /* LET segment did not fit the stride (bh_dd_let_check)     */
 
 typedef struct bh_dd_sizes {
   int64_t x1_bytes;     /* per-rank payload of exchange X1                                       */
