@@ -41,6 +41,25 @@ def load_traffic(n, theta):
     return None
 
 
+def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=10):
+    """device-to-device copy of 1 GiB (read + write) timed with events: the practical HBM ceiling of this
+    box next to the nominal 8 TB/s"""
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    return gbs
+
+
 def load_valu_insts(n, theta):
     """VALU instructions per force launch from the committed SQ counter pass (profiles/), or None."""
     if n != 1_000_000 or abs(theta - 0.5) > 1e-6:
@@ -225,6 +244,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_alg,
                 "per_body": {"V": V / n_total, "O": O / n_total, "P": P / n_total,
                              "bytes": bytes_alg / n_total},
+                "hbm_copy_measured_GBs": measured_copy_bandwidth(torch),
                 "valu_issue_frac": (valu * 4.0 / (1024 * avg_force_ms * 1e-3 * 2.4e9)) if valu else None,
                 "limiter": "instruction issue: 26 instructions (16 VALU) per (record, wave), 57.8M such pairs on "
                            "1024 SIMDs vs a 21-29 ns memory-free microbenchmark floor of the 15-VALU body "
