@@ -13,8 +13,10 @@
 //                       from the previous step do not survive a moving cube: a boundary body that
 //                       crosses a top-level cell plane changes its key by whole octants.)
 //  X2 migration         owner(key) = #{splitter keys <= key}.  Bodies whose owner changed are
-//                       compacted into a fixed-capacity buffer; every rank picks its immigrants out
-//                       of the gathered buffers.  Scan-based, so arrival order is deterministic.
+//                       compacted into the exchange buffer (its used size follows the observed
+//                       count; a larger wave leaves in further rounds of the same step); every rank
+//                       picks its immigrants out of the gathered buffers.  Scan-based, so arrival
+//                       order is deterministic.
 //  X3 piece descriptors after the local sort/build/COM.  A local cell that does not touch either end
 //                       of the local body range is a complete global cell (its key prefix is bounded
 //                       by local bodies on both sides).  The end-touching cells form two root-to-leaf
@@ -26,8 +28,20 @@
 //                       pieces.  Records are written with pool-relative child indices, so the gathered
 //                       segments are traversable in place.
 //
-// The stitched pool [local tree | top tree | world x LET segment] is the same canonical octree a
-// single GPU builds; the unchanged force kernel traverses it from the top-tree root.
+// The stitched pool [local tree + body digests | two top trees | world x LET segment] is the same
+// canonical octree a single GPU builds; the unchanged force kernel traverses it from a top-tree root.
+//
+// Two-pass force: the own pieces (about two thirds of the work) need nothing from other ranks, so
+// bh_dd_force_local walks them on a lowest-priority side stream right after X3 — top tree #1: other
+// ranks' pieces are null records, top cells carry this rank's share of their mass — while the main
+// stream marks/exports the LET and runs X4; bh_dd_top/bh_dd_force then do the mirror image (top tree
+// #2, re-emitted from #1's structure) and bh_integrate adds the two partial accelerations.  Both
+// passes apply the same MAC to the same cells, so the split is exact up to summation order.
+//
+// Failure handling: sizes that can overflow (X2, X4) are negotiated from all-gathered counts, so every
+// rank takes the same decision; an X4 segment that does not fit is sent closed (pieces unopenable) and
+// the exchange is repeated larger; a rank-local capacity failure is announced through the X4 header
+// (dist.py) so that no rank is left waiting in a collective.
 #include <stdlib.h>
 #include <string.h>
 
