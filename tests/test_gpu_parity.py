@@ -367,3 +367,50 @@ def test_force_range_matches_full(pkg, variant):
             assert rel.max() <= 1e-4
         e2.close()
     e.close()
+
+
+def _nested_corner_ic(levels=18, S=float(2 ** 22)):
+    """Cells nested towards the MAX corner of the cube, seven two-body sibling cells per level: the
+    nested cell is the last child of every block, so a depth-first walk of the deepest bodies keeps seven
+    opened siblings pending per level — a traversal stack ~7 x levels deep."""
+    pts = []
+    for L in range(1, levels + 1):
+        h = S * 2.0 ** -L
+        for o in range(1, 8):                       # the seven octants that are not the nested one
+            c = np.array([(o >> 2) & 1, (o >> 1) & 1, o & 1], np.float64) * h + h / 2
+            pts.append(c + np.array([h / 4, 0, 0]))
+            pts.append(c - np.array([h / 4, 0, 0]))
+    h = S * 2.0 ** -(levels + 1)
+    for o in range(8):                              # the innermost cell: eight bodies
+        pts.append(np.array([(o >> 2) & 1, (o >> 1) & 1, o & 1], np.float64) * h + h / 2)
+    u = np.array(pts)
+    p = (S - u).astype(np.float32)                  # nested corner = max corner: octant 7 at every level
+    n = len(p)
+    z = np.zeros(n, np.float32)
+    return p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy(), z, z.copy(), z.copy(), np.full(n, 3.0, np.float32)
+
+
+def test_force_fast_deep_stack_falls_back_to_the_large_stack(pkg, orc):
+    """the fast kernel walks with a 64-entry stack and redoes a wave with the 192-entry one when that
+    overflows: ~7 x 18 pending entries here; the result must still match the oracle and no flag is set"""
+    ic = _nested_corner_ic()
+    n = len(ic[0])
+    e = _engine(pkg, ic, theta=0.3)   # every sibling fails s/d < 0.3 for the innermost bodies: all 7 opened
+    e.tree_stages()
+    e.force()
+    ax, ay, az = e.download_acc()
+    st = e.stats()
+    assert st.status_flags == 0 and st.max_level >= 18
+    p = oparams(orc, e.params)
+    o = oracle_pipeline(orc, ic, p)
+    oacc, *_ = orc.force(o["rec"], o["xyzm"], p, orc.ORDER_PREORDER)
+    oa = np.zeros((n, 3), np.float32)
+    oa[o["perm"]] = oacc[:, :3]
+    ga = np.stack([ax, ay, az], 1)
+    rel = np.linalg.norm(ga - oa, axis=1) / np.maximum(np.linalg.norm(oa, axis=1), 1e-30)
+    assert np.median(rel) <= 2e-6 and rel.max() <= 2e-4, (np.median(rel), rel.max())
+    # the counting kernel (3 x 64 entries) sees the same tree: every body opens at least one cell per level
+    e.force_count()
+    V, O, P = e.download_counters()
+    assert O.max() >= 7 * 17      # >= 119 opened cells on one body's walk, seven pending per level
+    e.close()
