@@ -207,7 +207,20 @@ def main():
     if not multi:
         eng.step(args.steps)   # bh_step: the C-ABI's own fused stage sequence
     else:
-        stepper.step(args.steps)
+        try:
+            stepper.step(args.steps)
+        except Exception as ex:  # noqa: BLE001 - collective by construction (see DomainStepper.step)
+            if dist_mode != "domain":
+                raise
+            fallback_reason = repr(ex)
+            print(f"[bench rank {rank}] domain-decomposed stepping failed in the timed region "
+                  f"({fallback_reason}); re-timing with the replicated scheme", file=sys.stderr, flush=True)
+            dist_mode = "replicated"
+            eng, stepper = replicated()
+            stepper.step(args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            stepper.step(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
