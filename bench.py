@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--xcd-mode", type=int, default=0, help="tuning: block->chunk placement (bh_params.xcd_mode)")
     ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
     ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
+    ap.add_argument("--force-variant", type=int, default=0,
+                    help="A/B: 0 = hand-scheduled force walk (default), 1 = compiler-scheduled walk")
     args = ap.parse_args()
 
     import numpy as np
@@ -165,7 +167,8 @@ def main():
     def replicated():
         e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
                                         xcd_mode=args.xcd_mode,
-                                        leaf_cap=args.leaf_cap, force_block=args.force_block)
+                                        leaf_cap=args.leaf_cap, force_block=args.force_block,
+                                        force_variant=args.force_variant)
         e.upload(*ic)
         return e, st
 
@@ -176,7 +179,7 @@ def main():
         try:
             stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
                                            xcd_mode=args.xcd_mode,
-                                           force_block=args.force_block)
+                                           force_block=args.force_block, force_variant=args.force_variant)
             eng = stepper.e
             stepper.step(args.warmup)
         except Exception as ex:  # noqa: BLE001

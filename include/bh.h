@@ -57,9 +57,8 @@ typedef struct bh_params {
   int32_t strict_fp;  /* 0: fast force kernel (fma + v_rsq_f32);
                          1: force arithmetic exactly as the reference source text
                             in IEEE fp32 (sqrtf, '/', no contraction; ref:203-213) */
-  int32_t force_variant; /* reserved, must be 0.  (Two alternative fast kernels — an LDS work-list kernel with
-                            batched vector loads and a restructured scalar-overhead kernel — were measured
-                            22 % and 4 % slower and removed)                              */
+  int32_t force_variant; /* fast force kernel: 0 = hand-scheduled gfx950 walk (default), 1 = the same walk
+                            as scheduled by the compiler (A/B and fallback)                */
   int32_t xcd_mode;      /* fast force kernels, block -> body-chunk placement (speed only):
                             0 = one contiguous eighth of the Morton order per XCD, 1 = identity,
                             2 = runs of 16 chunks per XCD dealt round-robin                       */
@@ -108,7 +107,10 @@ typedef struct bh_stats {
      V = cell MAC evaluations, O = opened cells, P = body-body interactions.
      SURVEY §8(d): B_alg = 24 V + 32 O + 16 P + 24 n bytes. */
   uint64_t count_V, count_O, count_P;
-  int32_t reserved[8];
+  int32_t force_redo_waves; /* fast force kernel: waves (64 bodies) since upload that redid their walk with the
+                               generic loop (cross-lane stack deeper than 64 entries, or an unsplit cell of
+                               more than 8 bodies); a speed matter only                                   */
+  int32_t reserved[7];
 } bh_stats;
 
 #define BH_FLAG_POOL_OVERFLOW 1

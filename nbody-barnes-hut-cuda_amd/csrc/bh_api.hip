@@ -103,7 +103,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   if (n < 1 || n > (1 << 30) / 2) return BH_ERR_BAD_ARG;
   if (p.key_bits != 63 && p.key_bits != 30) return BH_ERR_BAD_ARG;
   if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0 ||
-      p.force_variant != 0)
+      p.force_variant < 0 || p.force_variant > 1)
     return BH_ERR_BAD_ARG;
 
   int ndev = 0;
@@ -523,6 +523,7 @@ int bh_get_stats(bh_ctx* c, bh_stats* st) {
     for (int i = 0; i < 7; i++) BH_HIP(c, hipEventElapsedTime(ms[i], ev[i], ev[i + 1]));
     BH_HIP(c, hipEventElapsedTime(&st->ms_step, ev[0], ev[7]));
   }
+  st->force_redo_waves = hi.redo_waves;
   st->count_V = c->tV;
   st->count_O = c->tO;
   st->count_P = c->tP;

@@ -128,6 +128,7 @@ __device__ __forceinline__ void ws_pop(const WaveStack& s, int sp, int& first, i
 }
 
 constexpr int kStackCap = 192;
+constexpr int kTraversalBudget = 1 << 22;  // child blocks one wave may pop in the domain-decomposed entry
 
 struct Lane {
   float px, py, pz;
@@ -334,9 +335,10 @@ __device__ __forceinline__ void load_frec2(cfloat_t* base, int e, FRec& a, FRec&
 
 // One wave's traversal from record `root` for the lanes of m0; returns false if the cross-lane stack
 // (64 * SETS entries) overflowed, in which case ax..az are incomplete.
-template <int SETS>
+template <int SETS, bool BUDGET>
 __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, float px, float py, float pz,
-                                              float eps2, float& ax, float& ay, float& az) {
+                                              float eps2, float& ax, float& ay, float& az, int budget,
+                                              bool& limit_hit) {
   WaveStack st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int sp = 0;
   bool overflow = false;
@@ -344,6 +346,10 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   while (sp > 0) {
     int first, count;
     u64 mask;
+    if (BUDGET && --budget < 0) {  // malformed pool (cycle / runaway counts): stop, the caller flags it
+      limit_hit = true;
+      return false;
+    }
     ws_pop<SETS>(st, --sp, first, count, mask);
     int k0 = 0;
     do {  // count >= 1 for every stack entry
@@ -366,11 +372,196 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   return !overflow;
 }
 
+// ------------------------------------------------------------------ hand-scheduled traversal
+// The same walk as fast_traverse<1>, written as one block of gfx950 assembly.  Two measured limits shape it
+// (tools/ubench_issue.hip, profiles/r02_ubench): a SIMD issues at most one instruction per ~2.2 cycles
+// whatever the unit (SALU and VALU of different waves do not co-issue), and one wave's DEPENDENT VALU
+// instructions issue only every ~4 cycles however many waves are resident.
+//   * the entry's lane mask is loaded into EXEC once per child block, so inactive lanes need no take-mask
+//     (`s_and` per record gone) and `s_andn2_b64 open, exec, accept` yields the open mask AND, in SCC,
+//     whether it is empty (`s_cmp_eq_u64` per record gone);
+//   * a child block is always fetched as the 8 records from its first (4 x s_load_dwordx16 into s[36:99])
+//     and evaluated LAST CHILD FIRST by a computed jump (s_setpc_b64) into the unrolled chain: no per-record
+//     count test, no loop counter (the pool is padded by 8 records, so the window stays inside the allocation);
+//   * the push arm is out of line; stack overflow and "child count > 8" are recorded with one s_max each
+//     and judged once, after the walk (the caller then redoes the wave with the generic loop).
+// Per record: 15 VALU + s_andn2 + s_cbranch.  Per block: 4 v_readlane, 4 s_load, 11 SALU/branch.
+// Per push: 4 v_writelane + 5 SALU/branch.  v_readlane/v_writelane ignore EXEC.
+// Children are evaluated in descending order (the reference pops its stack 7..0 too, ref:217-219).
+// Software pipeline: the 15 VALU of one record form a dependency chain, and a SIMD issues a wave's DEPENDENT
+// VALU instructions only every ~4 cycles however many waves are resident (tools/ubench_issue.hip: 4.3 vs 2.5
+// cycles per instruction, dependent vs independent).  So record k's force half (7 VALU) is interleaved,
+// instruction by instruction, with record k-1's MAC half (8 VALU): two independent chains per wave.
+// Even records use register set "e" (accept mask s[18:19]), odd records set "o" (s[14:15]).
+//   PRO(j)  = MAC(j); s_branch SEG(j)            entry for a block of j+1 children (computed jump)
+//   SEG(k)  = FORCE(k) || MAC(k-1), k = 7..1;    SEG(0) = FORCE(0)
+#define BH_V(n, s) "%[" n s "]"
+#define BH_MAC(T, j, ms, MM, X, Y, Z, THR)                                                  \
+  "v_sub_f32 " BH_V("dx", ms) ", " X ", %[px]\n"                                         \
+  "v_sub_f32 " BH_V("dy", ms) ", " Y ", %[py]\n"                                         \
+  "v_sub_f32 " BH_V("dz", ms) ", " Z ", %[pz]\n"                                         \
+  "v_fma_f32 " BH_V("d2", ms) ", " BH_V("dx", ms) ", " BH_V("dx", ms) ", %[eps2]\n"      \
+  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dy", ms) ", " BH_V("dy", ms) "\n"              \
+  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dz", ms) ", " BH_V("dz", ms) "\n"              \
+  "v_cmp_lt_f32_e64 " MM ", " THR ", " BH_V("d2", ms) "\n"                               \
+  "v_rsq_f32 " BH_V("t", ms) ", " BH_V("d2", ms) "\n"                                    \
+  "s_andn2_b64 s[26:27], exec, " MM "\n"                                                 \
+  "s_cbranch_scc1 L_push" T #j "_%=\n"                                                   \
+  "L_back" T #j "_%=:\n"
+#define BH_PRO(j, ms, MM, X, Y, Z, THR)                                                  \
+  "L_pro" #j "_%=:\n" BH_MAC("P", j, ms, MM, X, Y, Z, THR) "s_branch L_seg" #j "_%=\n"
+// FORCE(k) on set fs (mask FM, G*m in GM) interleaved with MAC(j = k-1) on set ms
+#define BH_SEG(k, j, fs, FM, GM, ms, MM, X, Y, Z, THR)                                   \
+  "L_seg" #k "_%=:\n"                                                                    \
+  "v_sub_f32 " BH_V("dx", ms) ", " X ", %[px]\n"                                         \
+  "v_mul_f32 " BH_V("d2", fs) ", " GM ", " BH_V("t", fs) "\n"                            \
+  "v_sub_f32 " BH_V("dy", ms) ", " Y ", %[py]\n"                                         \
+  "v_mul_f32 " BH_V("t", fs) ", " BH_V("t", fs) ", " BH_V("t", fs) "\n"                  \
+  "v_sub_f32 " BH_V("dz", ms) ", " Z ", %[pz]\n"                                         \
+  "v_mul_f32 " BH_V("t", fs) ", " BH_V("d2", fs) ", " BH_V("t", fs) "\n"                 \
+  "v_fma_f32 " BH_V("d2", ms) ", " BH_V("dx", ms) ", " BH_V("dx", ms) ", %[eps2]\n"      \
+  "v_cndmask_b32_e64 " BH_V("t", fs) ", 0, " BH_V("t", fs) ", " FM "\n"                  \
+  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dy", ms) ", " BH_V("dy", ms) "\n"              \
+  "v_fmac_f32 %[ax], " BH_V("t", fs) ", " BH_V("dx", fs) "\n"                            \
+  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dz", ms) ", " BH_V("dz", ms) "\n"              \
+  "v_fmac_f32 %[ay], " BH_V("t", fs) ", " BH_V("dy", fs) "\n"                            \
+  "v_cmp_lt_f32_e64 " MM ", " THR ", " BH_V("d2", ms) "\n"                               \
+  "v_fmac_f32 %[az], " BH_V("t", fs) ", " BH_V("dz", fs) "\n"                            \
+  "v_rsq_f32 " BH_V("t", ms) ", " BH_V("d2", ms) "\n"                                    \
+  "s_andn2_b64 s[26:27], exec, " MM "\n"                                                 \
+  "s_cbranch_scc1 L_pushS" #j "_%=\n"                                                    \
+  "L_backS" #j "_%=:\n"
+#define BH_SEG_LAST(fs, FM, GM)                                                          \
+  "L_seg0_%=:\n"                                                                         \
+  "v_mul_f32 " BH_V("d2", fs) ", " GM ", " BH_V("t", fs) "\n"                            \
+  "v_mul_f32 " BH_V("t", fs) ", " BH_V("t", fs) ", " BH_V("t", fs) "\n"                  \
+  "v_mul_f32 " BH_V("t", fs) ", " BH_V("d2", fs) ", " BH_V("t", fs) "\n"                 \
+  "v_cndmask_b32_e64 " BH_V("t", fs) ", 0, " BH_V("t", fs) ", " FM "\n"                  \
+  "v_fmac_f32 %[ax], " BH_V("t", fs) ", " BH_V("dx", fs) "\n"                            \
+  "v_fmac_f32 %[ay], " BH_V("t", fs) ", " BH_V("dy", fs) "\n"                            \
+  "v_fmac_f32 %[az], " BH_V("t", fs) ", " BH_V("dz", fs) "\n"
+#define BH_PUSH_REGS(T, k, FIRST, META)                                                  \
+  "L_push" T #k "_%=:\n"                                                                 \
+  "s_mov_b32 m0, s30\n"                                                                  \
+  "s_add_u32 s30, s30, 1\n"                                                              \
+  "s_max_u32 s31, s31, s30\n"                                                            \
+  "s_max_u32 s16, s16, " META "\n"                                                       \
+  "v_writelane_b32 %[ka], " FIRST ", m0\n"                                               \
+  "v_writelane_b32 %[kb], " META ", m0\n"                                                \
+  "v_writelane_b32 %[kl], s26, m0\n"                                                     \
+  "v_writelane_b32 %[kh], s27, m0\n"                                                     \
+  "s_branch L_back" T #k "_%=\n"
+// slot k of the record window = s[36+8k .. 43+8k] = x, y, z, gm, thr2, first, meta, pad
+#define BH_ME "s[18:19]"
+#define BH_MO "s[14:15]"
+#define BH_PRO_ALL                                                                       \
+  BH_PRO(7, "o", BH_MO, "s92", "s93", "s94", "s96") BH_PRO(6, "e", BH_ME, "s84", "s85", "s86", "s88") \
+  BH_PRO(5, "o", BH_MO, "s76", "s77", "s78", "s80") BH_PRO(4, "e", BH_ME, "s68", "s69", "s70", "s72") \
+  BH_PRO(3, "o", BH_MO, "s60", "s61", "s62", "s64") BH_PRO(2, "e", BH_ME, "s52", "s53", "s54", "s56") \
+  BH_PRO(1, "o", BH_MO, "s44", "s45", "s46", "s48") BH_PRO(0, "e", BH_ME, "s36", "s37", "s38", "s40")
+#define BH_SEG_ALL                                                                       \
+  BH_SEG(7, 6, "o", BH_MO, "s95", "e", BH_ME, "s84", "s85", "s86", "s88")                \
+  BH_SEG(6, 5, "e", BH_ME, "s87", "o", BH_MO, "s76", "s77", "s78", "s80")                \
+  BH_SEG(5, 4, "o", BH_MO, "s79", "e", BH_ME, "s68", "s69", "s70", "s72")                \
+  BH_SEG(4, 3, "e", BH_ME, "s71", "o", BH_MO, "s60", "s61", "s62", "s64")                \
+  BH_SEG(3, 2, "o", BH_MO, "s63", "e", BH_ME, "s52", "s53", "s54", "s56")                \
+  BH_SEG(2, 1, "e", BH_ME, "s55", "o", BH_MO, "s44", "s45", "s46", "s48")                \
+  BH_SEG(1, 0, "o", BH_MO, "s47", "e", BH_ME, "s36", "s37", "s38", "s40")                \
+  BH_SEG_LAST("e", BH_ME, "s39")
+#define BH_PUSH_SET(T)                                                                   \
+  BH_PUSH_REGS(T, 0, "s41", "s42") BH_PUSH_REGS(T, 1, "s49", "s50") BH_PUSH_REGS(T, 2, "s57", "s58") \
+  BH_PUSH_REGS(T, 3, "s65", "s66") BH_PUSH_REGS(T, 4, "s73", "s74") BH_PUSH_REGS(T, 5, "s81", "s82") \
+  BH_PUSH_REGS(T, 6, "s89", "s90")
+// record 7 is only ever the first of a block: its MAC exists in PRO(7) alone
+#define BH_PUSH_ALL BH_PUSH_SET("P") BH_PUSH_REGS("P", 7, "s97", "s98") BH_PUSH_SET("S")
+
+// Returns false if the 64-entry cross-lane stack overflowed or a block with more than 8 children was met
+// (unsplit cell of > 8 bodies); ax..az are then invalid and the caller redoes the wave.
+// BUDGET > 0: at most that many child blocks are popped (a malformed pool cannot hang the wave); the
+// walk then stops and *limit_hit is set.
+template <bool BUDGET>
+__device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u64 m0, float px, float py,
+                                                  float pz, float eps2, float& ax, float& ay, float& az,
+                                                  int budget, bool& limit_hit) {
+  float dxe, dye, dze, d2e, te, dxo, dyo, dzo, d2o, to;
+  int ka = 0, kb = 0, kl = 0, kh = 0;
+  int maxsp, maxc, left;
+  asm volatile(
+      "s_mov_b64 s[28:29], exec\n"
+      "s_mov_b64 s[20:21], %[base]\n"
+      "s_getpc_b64 s[22:23]\n"
+      "L_here_%=:\n"
+      "s_add_u32 s22, s22, L_proend_%=-L_here_%=\n"
+      "s_addc_u32 s23, s23, 0\n"
+      "s_mov_b32 s30, 0\n"
+      "s_mov_b32 s31, 0\n"
+      "s_mov_b32 s16, 0\n"
+      "s_mov_b32 s17, %[budget]\n"
+      "s_lshl_b32 s32, %[root], 5\n"
+      "s_mov_b32 s33, 1\n"
+      "s_mov_b64 s[34:35], %[mask]\n"
+      "s_branch L_block_%=\n"
+      "L_pop_%=:\n"
+      "s_sub_u32 s30, s30, 1\n"
+      "s_cbranch_scc1 L_done_%=\n"
+      "v_readlane_b32 s32, %[ka], s30\n"
+      "v_readlane_b32 s33, %[kb], s30\n"
+      "v_readlane_b32 s34, %[kl], s30\n"
+      "v_readlane_b32 s35, %[kh], s30\n"
+      "s_lshl_b32 s32, s32, 5\n"
+      "L_block_%=:\n"
+      "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"
+      "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"
+      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
+      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
+      ".if %c[use_budget]\n"
+      "s_sub_u32 s17, s17, 1\n"
+      "s_cbranch_scc1 L_done_%=\n"
+      ".endif\n"
+      "s_min_u32 s33, s33, 8\n"
+      "s_mul_i32 s33, s33, (L_proend_%=-L_pro7_%=)/8\n"
+      "s_sub_u32 s24, s22, s33\n"
+      "s_subb_u32 s25, s23, 0\n"
+      "s_mov_b64 exec, s[34:35]\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_setpc_b64 s[24:25]\n"
+      BH_PRO_ALL
+      "L_proend_%=:\n"  // a block of 0 children (never built; a clamped garbage count): nothing to evaluate
+      "s_branch L_pop_%=\n"
+      BH_SEG_ALL
+      "s_branch L_pop_%=\n"
+      BH_PUSH_ALL
+      "L_done_%=:\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_mov_b64 exec, s[28:29]\n"
+      "s_mov_b32 %[maxsp], s31\n"
+      "s_mov_b32 %[maxc], s16\n"
+      "s_mov_b32 %[left], s17\n"
+      : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [dxe] "=&v"(dxe), [dye] "=&v"(dye), [dze] "=&v"(dze),
+        [d2e] "=&v"(d2e), [te] "=&v"(te), [dxo] "=&v"(dxo), [dyo] "=&v"(dyo), [dzo] "=&v"(dzo),
+        [d2o] "=&v"(d2o), [to] "=&v"(to), [ka] "+v"(ka), [kb] "+v"(kb), [kl] "+v"(kl), [kh] "+v"(kh),
+        [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left)
+      : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
+        [eps2] "s"(eps2), [budget] "s"(budget), [use_budget] "n"(BUDGET ? 1 : 0)
+      : "memory", "vcc", "scc", "m0", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29",
+        "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44",
+        "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
+        "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74",
+        "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
+        "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+  limit_hit = BUDGET && left < 0;
+  return maxsp <= 64 && maxc <= 8;
+}
+
+// VARIANT 0: hand-scheduled walk (fast_traverse_asm); 1: the compiler-scheduled walk (A/B, bh_params.force_variant).
+// BUDGET: bound the number of child blocks a wave may pop (domain-decomposed entry: the pool holds records
+// written by other ranks, and a malformed pool must end in BH_FLAG_TRAVERSAL_LIMIT, not in a hang).
+template <int VARIANT, bool BUDGET>
 __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict__ frec_g,
                                                          const float4* __restrict__ posm,
                                                          float4* __restrict__ acc, int lo, int hi, float G,
                                                          float eps2, int xcd_mode,
-                                                         bh_devinfo* __restrict__ info, int root) {
+                                                         bh_devinfo* __restrict__ info, int root, int budget) {
   cfloat_t* frec = (cfloat_t*)frec_g;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
@@ -389,11 +580,19 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   if (m0 == 0) return;
   // 64 stack entries (one VGPR set, no set-select branches) cover every tree seen in practice; the
   // rare wave that needs more redoes its walk with the 192-entry stack (>= the 7*21+1 bound)
-  if (!fast_traverse<1>(frec, root, m0, px, py, pz, eps2, ax, ay, az)) {
+  bool ok, limit = false;
+  if (VARIANT == 0)
+    ok = fast_traverse_asm<BUDGET>(frec_g, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit);
+  else
+    ok = fast_traverse<1, BUDGET>(frec, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit);
+  if (!ok && !limit) {
     ax = ay = az = 0.0f;
-    if (!fast_traverse<3>(frec, root, m0, px, py, pz, eps2, ax, ay, az) && lane == 0)
+    if (lane == 0) atomicAdd(&info->redo_waves, 1);
+    if (!fast_traverse<3, BUDGET>(frec, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit) && !limit &&
+        lane == 0)
       atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
   }
+  if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
 }
 
@@ -553,8 +752,16 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
       int g2 = (hi - lo + tpb - 1) / tpb;
       if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
-      force_fast_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2, mode, c->info,
-                                                 0);
+      static const bool debug_budget = getenv("BH_FORCE_BUDGET") != nullptr;  // bring-up aid: bounded walk
+      if (debug_budget)
+        force_fast_kernel<0, true><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
+                                                              mode, c->info, 0, kTraversalBudget);
+      else if (c->p.force_variant == 1)
+        force_fast_kernel<1, false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
+                                                               mode, c->info, 0, 0);
+      else
+        force_fast_kernel<0, false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
+                                                               mode, c->info, 0, 0);
     }
   }
   return hipGetLastError();
@@ -568,8 +775,15 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
   const int mode = c->p.xcd_mode == 2 ? 0 : c->p.xcd_mode;
   const int g2 = (hi - lo + tpb - 1) / tpb;
-  force_fast_kernel<<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
-                                          c->p.eps2, mode, c->info, root);
+  // a wave pops one child block per opened cell: no wave of a well-formed pool can pop more blocks than
+  // the pool has records, so this bound never fires on valid data and always ends a walk over a cycle
+  const int budget = kTraversalBudget;
+  if (c->p.force_variant == 1)
+    force_fast_kernel<1, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
+                                                       c->p.eps2, mode, c->info, root, budget);
+  else
+    force_fast_kernel<0, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
+                                                       c->p.eps2, mode, c->info, root, budget);
   return hipGetLastError();
 }
 

@@ -40,6 +40,8 @@ struct bh_devinfo {
   int n_entries;   // E
   int max_level;
   int flags;       // BH_FLAG_*
+  int redo_waves;  // force waves that redid their walk with the generic loop (stack > 64 entries or a block of > 8 children)
+  int pad[3];
 };
 
 struct bh_ctx {

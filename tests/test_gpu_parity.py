@@ -186,10 +186,10 @@ def test_force_strict_edge_cases(pkg, orc, name):
     e.close()
 
 
-@pytest.mark.parametrize("variant", [0])
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("name", ["coincident", "collinear", "outlier", "pairs", "tiny", "grid", "zero_mass"])
 def test_force_fast_edge_cases(pkg, orc, name, variant):
-    """both fast kernels (0 = scalar depth-first, 1 = batched LDS work list) on the edge inputs,
+    """both fast kernels (0 = hand-scheduled walk, 1 = compiler-scheduled walk) on the edge inputs,
     incl. deep multi-body leaves (coincident) and mass<=0 records; tolerance as below"""
     ic = special_ics(name, 777, np.random.default_rng(1))
     e = _engine(pkg, ic, force_variant=variant)
@@ -222,12 +222,12 @@ def test_force_block_sizes_agree(pkg, orc, theta):
     assert np.array_equal(acc[0], acc[1]) and np.array_equal(acc[0], acc[2])
 
 
-def test_force_variant_is_reserved(pkg):
+def test_force_variant_out_of_range(pkg):
     with pytest.raises(Exception):
-        pkg.Engine(1000, force_variant=1)
+        pkg.Engine(1000, force_variant=2)
 
 
-@pytest.mark.parametrize("variant", [0])
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("n,theta", [(4096, 0.5), (65536, 0.5), (65536, 0.3)])
 def test_force_fast_vs_oracle(pkg, orc, n, theta, variant):
     """Default (fast) kernel: fma + v_rsq_f32 instead of sqrtf and '/'.  Stated fp32 tolerance:
