@@ -78,11 +78,15 @@ typedef struct bh_params {
 /* One 32-byte octree record ("entry").  The tree is an array of entries:
  * entry 0 is the root; the children of an internal entry are the `count`
  * consecutive entries starting at `first` (ascending octant digit, empty
- * octants omitted).  Replaces `struct OctreeNode` (ref:20-28, 76 B). */
+ * octants omitted); `first` is always even (BH_KIND_PAD entries fill the gaps).
+ * Replaces `struct OctreeNode` (ref:20-28, 76 B). */
 #define BH_KIND_BODY 0     /* exactly one body: (x,y,z,m) is the body, s = 0, first = sorted body index */
 #define BH_KIND_INTERNAL 1 /* subdivided cell: first/count = child block                               */
 #define BH_KIND_MULTI 2    /* unsplit cell holding `count` > 1 bodies [first, first+count) of the
                               Morton-sorted body array (depth-capped or leaf_cap > 1)                  */
+#define BH_KIND_PAD 3      /* padding entry (all fields zero): child blocks start at EVEN entries (64-byte
+                              boundaries), so entry 1 and the entry after every block of an odd number of
+                              children are padding; no record refers to them                           */
 typedef struct bh_node {
   float x, y, z;  /* centre of mass (ref:22 comX..Z after finalizeCOM ref:175-189) */
   float m;        /* total mass (ref:21)                                           */
@@ -96,7 +100,7 @@ typedef struct bh_node {
 typedef struct bh_stats {
   int32_t n;               /* bodies                                               */
   int32_t n_internal;      /* subdivided cells ( = reference nodeCounter intent, ref:109) */
-  int32_t n_entries;       /* tree records in use (root + all children)            */
+  int32_t n_entries;       /* tree entries in use (root + all children + padding)   */
   int32_t max_level;       /* deepest internal level + 1                           */
   int32_t status_flags;    /* device-side sticky error bits (BH_FLAG_*)            */
   int32_t steps;           /* bh_step calls since upload                           */

@@ -135,7 +135,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   }
 
   const size_t N = (size_t)n;
-  c->rec_cap = 2 * n + 8;
+  c->rec_cap = BH_REC_CAP(n);
   c->sort_tiles = (n + BH_SORT_TILE - 1) / BH_SORT_TILE;
   // scans run over n (+1) ints, 256*sort_tiles ints and n fp64 quadruples
   size_t scan_n = N + 1;
@@ -167,7 +167,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->cb, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->rec, (size_t)c->rec_cap) == hipSuccess;
-  ok = ok && dalloc(&c->frec, (size_t)c->rec_cap + N + 8) == hipSuccess;  // tree digests + body digests
+  ok = ok && dalloc(&c->frec, BH_FREC_POOL(c->rec_cap, N)) == hipSuccess;  // tree digests + body digests
   ok = ok && dalloc(&c->er_lo, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->er_hi, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->P, N + 1) == hipSuccess;
@@ -185,7 +185,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   }
   // the record pool is read up to 3 records past a child block (force kernel): keep it defined
   if (hipMemsetAsync(c->rec, 0, (size_t)c->rec_cap * sizeof(bh_node), c->stream) != hipSuccess ||
-      hipMemsetAsync(c->frec, 0, ((size_t)c->rec_cap + N + 8) * sizeof(bh_frec), c->stream) != hipSuccess ||
+      hipMemsetAsync(c->frec, 0, BH_FREC_POOL(c->rec_cap, N) * sizeof(bh_frec), c->stream) != hipSuccess ||
       hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream) != hipSuccess ||
       hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream) != hipSuccess) {
     free_all(c);

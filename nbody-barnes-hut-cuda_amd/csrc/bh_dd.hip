@@ -103,6 +103,11 @@ namespace {
 constexpr int kB = 21;
 constexpr int kTopMax = 4096;  // pieces in the whole system
 constexpr int kDescPerRank = 1 + BH_DD_PIECE_CAP;
+// X4 segment: record 0 header, records 1 .. PIECE_CAP the pieces' own records, one padding record, then the
+// exported child blocks from an EVEN record on (digest pairs: bh_internal.h)
+constexpr int kSegBlocks0 = 2 + BH_DD_PIECE_CAP;
+static_assert(kSegBlocks0 % 2 == 0, "child blocks start at even records");
+constexpr int kTopCap = 4 * 4096 + 8;  // records of one top tree incl. padding (kTopMax pieces)
 
 constexpr int kSampTotal = 4096;  // position samples in the whole system (sorted in LDS: 32 KiB)
 __host__ __device__ inline int samp_cap_of(int world) { return kSampTotal / world; }
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
     bool cand = false;
     bh_frec r;
     if (e < E) {
-      r = frec[e];
+      r = frec_get(frec, e);
       cand = r.thr2 * 1.0001f >= eps2;  // implies thr2 >= 0: an openable, massive cell
     }
     if (cand) {
@@ -539,8 +544,10 @@ __device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restric
   return fr;
 }
 
-// send[0] header, send[1 .. PIECE_CAP] the pieces' own records, then the child blocks in scan order.
-// Child indices are pool indices of the receiving side: seg0 = pool index of this rank's segment.
+// send[0] header, send[1 .. PIECE_CAP] the pieces' own records, one padding record, then the child blocks
+// in scan order, each at an even record (dst = scan of the counts rounded up to even), an odd block
+// followed by a null digest.  Child indices are pool indices of the receiving side: seg0 = pool index of
+// this rank's segment (even).
 __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restrict__ frec,
                                                         int rec_cap,
                                                         const int* __restrict__ w, const int* __restrict__ dst,
@@ -548,33 +555,35 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
                                                         const int* __restrict__ ddi, int seg0, int stride,
                                                         bh_frec* __restrict__ send) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int blocks0 = seg0 + 1 + BH_DD_PIECE_CAP;
+  const int blocks0 = seg0 + kSegBlocks0;
   const int np = ddi[8];
   if (e == 0) {
-    bh_frec h;
-    memset(&h, 0, sizeof(h));
-    h.first = 1 + BH_DD_PIECE_CAP + dst[rec_cap];  // records this rank needs (may exceed stride)
+    bh_frec h = frec_null();
+    h.thr2 = 0.0f;
+    h.first = kSegBlocks0 + dst[rec_cap];  // records this rank needs (may exceed stride)
     h.meta = np;
-    send[0] = h;
+    frec_put(send, 0, h);
+    frec_put(send, 1 + BH_DD_PIECE_CAP, frec_null());
   }
   // a segment that does not fit is sent closed: its pieces are made unopenable, so the (discarded)
   // force pass that runs before the host sees the header never walks unwritten records
-  const bool fits = 1 + BH_DD_PIECE_CAP + dst[rec_cap] <= stride;
+  const bool fits = kSegBlocks0 + dst[rec_cap] <= stride;
   if (e < BH_DD_PIECE_CAP) {
-    bh_frec fr;
-    memset(&fr, 0, sizeof(fr));
-    if (e < np) fr = reloc(frec[piece_idx[e]], piece_idx[e], w, dst, blocks0, rec_cap);
+    bh_frec fr = frec_null();
+    if (e < np) fr = reloc(frec_get(frec, piece_idx[e]), piece_idx[e], w, dst, blocks0, rec_cap);
     if (!fits) fr.thr2 = -1.0f;
-    send[1 + e] = fr;
+    frec_put(send, 1 + e, fr);
   }
   if (e >= rec_cap || !fits) return;
   const int wv = w[e];
   if (wv == 0) return;
-  const int off = 1 + BH_DD_PIECE_CAP + dst[e];
+  const int off = kSegBlocks0 + dst[e];
   if (off + wv > stride) return;  // does not fit: the header tells the host to repeat with more room
-  const bh_frec fr = frec[e];
+  const bh_frec fr = frec_get(frec, e);
   // children of a cell, or the body digests of an unsplit multi-body cell: one kind of block
-  for (int k = 0; k < wv; k++) send[off + k] = reloc(frec[fr.first + k], fr.first + k, w, dst, blocks0, rec_cap);
+  for (int k = 0; k < wv; k++)
+    frec_put(send, off + k, reloc(frec_get(frec, fr.first + k), fr.first + k, w, dst, blocks0, rec_cap));
+  if ((wv & 1) && off + wv < stride) frec_put(send, off + wv, frec_null());
 }
 
 // ------------------------------------------------------------------ top tree
@@ -627,18 +636,10 @@ __device__ __forceinline__ bh_frec top_piece_record(const bh_dd_piece* __restric
                                                     const bh_frec* __restrict__ pool, int seg_base, int stride,
                                                     int side) {
   const bh_dd_piece d = g[slot];
-  if ((side == 1 && d.owner != me) || (side == 2 && d.owner == me)) {
-    bh_frec z;
-    z.x = z.y = z.z = z.gm = 0.0f;
-    z.thr2 = -1.0f;
-    z.first = 0;
-    z.meta = 1;
-    z.pad = 0;
-    return z;
-  }
-  if (d.owner == me) return pool[d.rec_idx];
+  if ((side == 1 && d.owner != me) || (side == 2 && d.owner == me)) return frec_null();
+  if (d.owner == me) return frec_get(pool, d.rec_idx);
   const int k = slot - d.owner * kDescPerRank - 1;
-  return pool[(size_t)seg_base + (size_t)d.owner * stride + 1 + k];
+  return frec_get(pool, (long long)seg_base + (long long)d.owner * stride + 1 + k);
 }
 
 // Per-level bitmasks over the piece boundaries (row v+1: bit p set iff d[p] <= v): nearest-smaller
@@ -707,16 +708,19 @@ __global__ __launch_bounds__(256) void dd_top_emit_kernel(const bh_dd_piece* __r
                                                           const int* __restrict__ cc0, const int* __restrict__ cc1,
                                                           const int4* __restrict__ ci, const int* __restrict__ ddi,
                                                           int side) {
+  // e = position in the top tree: 0 the root, 1 padding, 2 + s the child slots (blocks at even positions)
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e > ddi[3]) return;
   const int4 c = ci[e];
   bh_frec fr;
-  if (c.x < 0)
+  if (c.x == -2)
+    fr = frec_null();
+  else if (c.x < 0)
     fr = top_piece_record(g, c.y, me, pool, seg_base, stride, side);
   else
-    fr = top_cell_record(ps, e == 0 ? 0 : cc0[e - 1], e == 0 ? ddi[2] : cc1[e - 1], c.x, top_base + c.y, c.z,
+    fr = top_cell_record(ps, e == 0 ? 0 : cc0[e - 2], e == 0 ? ddi[2] : cc1[e - 2], c.x, top_base + c.y, c.z,
                          bounds[6], G, theta, side);
-  pool[top_base + e] = fr;
+  frec_put(pool, top_base + e, fr);
 }
 
 __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restrict__ g, int world, int me,
@@ -828,11 +832,11 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
     }
     if (j < T) {
       pn[j] = (unsigned char)nc;
-      cb[j] = nc;
+      cb[j] = (nc + 1) & ~1;  // child blocks start at even positions: an odd block is followed by padding
     }
   }
   __syncthreads();
-  const int nchild = top_scan_i32(cb, T, wsum);
+  const int nslots = top_scan_i32(cb, T, wsum);
   // every representative lists the piece ranges of its children; then ONE THREAD PER CHILD builds the
   // record, so the dependent global loads (descriptor -> piece record) of all children overlap
 #pragma unroll
@@ -852,19 +856,23 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
       const int nx = tm_next(mle, c0, nw);
       c1 = (nx < 0 || nx > b) ? b : nx;
     }
+    if (pn[j] & 1) cc0[e] = cc1[e] = -1;  // padding slot
   }
   __syncthreads();
   const float s0 = bounds[6];
   if (tid == 0) {
     ddi[2] = T;
-    ddi[3] = nchild;
+    ddi[3] = 1 + nslots;  // last position of the top tree
   }
-  for (int e = tid; e <= nchild; e += 1024) {  // record 0 = the root, record 1 + k = child k
-    const int c0 = e == 0 ? 0 : cc0[e - 1];
-    const int c1 = e == 0 ? T : cc1[e - 1];
+  for (int e = tid; e <= 1 + nslots; e += 1024) {  // position 0 = the root, 1 = padding, 2 + s = child slot s
+    const int c0 = e == 0 ? 0 : (e == 1 ? -1 : cc0[e - 2]);
+    const int c1 = e == 0 ? T : (e == 1 ? -1 : cc1[e - 2]);
     bh_frec fr;
     int4 info4;
-    if (c1 - c0 == 1) {
+    if (c0 < 0) {
+      fr = frec_null();
+      info4 = make_int4(-2, 0, 0, 0);
+    } else if (c1 - c0 == 1) {
       fr = top_piece_record(g, tslot[c0], me, pool, seg_base, stride, side);
       info4 = make_int4(-1, tslot[c0], 0, 0);
     } else {  // the cell branches at the first lowest boundary strictly inside the range: the smallest
@@ -878,10 +886,10 @@ __global__ __launch_bounds__(1024) void dd_top_kernel(const bh_dd_piece* __restr
           break;
         }
       }
-      fr = top_cell_record(ps, c0, c1, Lb, top_base + 1 + cb[l], (int)pn[l], s0, G, theta, side);
-      info4 = make_int4(Lb, 1 + cb[l], (int)pn[l], 0);
+      fr = top_cell_record(ps, c0, c1, Lb, top_base + 2 + cb[l], (int)pn[l], s0, G, theta, side);
+      info4 = make_int4(Lb, 2 + cb[l], (int)pn[l], 0);
     }
-    pool[top_base + e] = fr;
+    frec_put(pool, top_base + e, fr);
     ci[e] = info4;
   }
 }
@@ -940,10 +948,11 @@ extern "C" {
 
 int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) {
   if (!o || n_cap < 1 || world < 1 || world > 64 || mig_cap < 1) return BH_ERR_BAD_ARG;
-  const long long let_min = 1 + BH_DD_PIECE_CAP;
-  if (let_cap < let_min) return BH_ERR_BAD_ARG;
-  const long long rec_cap = 2LL * n_cap + 8 + n_cap + 8;  // tree digests + body digests (bh_internal.h)
-  const long long top_cap = 2LL * kTopMax + 8;
+  const long long let_min = kSegBlocks0;
+  if (let_cap < let_min || (let_cap & 1)) return BH_ERR_BAD_ARG;  // segments hold whole digest pairs
+  long long rec_cap = (long long)BH_FREC_POOL(BH_REC_CAP((long long)n_cap), n_cap);  // tree + body digests
+  rec_cap += rec_cap & 1;
+  const long long top_cap = kTopCap;
   o->x1_bytes = (int64_t)x1_floats(world) * 4;
   o->x2_bytes = 32 + 32LL * mig_cap;
   o->x3_bytes = (int64_t)sizeof(bh_dd_piece) * kDescPerRank;
@@ -979,7 +988,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   d->pool = (bh_frec*)pool;
   d->pool_records = pool_records;
   d->top_base = (int)sz.top_base;
-  d->top_base2 = (int)sz.top_base + 2 * kTopMax + 8;
+  d->top_base2 = (int)sz.top_base + kTopCap;
   d->seg_base = (int)sz.seg_base;
   size_t fl = (size_t)n_cap;
   if ((size_t)world * mig_cap > fl) fl = (size_t)world * mig_cap;
@@ -996,9 +1005,9 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->boxes, (size_t)world * BH_DD_PIECE_CAP * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->rbox, (size_t)2 * 64 * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->top_ps, 2 * ((size_t)kTopMax + 1) * sizeof(top5)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_a, 2 * ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_b, 2 * ((size_t)2 * kTopMax + 8) * 4) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->top_ci, 2 * ((size_t)2 * kTopMax + 8) * sizeof(int4)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_a, 2 * (size_t)kTopCap * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_b, 2 * (size_t)kTopCap * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->top_ci, 2 * (size_t)kTopCap * sizeof(int4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->acc2, ((size_t)n_cap + 64) * sizeof(float4)) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_x3, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_own, hipEventDisableTiming) == hipSuccess;
@@ -1028,7 +1037,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
 int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const float* z, const float* vx,
                  const float* vy, const float* vz, const float* m, const int32_t* ids) {
   if (!c || !c->dd || !x || !y || !z || !vx || !vy || !vz || !m || !ids) return BH_ERR_BAD_ARG;
-  const int n_cap = (c->rec_cap - 8) / 2;
+  const int n_cap = (c->rec_cap - 8) / 3;
   if (n_loc < 1 || n_loc > n_cap) return BH_ERR_BAD_ARG;
   BH_HIP(c, hipSetDevice(c->device));
   dd_set_n(c, n_loc);
@@ -1103,7 +1112,7 @@ int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_lo
   const float4* g = (const float4*)gathered_x2;
   const size_t f4 = 2 + 2 * (size_t)limit;
   const int slots = d->world * limit;
-  const int n_cap = (c->rec_cap - 8) / 2;
+  const int n_cap = (c->rec_cap - 8) / 3;
   dd_nloc_init_kernel<<<1, 64, 0, c->stream>>>(g, d->world, f4, d->nloc);
   dd_absorb_flag_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, c->bounds, d->skeys,
                                                                     d->rank, d->flag, d->nloc);
@@ -1151,14 +1160,14 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
   if (!c || !c->dd || !gathered_x3 || !send_x4) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
-  if (stride < 1 + BH_DD_PIECE_CAP || stride > d->let_cap) return BH_ERR_BAD_ARG;
+  if (stride < kSegBlocks0 || stride > d->let_cap || (stride & 1)) return BH_ERR_BAD_ARG;
   dd_boxes_kernel<<<d->world, 256, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, c->bounds,
                                                    d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;
   dd_mark_kernel<<<(c->rec_cap + kMarkChunk) / kMarkChunk, 256, 0, c->stream>>>(
       c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w);
   BH_HIP(c, hipGetLastError());
-  BH_HIP(c, bhk_scan_i32(c, d->w, d->dst, c->rec_cap, nullptr));
+  BH_HIP(c, bhk_scan_i32_even(c, d->w, d->dst, c->rec_cap));  // exported blocks start at even records
   dd_export_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->rec_cap, d->w, d->dst,
                                                   d->piece_idx, d->ddi, d->seg_base + d->rank * stride, stride,
                                                   (bh_frec*)send_x4);
@@ -1178,9 +1187,9 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
   BH_HIP(c, hipEventRecord(d->ev_x3, c->stream));  // the X3 gather and the local tree are complete here
   BH_HIP(c, hipStreamWaitEvent(d->stream_own, d->ev_x3, 0));
   dd_top_kernel<<<1, 1024, 0, d->stream_own>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
-                                            d->top_base2, d->seg_base, 1 + BH_DD_PIECE_CAP, c->bounds, c->p.G,
-                                            c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + (2 * kTopMax + 8),
-                                            d->top_b + (2 * kTopMax + 8), d->top_ci + (2 * kTopMax + 8), d->ddi,
+                                            d->top_base2, d->seg_base, kSegBlocks0, c->bounds, c->p.G,
+                                            c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + kTopCap,
+                                            d->top_b + kTopCap, d->top_ci + kTopCap, d->ddi,
                                             c->info, 1);
   BH_HIP(c, hipGetLastError());
   BH_HIP(c, hipEventRecord(d->ev_top1, d->stream_own));  // the remote pass re-emits from this tree's scratch
@@ -1193,18 +1202,20 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
   if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
-  if (stride < 1 + BH_DD_PIECE_CAP || stride > d->let_cap) return BH_ERR_BAD_ARG;
+  if (stride < kSegBlocks0 || stride > d->let_cap || (stride & 1)) return BH_ERR_BAD_ARG;
   // the segment headers (records each rank needed) go to the host for bh_dd_let_check
-  BH_HIP(c, hipMemcpy2DAsync(d->host, sizeof(int), &d->pool[d->seg_base].first, (size_t)stride * sizeof(bh_frec),
-                             sizeof(int), (size_t)d->world, hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(c, hipMemcpy2DAsync(d->host, sizeof(int),
+                             reinterpret_cast<const int*>(d->pool) + BH_FREC_DW(d->seg_base, BH_FF_FIRST),
+                             (size_t)stride * sizeof(bh_frec), sizeof(int), (size_t)d->world,
+                             hipMemcpyDeviceToHost, c->stream));
   BH_HIP(c, hipEventRecord(d->ev_let, c->stream));
   d->let_copy_pending = true;
   if (d->split) {  // same structure as the own pass's tree: re-emit the records only
     BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_top1, 0));
-    dd_top_emit_kernel<<<(2 * kTopMax + 1 + 255) / 256, 256, 0, c->stream>>>(
+    dd_top_emit_kernel<<<(kTopCap + 255) / 256, 256, 0, c->stream>>>(
         (const bh_dd_piece*)gathered_x3, d->rank, d->pool, d->top_base, d->seg_base, stride, c->bounds, c->p.G,
-        c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + (2 * kTopMax + 8), d->top_b + (2 * kTopMax + 8),
-        d->top_ci + (2 * kTopMax + 8), d->ddi, 2);
+        c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + kTopCap, d->top_b + kTopCap,
+        d->top_ci + kTopCap, d->ddi, 2);
   } else {
     dd_top_kernel<<<1, 1024, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
                                              d->top_base, d->seg_base, stride, c->bounds, c->p.G, c->p.theta,

@@ -296,17 +296,18 @@ typedef __attribute__((address_space(4))) const float16_t cfloat16_t;
 
 // two consecutive records with one s_load_dwordx16
 typedef __attribute__((address_space(4))) const char cchar_t;
+// records e (even) and e + 1 = one 64-byte pair of the digest pool (bh_internal.h: fields interleaved)
 __device__ __forceinline__ void load_frec2(cfloat_t* base, int e, FRec& a, FRec& b) {
   // 32-bit unsigned byte offset: selects the SGPR-offset form of s_load (no 64-bit address
   // arithmetic per block); the launcher guarantees pool bytes < 4 GiB for this kernel
   const u32 off = (u32)e << 5;
   const float16_t v = *(cfloat16_t*)((cchar_t*)base + off);
-  a.x = v[0]; a.y = v[1]; a.z = v[2]; a.gm = v[3]; a.thr2 = v[4];
-  a.first = __float_as_int(v[5]);
-  a.meta = __float_as_int(v[6]);
-  b.x = v[8]; b.y = v[9]; b.z = v[10]; b.gm = v[11]; b.thr2 = v[12];
-  b.first = __float_as_int(v[13]);
-  b.meta = __float_as_int(v[14]);
+  a.x = v[0]; a.y = v[2]; a.z = v[4]; a.gm = v[6]; a.thr2 = v[8];
+  a.first = __float_as_int(v[10]);
+  a.meta = __float_as_int(v[12]);
+  b.x = v[1]; b.y = v[3]; b.z = v[5]; b.gm = v[7]; b.thr2 = v[9];
+  b.first = __float_as_int(v[11]);
+  b.meta = __float_as_int(v[13]);
 }
 
 #define BH_FAST_EVAL(R)                                                                  \
@@ -373,126 +374,118 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 }
 
 // ------------------------------------------------------------------ hand-scheduled traversal
-// The same walk as fast_traverse<1>, written as one block of gfx950 assembly.  Two measured limits shape it
-// (tools/ubench_issue.hip, profiles/r02_ubench): a SIMD issues at most one instruction per ~2.2 cycles
-// whatever the unit (SALU and VALU of different waves do not co-issue), and one wave's DEPENDENT VALU
-// instructions issue only every ~4 cycles however many waves are resident.
-//   * the entry's lane mask is loaded into EXEC once per child block, so inactive lanes need no take-mask
-//     (`s_and` per record gone) and `s_andn2_b64 open, exec, accept` yields the open mask AND, in SCC,
-//     whether it is empty (`s_cmp_eq_u64` per record gone);
-//   * a child block is always fetched as the 8 records from its first (4 x s_load_dwordx16 into s[36:99])
-//     and evaluated LAST CHILD FIRST by a computed jump (s_setpc_b64) into the unrolled chain: no per-record
-//     count test, no loop counter (the pool is padded by 8 records, so the window stays inside the allocation);
-//   * the push arm is out of line; stack overflow and "child count > 8" are recorded with one s_max each
-//     and judged once, after the walk (the caller then redoes the wave with the generic loop).
-// Per record: 15 VALU + s_andn2 + s_cbranch.  Per block: 4 v_readlane, 4 s_load, 11 SALU/branch.
+// The same walk as fast_traverse<1>, written as one block of gfx950 assembly.  What shapes it (measured:
+// tools/ubench_issue.hip, tools/ubench_forms.hip, tools/ubench_smem.hip, profiles/r02_ubench):
+//   * the kernel is bound by VALU issue, and the issue cost of a VALU instruction depends on its FORM: only
+//     two-source all-VGPR VOP2 runs at the full rate (2.3 cycles per wave64 instruction); anything with an
+//     SGPR operand, three sources, an SGPR result (v_cmp) or a mask operand costs 3.5-4 cycles, v_rsq 6.9 —
+//     and so does a PACKED fp32 instruction (v_pk_add/mul/fma_f32), which does the work of two.  The record
+//     chain (x - px, ... with the record in SGPRs) is all slow forms: 58 cycles per record.  Evaluating the
+//     two records of a digest pair (bh_internal.h: fields interleaved, so each field pair is an aligned SGPR
+//     pair) with packed instructions costs 37 cycles per record;
+//   * the entry's lane mask is loaded into EXEC once per child block, so inactive lanes need no take-mask and
+//     `s_andn2_b64 open, exec, accept` yields the open mask AND, in SCC, whether it is empty;
+//   * lanes that open a record must not take its monopole: only the path that pushed (16 % of the records)
+//     runs the variant of the force half with the two v_cndmask;
+//   * a child block is fetched as up to 4 pairs (s_load_dwordx16 each, 64-byte aligned: blocks start at even
+//     records) BEFORE anything else, two loads if it has <= 4 children, and evaluated LAST PAIR FIRST by a
+//     computed jump (entry offsets in the lanes of a VGPR, indexed by the child count): no per-record count
+//     test, no loop counter.  A block of an odd number of children ends in a null record (gm 0, thr2 -1);
+//   * stack overflow and "child count > 8" are recorded with one s_max each and judged once, after the walk
+//     (the caller then redoes the wave with the generic loop).
+// Per pair: 16 VALU + 2 x (s_andn2 + s_cbranch).  Per block: 5 v_readlane, <= 4 s_load, 10 SALU/branch.
 // Per push: 4 v_writelane + 5 SALU/branch.  v_readlane/v_writelane ignore EXEC.
-// Children are evaluated in descending order (the reference pops its stack 7..0 too, ref:217-219).
-// Software pipeline: the 15 VALU of one record form a dependency chain, and a SIMD issues a wave's DEPENDENT
-// VALU instructions only every ~4 cycles however many waves are resident (tools/ubench_issue.hip: 4.3 vs 2.5
-// cycles per instruction, dependent vs independent).  So record k's force half (7 VALU) is interleaved,
-// instruction by instruction, with record k-1's MAC half (8 VALU): two independent chains per wave.
-// Even records use register set "e" (accept mask s[18:19]), odd records set "o" (s[14:15]).
-//   PRO(j)  = MAC(j); s_branch SEG(j)            entry for a block of j+1 children (computed jump)
-//   SEG(k)  = FORCE(k) || MAC(k-1), k = 7..1;    SEG(0) = FORCE(0)
-#define BH_V(n, s) "%[" n s "]"
-#define BH_MAC(T, j, ms, MM, X, Y, Z, THR)                                                  \
-  "v_sub_f32 " BH_V("dx", ms) ", " X ", %[px]\n"                                         \
-  "v_sub_f32 " BH_V("dy", ms) ", " Y ", %[py]\n"                                         \
-  "v_sub_f32 " BH_V("dz", ms) ", " Z ", %[pz]\n"                                         \
-  "v_fma_f32 " BH_V("d2", ms) ", " BH_V("dx", ms) ", " BH_V("dx", ms) ", %[eps2]\n"      \
-  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dy", ms) ", " BH_V("dy", ms) "\n"              \
-  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dz", ms) ", " BH_V("dz", ms) "\n"              \
-  "v_cmp_lt_f32_e64 " MM ", " THR ", " BH_V("d2", ms) "\n"                               \
-  "v_rsq_f32 " BH_V("t", ms) ", " BH_V("d2", ms) "\n"                                    \
-  "s_andn2_b64 s[26:27], exec, " MM "\n"                                                 \
-  "s_cbranch_scc1 L_push" T #j "_%=\n"                                                   \
-  "L_back" T #j "_%=:\n"
-#define BH_PRO(j, ms, MM, X, Y, Z, THR)                                                  \
-  "L_pro" #j "_%=:\n" BH_MAC("P", j, ms, MM, X, Y, Z, THR) "s_branch L_seg" #j "_%=\n"
-// FORCE(k) on set fs (mask FM, G*m in GM) interleaved with MAC(j = k-1) on set ms
-#define BH_SEG(k, j, fs, FM, GM, ms, MM, X, Y, Z, THR)                                   \
-  "L_seg" #k "_%=:\n"                                                                    \
-  "v_sub_f32 " BH_V("dx", ms) ", " X ", %[px]\n"                                         \
-  "v_mul_f32 " BH_V("d2", fs) ", " GM ", " BH_V("t", fs) "\n"                            \
-  "v_sub_f32 " BH_V("dy", ms) ", " Y ", %[py]\n"                                         \
-  "v_mul_f32 " BH_V("t", fs) ", " BH_V("t", fs) ", " BH_V("t", fs) "\n"                  \
-  "v_sub_f32 " BH_V("dz", ms) ", " Z ", %[pz]\n"                                         \
-  "v_mul_f32 " BH_V("t", fs) ", " BH_V("d2", fs) ", " BH_V("t", fs) "\n"                 \
-  "v_fma_f32 " BH_V("d2", ms) ", " BH_V("dx", ms) ", " BH_V("dx", ms) ", %[eps2]\n"      \
-  "v_cndmask_b32_e64 " BH_V("t", fs) ", 0, " BH_V("t", fs) ", " FM "\n"                  \
-  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dy", ms) ", " BH_V("dy", ms) "\n"              \
-  "v_fmac_f32 %[ax], " BH_V("t", fs) ", " BH_V("dx", fs) "\n"                            \
-  "v_fmac_f32 " BH_V("d2", ms) ", " BH_V("dz", ms) ", " BH_V("dz", ms) "\n"              \
-  "v_fmac_f32 %[ay], " BH_V("t", fs) ", " BH_V("dy", fs) "\n"                            \
-  "v_cmp_lt_f32_e64 " MM ", " THR ", " BH_V("d2", ms) "\n"                               \
-  "v_fmac_f32 %[az], " BH_V("t", fs) ", " BH_V("dz", fs) "\n"                            \
-  "v_rsq_f32 " BH_V("t", ms) ", " BH_V("d2", ms) "\n"                                    \
-  "s_andn2_b64 s[26:27], exec, " MM "\n"                                                 \
-  "s_cbranch_scc1 L_pushS" #j "_%=\n"                                                    \
-  "L_backS" #j "_%=:\n"
-#define BH_SEG_LAST(fs, FM, GM)                                                          \
-  "L_seg0_%=:\n"                                                                         \
-  "v_mul_f32 " BH_V("d2", fs) ", " GM ", " BH_V("t", fs) "\n"                            \
-  "v_mul_f32 " BH_V("t", fs) ", " BH_V("t", fs) ", " BH_V("t", fs) "\n"                  \
-  "v_mul_f32 " BH_V("t", fs) ", " BH_V("d2", fs) ", " BH_V("t", fs) "\n"                 \
-  "v_cndmask_b32_e64 " BH_V("t", fs) ", 0, " BH_V("t", fs) ", " FM "\n"                  \
-  "v_fmac_f32 %[ax], " BH_V("t", fs) ", " BH_V("dx", fs) "\n"                            \
-  "v_fmac_f32 %[ay], " BH_V("t", fs) ", " BH_V("dy", fs) "\n"                            \
-  "v_fmac_f32 %[az], " BH_V("t", fs) ", " BH_V("dz", fs) "\n"
-#define BH_PUSH_REGS(T, k, FIRST, META)                                                  \
-  "L_push" T #k "_%=:\n"                                                                 \
-  "s_mov_b32 m0, s30\n"                                                                  \
-  "s_add_u32 s30, s30, 1\n"                                                              \
-  "s_max_u32 s31, s31, s30\n"                                                            \
-  "s_max_u32 s16, s16, " META "\n"                                                       \
-  "v_writelane_b32 %[ka], " FIRST ", m0\n"                                               \
-  "v_writelane_b32 %[kb], " META ", m0\n"                                                \
-  "v_writelane_b32 %[kl], s26, m0\n"                                                     \
-  "v_writelane_b32 %[kh], s27, m0\n"                                                     \
-  "s_branch L_back" T #k "_%=\n"
-// slot k of the record window = s[36+8k .. 43+8k] = x, y, z, gm, thr2, first, meta, pad
-#define BH_ME "s[18:19]"
-#define BH_MO "s[14:15]"
-#define BH_PRO_ALL                                                                       \
-  BH_PRO(7, "o", BH_MO, "s92", "s93", "s94", "s96") BH_PRO(6, "e", BH_ME, "s84", "s85", "s86", "s88") \
-  BH_PRO(5, "o", BH_MO, "s76", "s77", "s78", "s80") BH_PRO(4, "e", BH_ME, "s68", "s69", "s70", "s72") \
-  BH_PRO(3, "o", BH_MO, "s60", "s61", "s62", "s64") BH_PRO(2, "e", BH_ME, "s52", "s53", "s54", "s56") \
-  BH_PRO(1, "o", BH_MO, "s44", "s45", "s46", "s48") BH_PRO(0, "e", BH_ME, "s36", "s37", "s38", "s40")
-#define BH_SEG_ALL                                                                       \
-  BH_SEG(7, 6, "o", BH_MO, "s95", "e", BH_ME, "s84", "s85", "s86", "s88")                \
-  BH_SEG(6, 5, "e", BH_ME, "s87", "o", BH_MO, "s76", "s77", "s78", "s80")                \
-  BH_SEG(5, 4, "o", BH_MO, "s79", "e", BH_ME, "s68", "s69", "s70", "s72")                \
-  BH_SEG(4, 3, "e", BH_ME, "s71", "o", BH_MO, "s60", "s61", "s62", "s64")                \
-  BH_SEG(3, 2, "o", BH_MO, "s63", "e", BH_ME, "s52", "s53", "s54", "s56")                \
-  BH_SEG(2, 1, "e", BH_ME, "s55", "o", BH_MO, "s44", "s45", "s46", "s48")                \
-  BH_SEG(1, 0, "o", BH_MO, "s47", "e", BH_ME, "s36", "s37", "s38", "s40")                \
-  BH_SEG_LAST("e", BH_ME, "s39")
-#define BH_PUSH_SET(T)                                                                   \
-  BH_PUSH_REGS(T, 0, "s41", "s42") BH_PUSH_REGS(T, 1, "s49", "s50") BH_PUSH_REGS(T, 2, "s57", "s58") \
-  BH_PUSH_REGS(T, 3, "s65", "s66") BH_PUSH_REGS(T, 4, "s73", "s74") BH_PUSH_REGS(T, 5, "s81", "s82") \
-  BH_PUSH_REGS(T, 6, "s89", "s90")
-// record 7 is only ever the first of a block: its MAC exists in PRO(7) alone
-#define BH_PUSH_ALL BH_PUSH_SET("P") BH_PUSH_REGS("P", 7, "s97", "s98") BH_PUSH_SET("S")
+// Fixed registers inside the block: s[36:99] record window (pair p at s[36+16p..]), s14-s35 state;
+// v[32:33] = (px,py), v[34:35] = (pz,-), v[36:37] = (eps2,eps2), v[38:43] d, v[44:45] d2, v[46:47] rinv,
+// v[48:49] f, v[50:55] six partial accumulators, v56-v59 cross-lane stack, v60 jump table.
+#define BH_PAIR_MAC(p, X, Y, Z, THR0, THR1)                                                              \
+  "L_seg" #p "_%=:\n"                                                                                     \
+  "v_pk_add_f32 v[38:39], " X ", v[32:33] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                    \
+  "v_pk_add_f32 v[40:41], " Y ", v[32:33] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"       \
+  "v_pk_add_f32 v[42:43], " Z ", v[34:35] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                    \
+  "v_pk_fma_f32 v[44:45], v[38:39], v[38:39], v[36:37]\n"                                                 \
+  "v_pk_fma_f32 v[44:45], v[40:41], v[40:41], v[44:45]\n"                                                 \
+  "v_pk_fma_f32 v[44:45], v[42:43], v[42:43], v[44:45]\n"                                                 \
+  "v_cmp_lt_f32_e64 s[18:19], " THR0 ", v44\n"                                                            \
+  "v_cmp_lt_f32_e64 s[14:15], " THR1 ", v45\n"                                                            \
+  "v_rsq_f32 v46, v44\n"                                                                                  \
+  "v_rsq_f32 v47, v45\n"                                                                                  \
+  "s_andn2_b64 s[26:27], exec, s[18:19]\n"                                                                \
+  "s_cbranch_scc1 L_pushA" #p "_%=\n"                                                                     \
+  "s_andn2_b64 s[26:27], exec, s[14:15]\n"                                                                \
+  "s_cbranch_scc1 L_pushB" #p "_%=\n"
+#define BH_PAIR_F1(GM)                                                                                   \
+  "v_pk_mul_f32 v[48:49], " GM ", v[46:47]\n"                                                             \
+  "v_pk_mul_f32 v[46:47], v[46:47], v[46:47]\n"                                                           \
+  "v_pk_mul_f32 v[48:49], v[48:49], v[46:47]\n"
+#define BH_PAIR_F2                                                                                       \
+  "v_pk_fma_f32 v[50:51], v[48:49], v[38:39], v[50:51]\n"                                                 \
+  "v_pk_fma_f32 v[52:53], v[48:49], v[40:41], v[52:53]\n"                                                 \
+  "v_pk_fma_f32 v[54:55], v[48:49], v[42:43], v[54:55]\n"
+#define BH_PAIR_SEG(p, X, Y, Z, GM, THR0, THR1) BH_PAIR_MAC(p, X, Y, Z, THR0, THR1) BH_PAIR_F1(GM) BH_PAIR_F2
+#define BH_PUSH1(FIRST, META)                                                                            \
+  "s_mov_b32 m0, s30\n"                                                                                   \
+  "s_add_u32 s30, s30, 1\n"                                                                               \
+  "s_max_u32 s31, s31, s30\n"                                                                             \
+  "s_max_u32 s16, s16, " META "\n"                                                                        \
+  "v_writelane_b32 v56, " FIRST ", m0\n"                                                                  \
+  "v_writelane_b32 v57, " META ", m0\n"                                                                   \
+  "v_writelane_b32 v58, s26, m0\n"                                                                        \
+  "v_writelane_b32 v59, s27, m0\n"
+// the path of a pair with at least one opened record: pushes, then the force half with the take masks
+#define BH_PAIR_ARMS(p, NEXT, GM, F0, M0, F1, M1)                                                        \
+  "L_pushA" #p "_%=:\n" BH_PUSH1(F0, M0)                                                                  \
+  "s_andn2_b64 s[26:27], exec, s[14:15]\n"                                                                \
+  "s_cbranch_scc0 L_masked" #p "_%=\n"                                                                    \
+  "L_pushB" #p "_%=:\n" BH_PUSH1(F1, M1)                                                                  \
+  "L_masked" #p "_%=:\n" BH_PAIR_F1(GM)                                                                   \
+  "v_cndmask_b32_e64 v48, 0, v48, s[18:19]\n"                                                             \
+  "v_cndmask_b32_e64 v49, 0, v49, s[14:15]\n" BH_PAIR_F2                                                  \
+  "s_branch " NEXT "\n"
+// pair p of the window: x s[36+16p:37+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11, meta +12/+13
+#define BH_SEG_ALL                                                                                       \
+  BH_PAIR_SEG(3, "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s92", "s93")                            \
+  BH_PAIR_SEG(2, "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", "s76", "s77")                            \
+  BH_PAIR_SEG(1, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", "s60", "s61")                            \
+  BH_PAIR_SEG(0, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "s44", "s45")
+#define BH_ARMS_ALL                                                                                      \
+  BH_PAIR_ARMS(3, "L_seg2_%=", "s[90:91]", "s94", "s96", "s95", "s97")                                    \
+  BH_PAIR_ARMS(2, "L_seg1_%=", "s[74:75]", "s78", "s80", "s79", "s81")                                    \
+  BH_PAIR_ARMS(1, "L_seg0_%=", "s[58:59]", "s62", "s64", "s63", "s65")                                    \
+  BH_PAIR_ARMS(0, "L_pop_%=", "s[42:43]", "s46", "s48", "s47", "s49")
+// jump table in the lanes of v60: lane c = entry offset (from L_seg3) of a block of c children; lanes >= 8
+// keep 0 = the 4-pair entry (such a block also trips the "> 8 children" redo); read with one v_readlane
+#define BH_TBL(c, L) "s_mov_b32 s33, " L "-L_seg3_%=\n v_writelane_b32 v60, s33, " #c "\n"
+#define BH_TBL_ALL                                                                                       \
+  "v_mov_b32 v60, 0\n"                                                                                    \
+  BH_TBL(0, "L_end_%=") BH_TBL(1, "L_seg0_%=") BH_TBL(2, "L_seg0_%=") BH_TBL(3, "L_seg1_%=")               \
+  BH_TBL(4, "L_seg1_%=") BH_TBL(5, "L_seg2_%=") BH_TBL(6, "L_seg2_%=")
 
 // Returns false if the 64-entry cross-lane stack overflowed or a block with more than 8 children was met
 // (unsplit cell of > 8 bodies); ax..az are then invalid and the caller redoes the wave.
-// BUDGET > 0: at most that many child blocks are popped (a malformed pool cannot hang the wave); the
-// walk then stops and *limit_hit is set.
+// BUDGET: at most `budget` child blocks are popped (a malformed pool cannot hang the wave); the walk then
+// stops and limit_hit is set.  `root` must be an even record index.
 template <bool BUDGET>
 __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u64 m0, float px, float py,
                                                   float pz, float eps2, float& ax, float& ay, float& az,
                                                   int budget, bool& limit_hit) {
-  float dxe, dye, dze, d2e, te, dxo, dyo, dzo, d2o, to;
-  int ka = 0, kb = 0, kl = 0, kh = 0;
   int maxsp, maxc, left;
   asm volatile(
       "s_mov_b64 s[28:29], exec\n"
       "s_mov_b64 s[20:21], %[base]\n"
+      "v_mov_b32 v32, %[px]\n"
+      "v_mov_b32 v33, %[py]\n"
+      "v_mov_b32 v34, %[pz]\n"
+      "v_mov_b32 v35, 0\n"
+      "v_mov_b32 v36, %[eps2]\n"
+      "v_mov_b32 v37, %[eps2]\n"
+      "v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n v_mov_b32 v52, 0\n v_mov_b32 v53, 0\n v_mov_b32 v54, 0\n v_mov_b32 v55, 0\n"
+      "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"
       "s_getpc_b64 s[22:23]\n"
       "L_here_%=:\n"
-      "s_add_u32 s22, s22, L_proend_%=-L_here_%=\n"
+      "s_add_u32 s22, s22, L_seg3_%=-L_here_%=\n"
       "s_addc_u32 s23, s23, 0\n"
+      BH_TBL_ALL
       "s_mov_b32 s30, 0\n"
       "s_mov_b32 s31, 0\n"
       "s_mov_b32 s16, 0\n"
@@ -504,51 +497,53 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "L_pop_%=:\n"
       "s_sub_u32 s30, s30, 1\n"
       "s_cbranch_scc1 L_done_%=\n"
-      "v_readlane_b32 s32, %[ka], s30\n"
-      "v_readlane_b32 s33, %[kb], s30\n"
-      "v_readlane_b32 s34, %[kl], s30\n"
-      "v_readlane_b32 s35, %[kh], s30\n"
+      "v_readlane_b32 s33, v57, s30\n"  // the count first: it is the lane select of the table read below,
+      "v_readlane_b32 s32, v56, s30\n"  // which must come >= 4 instructions after the VALU write of it
+      "v_readlane_b32 s34, v58, s30\n"
+      "v_readlane_b32 s35, v59, s30\n"
       "s_lshl_b32 s32, s32, 5\n"
       "L_block_%=:\n"
-      "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"
-      "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"
-      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
-      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
       ".if %c[use_budget]\n"
       "s_sub_u32 s17, s17, 1\n"
       "s_cbranch_scc1 L_done_%=\n"
       ".endif\n"
-      "s_min_u32 s33, s33, 8\n"
-      "s_mul_i32 s33, s33, (L_proend_%=-L_pro7_%=)/8\n"
-      "s_sub_u32 s24, s22, s33\n"
-      "s_subb_u32 s25, s23, 0\n"
+      "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"
+      "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"
+      "s_cmp_gt_u32 s33, 4\n"
+      "s_cbranch_scc0 L_small_%=\n"
+      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
+      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
+      "L_small_%=:\n"
+      "v_readlane_b32 s33, v60, s33\n"
       "s_mov_b64 exec, s[34:35]\n"
+      "s_add_u32 s24, s22, s33\n"
+      "s_addc_u32 s25, s23, 0\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_setpc_b64 s[24:25]\n"
-      BH_PRO_ALL
-      "L_proend_%=:\n"  // a block of 0 children (never built; a clamped garbage count): nothing to evaluate
-      "s_branch L_pop_%=\n"
       BH_SEG_ALL
+      "L_end_%=:\n"  // also the entry of a block of 0 children (never built; every table offset is >= 0)
       "s_branch L_pop_%=\n"
-      BH_PUSH_ALL
+      BH_ARMS_ALL
       "L_done_%=:\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_mov_b64 exec, s[28:29]\n"
+      "v_add_f32 %[ax], v50, v51\n"
+      "v_add_f32 %[ay], v52, v53\n"
+      "v_add_f32 %[az], v54, v55\n"
       "s_mov_b32 %[maxsp], s31\n"
       "s_mov_b32 %[maxc], s16\n"
       "s_mov_b32 %[left], s17\n"
-      : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [dxe] "=&v"(dxe), [dye] "=&v"(dye), [dze] "=&v"(dze),
-        [d2e] "=&v"(d2e), [te] "=&v"(te), [dxo] "=&v"(dxo), [dyo] "=&v"(dyo), [dzo] "=&v"(dzo),
-        [d2o] "=&v"(d2o), [to] "=&v"(to), [ka] "+v"(ka), [kb] "+v"(kb), [kl] "+v"(kl), [kh] "+v"(kh),
-        [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left)
+      : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left)
       : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
         [eps2] "s"(eps2), [budget] "s"(budget), [use_budget] "n"(BUDGET ? 1 : 0)
-      : "memory", "vcc", "scc", "m0", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29",
-        "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44",
-        "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
-        "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74",
-        "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
-        "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+      : "memory", "vcc", "scc", "m0", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25",
+        "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41",
+        "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",
+        "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
+        "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
+        "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v32", "v33", "v34", "v35", "v36", "v37",
+        "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+        "v54", "v55", "v56", "v57", "v58", "v59", "v60");
   limit_hit = BUDGET && left < 0;
   return maxsp <= 64 && maxc <= 8;
 }
@@ -742,7 +737,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
     else {
       const int mode = c->p.xcd_mode;
       // the frec pool = tree digests + one digest slot per body (bh_internal.h)
-      if ((long long)c->rec_cap + c->n + 8 >= (1ll << 27)) {
+      if ((long long)BH_FREC_POOL(c->rec_cap, c->n) >= (1ll << 27)) {
         // the fast kernel addresses records with 32-bit byte offsets (pool < 4 GiB, ~44M bodies):
         // beyond that the generic kernel does the same arithmetic on the canonical records
         force_kernel<false, false><<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, th, e2, nullptr, nullptr, nullptr, c->info);

@@ -9,15 +9,51 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-// fast-kernel record: same block layout as bh_node, fields pre-digested by the COM stage
+// fast-kernel record ("digest"), written by the COM stage.  LOGICAL fields:
 struct bh_frec {
   float x, y, z;  // centre of mass
   float gm;       // G*m, 0 when m <= 0
   float thr2;     // (s/theta)^2; -1 for a body or a mass<=0 record (always accepted)
-  int first;      // child block; body index for a body; rec_cap + first body for an unsplit multi-body cell
+  int first;      // child block; body index for a body; digest slot of the first body for an unsplit multi-body cell
   int meta;       // child count (bodies of an unsplit cell count as its children)
   int pad;
 };
+// PHYSICAL layout of a digest pool: records 2p and 2p+1 share one 64-byte PAIR, fields interleaved
+//   dword  0 1 | 2 3 | 4 5 | 6  7  | 8    9    | 10     11     | 12    13    | 14 15
+//          x0 x1 y0 y1 z0 z1 gm0 gm1 thr0 thr1   first0 first1   meta0 meta1   pad
+// so one s_load_dwordx16 brings two records with every field of the two in an adjacent, even-aligned SGPR
+// pair — the operand shape of the packed fp32 VALU instructions (v_pk_add/mul/fma_f32), which cost the
+// same issue time as ONE scalar-operand fp32 instruction but evaluate both records (tools/ubench_forms.hip).
+// Child blocks start at even record indices, so a block is a whole number of pairs; a block with an odd
+// number of children ends in a NULL record (gm = 0, thr2 = -1: accepted by every body with zero force).
+// A pool pointer is typed bh_frec* (32 bytes per record) but must only be dereferenced through these accessors.
+#define BH_FREC_DW(e, field) ((size_t)((e) >> 1) * 16 + (size_t)(field) * 2 + ((e) & 1))
+enum { BH_FF_X = 0, BH_FF_Y, BH_FF_Z, BH_FF_GM, BH_FF_THR2, BH_FF_FIRST, BH_FF_META, BH_FF_PAD };
+__host__ __device__ __forceinline__ bh_frec frec_get(const bh_frec* pool, long long e) {
+  const float* f = reinterpret_cast<const float*>(pool) + (size_t)(e >> 1) * 16 + (e & 1);
+  const int* i = reinterpret_cast<const int*>(f);
+  bh_frec r;
+  r.x = f[0]; r.y = f[2]; r.z = f[4]; r.gm = f[6]; r.thr2 = f[8];
+  r.first = i[10]; r.meta = i[12]; r.pad = i[14];
+  return r;
+}
+__host__ __device__ __forceinline__ void frec_put(bh_frec* pool, long long e, const bh_frec& r) {
+  float* f = reinterpret_cast<float*>(pool) + (size_t)(e >> 1) * 16 + (e & 1);
+  int* i = reinterpret_cast<int*>(f);
+  f[0] = r.x; f[2] = r.y; f[4] = r.z; f[6] = r.gm; f[8] = r.thr2;
+  i[10] = r.first; i[12] = r.meta; i[14] = r.pad;
+}
+__host__ __device__ __forceinline__ bh_frec frec_null() {
+  bh_frec z;
+  z.x = z.y = z.z = z.gm = 0.0f;
+  z.thr2 = -1.0f;
+  z.first = 0; z.meta = 0; z.pad = 0;
+  return z;
+}
+// digest slot of body b of the unsplit multi-body cell whose first body is lo: the cell's bodies form a child
+// block, which must start at an even slot; the ranges [2 lo, 2 hi) of different cells do not overlap
+#define BH_BODY_DIGEST(rec_cap, lo, b) ((rec_cap) + 2 * (lo) + ((b) - (lo)))
+#define BH_FREC_POOL(rec_cap, n) ((size_t)(rec_cap) + 2 * (size_t)(n) + 8)  // tree digests + body digests + window pad
 
 struct bh_d4 {  // fp64 prefix-sum element: (sum m, sum m*x, sum m*y, sum m*z)
   double m, x, y, z;
@@ -90,8 +126,8 @@ struct bh_ctx {
   int* pn;        // [n] its child count (0: j represents no emitted cell)
   int* cb;        // [n+1] exclusive scan of pn; cb[n] = records - 1
   bh_node* rec;   // [rec_cap] tree records (canonical: ABI download, strict/counting kernels)
-  bh_frec* frec;  // [rec_cap + n] digests for the fast force kernel (written by COM): tree records, then
-                  // one slot per sorted body (used only for the bodies of unsplit multi-body cells)
+  bh_frec* frec;  // [BH_FREC_POOL] digests for the fast force kernel (written by COM, pair layout): tree records,
+                  // then BH_BODY_DIGEST slots (used only for the bodies of unsplit multi-body cells)
   int* er_lo;     // [rec_cap] body range of each record
   int* er_hi;
   int rec_cap;
@@ -120,6 +156,12 @@ struct bh_ctx {
   long timed_steps;    // steps recorded into the ring since timing was switched on
 };
 
+// Record layout: entry 0 = root, entry 1 = padding, child blocks start at EVEN entries (a block of an odd
+// number of children is followed by one padding entry), so a block never straddles more 64-byte lines than
+// it has to: the force kernel's scalar loads are bound by the number of cache-line requests.
+// Entries <= root + bodies + cells + one pad per cell <= 3n.
+#define BH_REC_CAP(n) (3 * (n) + 8)
+#define BH_BLOCK0 2  // first child block
 #define BH_FORCE_BLOCK_DEFAULT 256
 #define BH_BBOX_BLOCKS 1024
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
@@ -145,6 +187,7 @@ void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 
 // device-wide scans (bh_scan.hip)
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);
+hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out /* n+1 */, int n);  // of (in[i]+1)&~1
 hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n, bool side);
 hipError_t bhk_com_records(bh_ctx* c);  // second half of bhk_com: records from the prefix sums
 size_t bhk_scan_tmp_bytes(int n);

@@ -43,6 +43,10 @@ struct LoadI32 {
   const int* p;
   __device__ __forceinline__ int operator()(int i) const { return p[i]; }
 };
+struct LoadI32Even {  // child counts rounded up to even: child blocks start on 64-byte boundaries
+  const int* p;
+  __device__ __forceinline__ int operator()(int i) const { return (p[i] + 1) & ~1; }
+};
 struct LoadPM {  // body i -> (m, m x, m y, m z) in fp64; the products of two fp32 are exact in fp64
   const float4* posm;
   __device__ __forceinline__ bh_d4 operator()(int i) const {
@@ -172,6 +176,10 @@ size_t bhk_scan_tmp_bytes(int n) {
 
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out, int n, const int* n_dev) {
   return run_scan<OpI32>(c->stream, c->scan_tmp, LoadI32{in}, out, n, n_dev);
+}
+
+hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out, int n) {
+  return run_scan<OpI32>(c->stream, c->scan_tmp, LoadI32Even{in}, out, n, nullptr);
 }
 
 // side = true: run on the context's side stream with its own scratch (bh_step overlaps this scan,

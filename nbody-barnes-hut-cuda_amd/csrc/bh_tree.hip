@@ -467,7 +467,7 @@ __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, 
     }
   }
   r.kind = BH_KIND_INTERNAL;
-  r.first = 1 + cb[l];
+  r.first = BH_BLOCK0 + cb[l];
   r.count = pn[l];
   r.s = ldexpf(s0, -Lb);
   return r;
@@ -508,9 +508,17 @@ __device__ __forceinline__ bh_node make_child_win(u64 (*m)[kPairWords], int base
     return r;
   }
   r.kind = BH_KIND_INTERNAL;
-  r.first = 1 + cb[base + jr];
+  r.first = BH_BLOCK0 + cb[base + jr];
   r.count = pn[base + jr];
   r.s = ldexpf(s0, -Lb);
+  return r;
+}
+
+__device__ __forceinline__ bh_node pad_entry() {
+  bh_node r;
+  r.x = r.y = r.z = r.m = r.s = 0.0f;
+  r.first = r.count = 0;
+  r.kind = BH_KIND_PAD;
   return r;
 }
 
@@ -541,17 +549,19 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     const int j = base + p;
     if (j >= n) break;
     if (j == 0) {  // root record (ref:65-81 initRootKernel)
-      const int E = 1 + cb[n];
+      const int E = BH_BLOCK0 + cb[n];
       info->n_entries = E;
       if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
       rec[0] = make_child(k, B, D, cap, s0, pn, cb, 0, n, 0);
       er_lo[0] = 0;
       er_hi[0] = n;
+      rec[1] = pad_entry();  // child blocks start at even entries (BH_BLOCK0)
+      er_lo[1] = er_hi[1] = 0;
       continue;
     }
     const int nc = pn[j];
     if (nc == 0) continue;
-    int e = 1 + cb[j];
+    int e = BH_BLOCK0 + cb[j];
     if (e + nc > rec_cap) continue;  // cannot happen (records <= 2n); flagged by thread 0 if it did
     const int a = pa[j], b = pb[j];
     const int L = dl[p];
@@ -572,6 +582,10 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       c0 = c1;
       const int nx = next_set(mle, c0);
       c1 = (nx < 0 || nx > qb) ? qb : nx;
+    }
+    if (nc & 1) {  // a block of an odd number of children is followed by one padding entry
+      rec[e] = pad_entry();
+      er_lo[e] = er_hi[e] = 0;
     }
   }
   __syncthreads();
@@ -597,11 +611,19 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       const bool nonempty = nxt > l;
       const u64 grp = (__ballot(nonempty) >> (lane & ~7)) & 0xffull;
       if (nonempty) {
-        const int e = 1 + cb[j] + __popcll(grp & ((1ull << sub) - 1ull));
+        const int e = BH_BLOCK0 + cb[j] + __popcll(grp & ((1ull << sub) - 1ull));
         if (e < rec_cap) {
           rec[e] = make_child(k, B, D, cap, s0, pn, cb, l, nxt, L + 1, n, s_samp, ns, ss);
           er_lo[e] = l;
           er_hi[e] = nxt;
+        }
+      }
+      if (sub == 0) {
+        const int nc = __popcll(grp);
+        const int e = BH_BLOCK0 + cb[j] + nc;
+        if ((nc & 1) && e < rec_cap) {
+          rec[e] = pad_entry();
+          er_lo[e] = er_hi[e] = 0;
         }
       }
     }
@@ -620,8 +642,13 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
   const int E = min(info->n_entries, rec_cap);
   if (e >= E) return;
   const int lo = er_lo[e], hi = er_hi[e];
+  const int kind = rec[e].kind;
+  if (kind == BH_KIND_PAD) {  // padding entry: a null digest (accepted by every body, zero force)
+    frec_put(frec, e, frec_null());
+    return;
+  }
   float4 o;
-  if (rec[e].kind == BH_KIND_BODY) {
+  if (kind == BH_KIND_BODY) {
     o = posm[lo];
   } else {
     const bh_d4 p1 = P[hi], p0 = P[lo];
@@ -641,7 +668,7 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
   }
   // x,y,z,m are the first 16 bytes of the record
   *reinterpret_cast<float4*>(&rec[e]) = o;
-  // digest for the fast force kernel (see bh_force.hip)
+  // digest for the fast force kernel (see bh_force.hip; pair layout: bh_internal.h)
   const bh_node r = rec[e];
   bh_frec fr;
   fr.x = o.x; fr.y = o.y; fr.z = o.z;
@@ -657,10 +684,10 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
   fr.meta = r.count;
   fr.pad = 0;
   if (r.kind == BH_KIND_MULTI) {
-    // an unsplit multi-body cell is, for the fast kernel, a cell whose children are its bodies: body b's
-    // digest lives at rec_cap + b (bodies of a cell are consecutive, so the block is contiguous); only
-    // the slots of such bodies are ever written or read
-    fr.first = rec_cap + lo;
+    // an unsplit multi-body cell is, for the fast kernel, a cell whose children are its bodies: their
+    // digests form a child block at BH_BODY_DIGEST (even start; a null digest follows an odd count);
+    // only the slots of such bodies are ever written or read
+    fr.first = BH_BODY_DIGEST(rec_cap, lo, lo);
     for (int b = lo; b < hi; b++) {
       const float4 q = posm[b];
       bh_frec br;
@@ -670,10 +697,11 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
       br.first = b;
       br.meta = 1;
       br.pad = 0;
-      frec[rec_cap + b] = br;
+      frec_put(frec, BH_BODY_DIGEST(rec_cap, lo, b), br);
     }
+    if ((hi - lo) & 1) frec_put(frec, BH_BODY_DIGEST(rec_cap, lo, hi), frec_null());
   }
-  frec[e] = fr;
+  frec_put(frec, e, fr);
 }
 
 }  // namespace
@@ -727,7 +755,7 @@ hipError_t bhk_build(bh_ctx* c) {
   pairs_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
                                                                         c->ksamp, ns, ss, c->pa, c->pb, c->pn,
                                                                         c->info);
-  const hipError_t e = bhk_scan_i32(c, c->pn, c->cb, n, nullptr);  // child-block offsets; cb[n] = total children
+  const hipError_t e = bhk_scan_i32_even(c, c->pn, c->cb, n);  // child-block offsets (even: 64-byte aligned); cb[n] = entries - 2
   if (e != hipSuccess) return e;
   emit_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
                                                                        c->ksamp, ns, ss, c->pa,

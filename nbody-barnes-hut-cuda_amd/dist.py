@@ -175,8 +175,9 @@ class DomainStepper:
         self.mig_rounds = 0
         self.mig_last = 0
         e_cls = pkg.Engine
-        lmin = 1 + 512
+        lmin = 2 + 512  # header + piece slots + padding (BH_DD_PIECE_CAP, csrc/bh_dd.hip kSegBlocks0)
         self.let_cap = int(let_cap) if let_cap else lmin + self.n_cap
+        self.let_cap += self.let_cap & 1                        # segments hold whole 64-byte digest pairs
         sz = e_cls.dd_query(self.n_cap, P, self.mig_cap, self.let_cap)
         self.sz = sz
         self.stream = stream if stream is not None else torch.cuda.Stream(device)
@@ -308,7 +309,8 @@ class DomainStepper:
                     seg = self.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32]
                     if failed is not None:
                         self.lets[:stride * 32].zero_()
-                        self.lets[:32].view(torch.int32)[5] = -1        # header count < 0: "this rank failed"
+                        self.lets[:64].view(torch.int32)[10] = -1       # header count < 0: "this rank failed" (record 0 of a
+                        # digest pair: field `first` is dword 10, csrc/bh_internal.h)
                         c.all_gather(seg, self.lets[:stride * 32])
                         raise RuntimeError(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
                     e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)

@@ -6,7 +6,7 @@ import numpy as np
 from . import _lib
 from ._lib import lib, BhParams, BhNode, BhStats
 
-KIND_BODY, KIND_INTERNAL, KIND_MULTI = 0, 1, 2
+KIND_BODY, KIND_INTERNAL, KIND_MULTI, KIND_PAD = 0, 1, 2, 3
 _F = C.POINTER(C.c_float)
 
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libbh_oracle.so")
 
 ORDER_PREORDER, ORDER_BATCHED = 0, 1
-KIND_BODY, KIND_INTERNAL, KIND_MULTI = 0, 1, 2
+KIND_BODY, KIND_INTERNAL, KIND_MULTI, KIND_PAD = 0, 1, 2, 3
 
 NODE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("m", "f4"), ("s", "f4"),
                        ("first", "i4"), ("count", "i4"), ("kind", "i4")])
@@ -140,7 +140,7 @@ def build_tree(sorted_keys, p, s0):
     """-> (rec, er_lo, er_hi, n_internal, max_level); rec is a NODE_DTYPE array (topology only)."""
     sk = np.ascontiguousarray(sorted_keys, dtype=np.uint64)
     n = len(sk)
-    cap = 2 * n + 8
+    cap = 3 * n + 8
     rec = np.zeros(cap, NODE_DTYPE)
     lo = np.zeros(cap, np.int32)
     hi = np.zeros(cap, np.int32)

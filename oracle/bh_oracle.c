@@ -313,6 +313,12 @@ static void write_entry(bho_node* r, int32_t* er_lo, int32_t* er_hi, int e, int 
   }
 }
 
+static void write_pad(bho_node* rec, int32_t* er_lo, int32_t* er_hi, int e) {
+  memset(&rec[e], 0, sizeof(rec[e]));
+  rec[e].kind = BHO_KIND_PAD;
+  er_lo[e] = er_hi[e] = 0;
+}
+
 int bho_build(const uint64_t* sorted_keys, int n, const bho_params* p, float s0, bho_node* rec,
               int32_t* er_lo, int32_t* er_hi, int capacity, int* n_internal, int* max_level) {
   bctx c;
@@ -324,18 +330,20 @@ int bho_build(const uint64_t* sorted_keys, int n, const bho_params* p, float s0,
   c.cells = NULL;
   c.ncells = c.cellcap = 0;
   c.max_level = 0;
-  if (capacity < 1) return -1;
+  if (capacity < 2) return -1;
   int split;
   int root_internal = classify(&c, 0, n, 0, &split);
   int root = root_internal ? discover(&c, 0, n, split) : -1;
-  /* child blocks in sortkey order, starting at entry 1 */
+  /* child blocks in sortkey order.  Layout (include/bh.h): entry 0 = root, child blocks start at EVEN
+     entries (64-byte boundaries of the 32-byte records), so entry 1 and the entry after every block of
+     an odd number of children are padding (kind BHO_KIND_PAD, all fields zero) */
   ocell** order = (ocell**)malloc((size_t)(c.ncells + 1) * sizeof(ocell*));
   for (int i = 0; i < c.ncells; i++) order[i] = &c.cells[i];
   qsort(order, (size_t)c.ncells, sizeof(ocell*), cmp_cell);
-  int next = 1;
+  int next = 2;
   for (int i = 0; i < c.ncells; i++) {
     order[i]->block = next;
-    next += order[i]->nchild;
+    next += (order[i]->nchild + 1) & ~1;
   }
   int E = next;
   if (E > capacity) {
@@ -344,11 +352,13 @@ int bho_build(const uint64_t* sorted_keys, int n, const bho_params* p, float s0,
     return -1;
   }
   write_entry(rec, er_lo, er_hi, 0, 0, n, root >= 0 ? &c.cells[root] : NULL, split, s0);
+  write_pad(rec, er_lo, er_hi, 1);
   for (int i = 0; i < c.ncells; i++) {
     const ocell* q = &c.cells[i];
     for (int j = 0; j < q->nchild; j++)
       write_entry(rec, er_lo, er_hi, q->block + j, q->clo[j], q->chi[j],
                   q->ccell[j] >= 0 ? &c.cells[q->ccell[j]] : NULL, q->clevel[j], s0);
+    if (q->nchild & 1) write_pad(rec, er_lo, er_hi, q->block + q->nchild);
   }
   if (n_internal) *n_internal = c.ncells;
   if (max_level) *max_level = c.max_level;
@@ -367,6 +377,7 @@ void bho_com(bho_node* rec, const int32_t* er_lo, const int32_t* er_hi, int n_en
   for (int e = 0; e < n_entries; e++) {
     bho_node* r = &rec[e];
     const int lo = er_lo[e], hi = er_hi[e];
+    if (r->kind == BHO_KIND_PAD) continue; /* padding entry: stays all zero */
     if (r->kind == BHO_KIND_BODY) {
       r->x = xyzm[4 * (size_t)lo + 0];
       r->y = xyzm[4 * (size_t)lo + 1];
@@ -596,7 +607,7 @@ bho_state* bho_create(int n, const bho_params* p) {
   s->keys = (uint64_t*)calloc(N, 8);
   s->skeys = (uint64_t*)calloc(N, 8);
   s->perm = (int32_t*)calloc(N, 4);
-  s->capacity = 2 * n + 8;
+  s->capacity = 3 * n + 8;
   s->rec = (bho_node*)calloc((size_t)s->capacity, sizeof(bho_node));
   s->er_lo = (int32_t*)calloc((size_t)s->capacity, 4);
   s->er_hi = (int32_t*)calloc((size_t)s->capacity, 4);

@@ -33,6 +33,7 @@ typedef struct bho_params {
 #define BHO_KIND_BODY 0
 #define BHO_KIND_INTERNAL 1
 #define BHO_KIND_MULTI 2
+#define BHO_KIND_PAD 3 /* padding entry: child blocks start at even entries (include/bh.h BH_KIND_PAD) */
 
 /* same 32-byte record as include/bh.h's bh_node (defined independently here) */
 typedef struct bho_node {

@@ -65,9 +65,9 @@ class ScriptedEngine:
     def dd_force_local(self, ptr):
         self.calls.append("force_local")
 
-    # X4: record 0 of the segment, int field 5 = records needed
+    # X4: record 0 of the segment (slot 0 of a 64-byte digest pair), field `first` = dword 10 = records needed
     def dd_let_pack(self, x3ptr, sendptr, stride):
-        self.st.lets[:32].view(torch.int32)[5] = self.need[self.step_no][self.rank]
+        self.st.lets[:64].view(torch.int32)[10] = self.need[self.step_no][self.rank]
         self.calls.append(("let_pack", stride))
 
     def dd_top(self, x3ptr, stride):
@@ -79,7 +79,7 @@ class ScriptedEngine:
     def dd_let_check(self, stride, P):
         sz = self.st.sz
         seg = self.st.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32].view(P, stride * 32)
-        counts = np.array([int(seg[q, :32].view(torch.int32)[5]) for q in range(P)], np.int32)
+        counts = np.array([int(seg[q, :64].view(torch.int32)[10]) for q in range(P)], np.int32)
         return bool(counts.max() <= stride), counts
 
     def integrate(self):
@@ -93,10 +93,10 @@ def main():
     from nbody_barnes_hut_cuda_amd import dist as bhdist
     comm = bhdist.TorchComm()
     P, r = comm.world, comm.rank
-    n_cap, mig_cap, let_cap = 20000, 10000, 1 + PIECES + 20000
+    n_cap, mig_cap, let_cap = 20000, 10000, 2 + PIECES + 20000
     sz = types.SimpleNamespace(x1_bytes=64, x2_bytes=32 + 32 * mig_cap, x3_bytes=80 * (1 + PIECES),
                                pool_records=2 * n_cap + 8 + 100 + P * let_cap + 8, seg_base=2 * n_cap + 108,
-                               let_min=1 + PIECES, let_cap=let_cap, top_base=2 * n_cap + 8)
+                               let_min=2 + PIECES, let_cap=let_cap, top_base=2 * n_cap + 8)
     steps = 4
     emig = [[10, 20, 5][:P] + [0] * (P - 3), [6000] * P, [9000] + [100] * (P - 1), [50] * P]
     need = [[600] * P, [700 + 4000 * (q == 1) for q in range(P)], [15000] * P, [15500] * P]

@@ -1,12 +1,16 @@
-"""Parity at BASELINE.json's full single-GPU sizes (500,000 and 1,000,000 bodies, theta 0.5 and 0.3)
-through size-independent properties, plus oracle checks on a bounded sample:
+"""Parity at BASELINE.json's full sizes (500,000 / 1,000,000 bodies at theta 0.5 and 0.3; the 8,000,000
+bodies of configs[3] as ONE context) through size-independent properties, plus oracle checks:
   * keys sorted, sort is a permutation, gather consistent;
   * the tree is a tree: children partition their parent's body range, every body in exactly one
-    leaf, every emitted cell branches, cells <= n-1, records <= 2n, edges halve;
+    leaf, every emitted cell branches, cells <= n-1, records <= 2n (+ padding), edges halve, child
+    blocks start on 64-byte boundaries;
   * root mass/COM = total mass / mass-weighted mean (fp64 on the host);
   * strict kernel on a 4096-body slab == oracle walking the GPU's tree, bit for bit, and the V/O/P
     counters of the slab match;
+  * the FAST (benchmarked) kernel on the same slab vs the ORACLE, stated distribution;
   * fast kernel vs strict kernel within the stated tolerance over ALL bodies;
+  * K = 10 whole steps (bh_step, fast kernel) vs oracle.Oracle.step at 500k and 1M, stated distribution
+    on positions and velocities (north_star: "after N steps");
   * a whole step conserves the body set and the sticky flags stay clear.
 """
 import numpy as np
@@ -16,23 +20,29 @@ from helpers import oparams
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = [(500_000, 0.5), (1_000_000, 0.5), (1_000_000, 0.3)]
+CONFIGS = [(500_000, 0.5), (1_000_000, 0.5), (1_000_000, 0.3), (8_000_000, 0.5)]
 
 
 def _tree_invariants_vectorised(rec, n):
     kind, first, count, s = rec["kind"], rec["first"], rec["count"], rec["s"]
     internal = np.flatnonzero(kind == 1)
-    assert len(internal) <= n - 1 and len(rec) <= 2 * n
+    pad = kind == 3
+    assert len(internal) <= n - 1 and len(rec) - int(pad.sum()) <= 2 * n and len(rec) <= 3 * n + 2
     assert count[internal].min() >= 2 and count[internal].max() <= 8   # every emitted cell branches
-    # every record except the root is the child of exactly one cell
-    ref = np.zeros(len(rec), np.int32)
     starts = first[internal]
+    assert np.all(starts % 2 == 0) and starts.min() >= 2                 # blocks on 64-byte boundaries
+    odd = internal[count[internal] % 2 == 1]
+    assert np.all(kind[first[odd] + count[odd]] == 3)                     # odd block -> one padding entry
+    # every record except the root and the padding is the child of exactly one cell
+    ref = np.zeros(len(rec), np.int32)
     for k in range(8):
         sel = count[internal] > k
         np.add.at(ref, starts[sel] + k, 1)
-    assert ref[0] == 0 and np.all(ref[1:] == 1)
+    assert ref[0] == 0 and pad[1] and np.all(ref[pad] == 0) and np.all(ref[1:][~pad[1:]] == 1)
+    for f in ("x", "y", "z", "m", "s"):
+        assert not np.any(rec[f][pad])
     # body ranges: leaves cover [0, n) exactly once
-    leaves = np.flatnonzero(kind != 1)
+    leaves = np.flatnonzero((kind != 1) & ~pad)
     lo = first[leaves].astype(np.int64)
     cnt = np.where(kind[leaves] == 0, 1, count[leaves]).astype(np.int64)
     order = np.argsort(lo)
@@ -87,14 +97,19 @@ def test_fullsize_properties(pkg, orc, n, theta):
     assert np.array_equal(gV[sel], V[lo:hi]) and np.array_equal(gO[sel], O[lo:hi]) and np.array_equal(gP[sel], P[lo:hi])
     strict = np.stack([ax, ay, az], 1)
     e.close()
-    # fast kernel over all bodies vs strict.  Stated fp32 tolerance, as a distribution (a MAC
-    # decision can flip on a 1-ulp tie among ~1e9-1e10 decisions; the flipped cell then differs by
-    # one cell's Barnes-Hut truncation error, itself far below the method's ~1e-3 error):
+    # fast kernel over all bodies.  Stated fp32 tolerance, as a distribution (a MAC decision can flip on
+    # a 1-ulp tie among ~1e9-1e10 decisions; the flipped cell then differs by one cell's Barnes-Hut
+    # truncation error, itself far below the method's ~1e-3 error):
     # median <= 2e-6, 99.99th percentile <= 1e-4, max <= 1e-3 relative
     f = pkg.Engine(n, theta=theta)
     f.upload(*ic)
     f.tree_stages(); f.force()
     fast = np.stack(f.download_acc(), 1)
+    # (i) the benchmarked kernel against the ORACLE itself on the slab (pre-order walk of the same tree)
+    oslab = oacc[lo:hi, :3]
+    rel_o = np.linalg.norm(fast[sel] - oslab, axis=1) / np.linalg.norm(oslab, axis=1)
+    assert np.median(rel_o) <= 2e-6 and rel_o.max() <= 1e-3
+    # (ii) against the strict kernel (== oracle arithmetic, proven on the slab) over ALL bodies
     rel = np.linalg.norm(fast - strict, axis=1) / np.linalg.norm(strict, axis=1)
     assert np.median(rel) <= 2e-6 and np.percentile(rel, 99.99) <= 1e-4 and rel.max() <= 1e-3
     # one whole step keeps the body set intact
@@ -105,3 +120,33 @@ def test_fullsize_properties(pkg, orc, n, theta):
     assert np.array_equal(f.download_mass(), ic[6])                        # ids still line up
     assert f.stats().status_flags == 0
     f.close()
+
+
+@pytest.mark.parametrize("n", [500_000, 1_000_000])
+def test_fullsize_ten_steps_vs_oracle(pkg, orc, n):
+    """K = 10 whole steps of the default (fast) engine vs the oracle's step loop from identical Plummer
+    inputs (ref:255-283 stage order on both sides).  Stated fp32 tolerance on the state after 10 steps,
+    caller order, as a distribution over the bodies (coordinates reach ~4000, so one ulp of a position is
+    up to 4.9e-4; a MAC tie that flips changes one body's acceleration by one cell's truncation error):
+        |dx|: median <= 3.1e-5 (one ulp at |x| < 512), 99.99th percentile <= 5e-4, max <= 2e-3
+        |dv|: median <= 1e-6, 99.99th percentile <= 1e-4, max <= 1e-3
+    (measured on MI355X, round 2: |dx| 0 / 6.1e-5 / 1.2e-4 and |dv| 3e-8 / 7.6e-6 / 2.3e-5 at 1M)"""
+    K = 10
+    ic = pkg.plummer(n, seed=42)
+    e = pkg.Engine(n)
+    e.upload(*ic)
+    e.step(K)
+    g = np.stack(e.download(), 1).astype(np.float64)
+    assert e.stats().status_flags == 0
+    e.close()
+    o = orc.Oracle(n)
+    o.upload(*ic)
+    o.step(K, order=orc.ORDER_BATCHED)
+    w = np.stack(o.download(), 1).astype(np.float64)
+    o.close()
+    dx = np.abs(g[:, :3] - w[:, :3]).max(axis=1)
+    dv = np.abs(g[:, 3:] - w[:, 3:]).max(axis=1)
+    print(f"n={n} K={K}: |dx| p50 {np.median(dx):.3e} p99.99 {np.percentile(dx, 99.99):.3e} max {dx.max():.3e}; "
+          f"|dv| p50 {np.median(dv):.3e} p99.99 {np.percentile(dv, 99.99):.3e} max {dv.max():.3e}")
+    assert np.median(dx) <= 3.1e-5 and np.percentile(dx, 99.99) <= 5e-4 and dx.max() <= 2e-3
+    assert np.median(dv) <= 1e-6 and np.percentile(dv, 99.99) <= 1e-4 and dv.max() <= 1e-3

@@ -84,19 +84,26 @@ def _tree_invariants(rec, lo, hi, n, cap, compress):
         assert 1 <= c <= 8
         if compress:
             assert c >= 2  # every emitted cell branches
+        assert f % 2 == 0 and f >= 2                                 # blocks start on 64-byte boundaries
+        if c % 2:
+            assert rec["kind"][f + c] == 3                           # odd block: one padding entry follows
         ch = np.arange(f, f + c)
         referenced[ch] += 1
         assert lo[ch[0]] == lo[e] and hi[ch[-1]] == hi[e]          # children partition the parent
         assert np.array_equal(hi[ch[:-1]], lo[ch[1:]])
         assert np.all(rec["s"][ch][rec["kind"][ch] != 0] < rec["s"][e])  # edges shrink
         assert hi[e] - lo[e] > cap
-    assert np.all(referenced == 1)                                   # a tree: every entry has one parent
-    leaves = np.flatnonzero(rec["kind"] != 1)
+    pad = rec["kind"] == 3
+    assert pad[1] and np.all(referenced[pad] == 0)                   # padding is never referenced
+    for f in ("x", "y", "z", "m", "s"):
+        assert not np.any(rec[f][pad])
+    assert np.all(referenced[~pad] == 1)                             # a tree: every entry has one parent
+    leaves = np.flatnonzero((rec["kind"] != 1) & ~pad)
     for e in leaves:
         seen_body[lo[e]:hi[e]] += 1
     assert np.all(seen_body == 1)                                    # every body in exactly one leaf
     if compress:
-        assert len(internal) <= max(n - 1, 0) and len(rec) <= 2 * n
+        assert len(internal) <= max(n - 1, 0) and len(rec) - int(pad.sum()) <= 2 * n and len(rec) <= 3 * n + 2
 
 
 @pytest.mark.parametrize("compress", [0, 1])
@@ -116,13 +123,13 @@ def test_tree_invariants_edge_cases(orc, name):
     for compress in (0, 1):
         p = orc.params(compress=compress)
         if compress == 0 and name == "pairs":
-            continue  # chains of ~17 cells per pair overflow the 2n+8 pool by design
+            continue  # chains of ~17 cells per pair overflow the 3n+8 pool by design
         o = oracle_pipeline(orc, ic, p)
         _tree_invariants(o["rec"], o["er_lo"], o["er_hi"], 500, 1, compress)
 
 
 def test_uncompressed_pairs_overflow_is_reported(orc):
-    """the literal chain tree needs more than 2n records on close pairs: the oracle says so"""
+    """the literal chain tree needs more than 3n entries on close pairs: the oracle says so"""
     ic = special_ics("pairs", 500, np.random.default_rng(6))
     with pytest.raises(RuntimeError):
         oracle_pipeline(orc, ic, orc.params(compress=0))
