@@ -393,73 +393,97 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 //     test, no loop counter.  A block of an odd number of children ends in a null record (gm 0, thr2 -1);
 //   * stack overflow and "child count > 8" are recorded with one s_max each and judged once, after the walk
 //     (the caller then redoes the wave with the generic loop).
-// Per pair: 16 VALU + 2 x (s_andn2 + s_cbranch).  Per block: 5 v_readlane, <= 4 s_load, 10 SALU/branch.
+//   * the pair chain is software-pipelined: the force half of pair p (8 VALU) is interleaved, instruction by
+//     instruction, with the MAC half of pair p-1 (10 VALU), so consecutive instructions of a wave are
+//     independent (a wave's DEPENDENT VALU instructions issue only every ~4+ cycles whatever the occupancy).
+// Per pair: 16 VALU + 2 x (s_andn2 + s_cbranch).  Per block: 5 v_readlane, <= 4 s_load, 11 SALU/branch.
 // Per push: 4 v_writelane + 5 SALU/branch.  v_readlane/v_writelane ignore EXEC.
-// Fixed registers inside the block: s[36:99] record window (pair p at s[36+16p..]), s14-s35 state;
-// v[32:33] = (px,py), v[34:35] = (pz,-), v[36:37] = (eps2,eps2), v[38:43] d, v[44:45] d2, v[46:47] rinv,
-// v[48:49] f, v[50:55] six partial accumulators, v56-v59 cross-lane stack, v60 jump table.
-#define BH_PAIR_MAC(p, X, Y, Z, THR0, THR1)                                                              \
-  "L_seg" #p "_%=:\n"                                                                                     \
-  "v_pk_add_f32 v[38:39], " X ", v[32:33] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                    \
-  "v_pk_add_f32 v[40:41], " Y ", v[32:33] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"       \
-  "v_pk_add_f32 v[42:43], " Z ", v[34:35] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                    \
-  "v_pk_fma_f32 v[44:45], v[38:39], v[38:39], v[36:37]\n"                                                 \
-  "v_pk_fma_f32 v[44:45], v[40:41], v[40:41], v[44:45]\n"                                                 \
-  "v_pk_fma_f32 v[44:45], v[42:43], v[42:43], v[44:45]\n"                                                 \
-  "v_cmp_lt_f32_e64 s[18:19], " THR0 ", v44\n"                                                            \
-  "v_cmp_lt_f32_e64 s[14:15], " THR1 ", v45\n"                                                            \
-  "v_rsq_f32 v46, v44\n"                                                                                  \
-  "v_rsq_f32 v47, v45\n"                                                                                  \
-  "s_andn2_b64 s[26:27], exec, s[18:19]\n"                                                                \
-  "s_cbranch_scc1 L_pushA" #p "_%=\n"                                                                     \
-  "s_andn2_b64 s[26:27], exec, s[14:15]\n"                                                                \
-  "s_cbranch_scc1 L_pushB" #p "_%=\n"
-#define BH_PAIR_F1(GM)                                                                                   \
-  "v_pk_mul_f32 v[48:49], " GM ", v[46:47]\n"                                                             \
-  "v_pk_mul_f32 v[46:47], v[46:47], v[46:47]\n"                                                           \
-  "v_pk_mul_f32 v[48:49], v[48:49], v[46:47]\n"
-#define BH_PAIR_F2                                                                                       \
-  "v_pk_fma_f32 v[50:51], v[48:49], v[38:39], v[50:51]\n"                                                 \
-  "v_pk_fma_f32 v[52:53], v[48:49], v[40:41], v[52:53]\n"                                                 \
-  "v_pk_fma_f32 v[54:55], v[48:49], v[42:43], v[54:55]\n"
-#define BH_PAIR_SEG(p, X, Y, Z, GM, THR0, THR1) BH_PAIR_MAC(p, X, Y, Z, THR0, THR1) BH_PAIR_F1(GM) BH_PAIR_F2
+// Code:  PRO(q) = MAC(q)              entry of a block of 2q+1 or 2q+2 children (computed jump)
+//        SEG(q) = FORCE(q) || MAC(q-1)   q = 3..1;  SEG(0) = FORCE(0);  SEGm(q) = the same with the take masks
+//        ARMS(q)= pushes of pair q, then SEGm(q)
+// Fixed registers inside the block: s[36:99] record window (pair p at s[36+16p..]), s10-s35 state;
+// v[16:17] = (px,py), v[18:19] = (pz,-), v[20:21] = (eps2,eps2); pair sets (even / odd pairs) d = v[22:27] /
+// v[30:35], rinv = v[28:29] / v[36:37], accept masks s[18:19],s[14:15] / s[12:13],s[10:11]; v[38:39] d2,
+// v[40:41] f, v[42:47] six partial accumulators, v48-v51 cross-lane stack, v52 jump table.
+#define BH_S0 "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v28", "v29", "s[18:19]", "s[14:15]"
+#define BH_S1 "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v36", "v37", "s[12:13]", "s[10:11]"
+// MAC of the pair (X, Y, Z, THR0, THR1) into set (DX, DY, DZ, R, R0, R1, MA, MB)
+#define BH_M1(DX, X) "v_pk_add_f32 " DX ", " X ", v[16:17] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define BH_M2(DY, Y) "v_pk_add_f32 " DY ", " Y ", v[16:17] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define BH_M3(DZ, Z) "v_pk_add_f32 " DZ ", " Z ", v[18:19] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define BH_M4(DX) "v_pk_fma_f32 v[38:39], " DX ", " DX ", v[20:21]\n"
+#define BH_M5(DY) "v_pk_fma_f32 v[38:39], " DY ", " DY ", v[38:39]\n"
+#define BH_M7(MA, T0) "v_cmp_lt_f32_e64 " MA ", " T0 ", v38\n"
+#define BH_M8(MB, T1) "v_cmp_lt_f32_e64 " MB ", " T1 ", v39\n"
+#define BH_M9(R0, R1) "v_rsq_f32 " R0 ", v38\n v_rsq_f32 " R1 ", v39\n"
+#define BH_CHK(q, MA, MB)                                                                                \
+  "s_andn2_b64 s[26:27], exec, " MA "\n s_cbranch_scc1 L_pushA" #q "_%=\n"                                \
+  "s_andn2_b64 s[26:27], exec, " MB "\n s_cbranch_scc1 L_pushB" #q "_%=\n"
+#define BH_MAC_(q, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1)                                       \
+  BH_M1(DX, X) BH_M2(DY, Y) BH_M3(DZ, Z) BH_M4(DX) BH_M5(DY) BH_M5(DZ) BH_M7(MA, T0) BH_M8(MB, T1)        \
+  BH_M9(R0, R1) BH_CHK(q, MA, MB)
+// BH_S0 / BH_P0 ... are comma lists: BH_X expands them before the callee counts its arguments
+#define BH_X(M, ...) M(__VA_ARGS__)
+#define BH_MAC(...) BH_X(BH_MAC_, __VA_ARGS__)
+#define BH_PRO(q, ...) "L_pro" #q "_%=:\n" BH_MAC(q, __VA_ARGS__) "s_branch L_seg" #q "_%=\n"
+// force half on set F (pair GM), masked or not, interleaved with the MAC of pair qm (set M)
+#define BH_F1(GM, R) "v_pk_mul_f32 v[40:41], " GM ", " R "\n"
+#define BH_F2(R) "v_pk_mul_f32 " R ", " R ", " R "\n"
+#define BH_F3(R) "v_pk_mul_f32 v[40:41], v[40:41], " R "\n"
+#define BH_FA(D, A) "v_pk_fma_f32 " A ", v[40:41], " D ", " A "\n"
+#define BH_FM(MA, MB) "v_cndmask_b32_e64 v40, 0, v40, " MA "\n v_cndmask_b32_e64 v41, 0, v41, " MB "\n"
+#define BH_SEG_(LBL, MASK, qm, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1) \
+  LBL ":\n"                                                                                               \
+  BH_M1(DX, X) BH_F1(GM, FR) BH_M2(DY, Y) BH_F2(FR) BH_M3(DZ, Z) BH_F3(FR) BH_M4(DX) MASK(FMA, FMB)       \
+  BH_M5(DY) BH_FA(FDX, "v[42:43]") BH_M5(DZ) BH_FA(FDY, "v[44:45]") BH_M7(MA, T0) BH_FA(FDZ, "v[46:47]")  \
+  BH_M8(MB, T1) BH_M9(R0, R1) BH_CHK(qm, MA, MB)
+#define BH_NOMASK(MA, MB) ""
+#define BH_SEG(q, qm, ...) BH_X(BH_SEG_, "L_seg" #q "_%=", BH_NOMASK, qm, __VA_ARGS__)
+#define BH_SEGM(q, qm, ...) BH_X(BH_SEG_, "L_segm" #q "_%=", BH_FM, qm, __VA_ARGS__) "s_branch L_seg" #qm "_%=\n"
+#define BH_LAST_(LBL, MASK, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM)                                   \
+  LBL ":\n" BH_F1(GM, FR) BH_F2(FR) BH_F3(FR) MASK(FMA, FMB) BH_FA(FDX, "v[42:43]") BH_FA(FDY, "v[44:45]") \
+  BH_FA(FDZ, "v[46:47]")
+#define BH_LAST(...) BH_X(BH_LAST_, __VA_ARGS__)
 #define BH_PUSH1(FIRST, META)                                                                            \
   "s_mov_b32 m0, s30\n"                                                                                   \
   "s_add_u32 s30, s30, 1\n"                                                                               \
   "s_max_u32 s31, s31, s30\n"                                                                             \
   "s_max_u32 s16, s16, " META "\n"                                                                        \
-  "v_writelane_b32 v56, " FIRST ", m0\n"                                                                  \
-  "v_writelane_b32 v57, " META ", m0\n"                                                                   \
-  "v_writelane_b32 v58, s26, m0\n"                                                                        \
-  "v_writelane_b32 v59, s27, m0\n"
-// the path of a pair with at least one opened record: pushes, then the force half with the take masks
-#define BH_PAIR_ARMS(p, NEXT, GM, F0, M0, F1, M1)                                                        \
-  "L_pushA" #p "_%=:\n" BH_PUSH1(F0, M0)                                                                  \
-  "s_andn2_b64 s[26:27], exec, s[14:15]\n"                                                                \
-  "s_cbranch_scc0 L_masked" #p "_%=\n"                                                                    \
-  "L_pushB" #p "_%=:\n" BH_PUSH1(F1, M1)                                                                  \
-  "L_masked" #p "_%=:\n" BH_PAIR_F1(GM)                                                                   \
-  "v_cndmask_b32_e64 v48, 0, v48, s[18:19]\n"                                                             \
-  "v_cndmask_b32_e64 v49, 0, v49, s[14:15]\n" BH_PAIR_F2                                                  \
-  "s_branch " NEXT "\n"
+  "v_writelane_b32 v48, " FIRST ", m0\n"                                                                  \
+  "v_writelane_b32 v49, " META ", m0\n"                                                                   \
+  "v_writelane_b32 v50, s26, m0\n"                                                                        \
+  "v_writelane_b32 v51, s27, m0\n"
+// a pair with at least one opened record: push, then continue in the masked variant of its force half
+#define BH_ARMS_(q, MB, F0, M0, F1, M1)                                                                  \
+  "L_pushA" #q "_%=:\n" BH_PUSH1(F0, M0)                                                                  \
+  "s_andn2_b64 s[26:27], exec, " MB "\n"                                                                  \
+  "s_cbranch_scc0 L_segm" #q "_%=\n"                                                                      \
+  "L_pushB" #q "_%=:\n" BH_PUSH1(F1, M1)                                                                  \
+  "s_branch L_segm" #q "_%=\n"
 // pair p of the window: x s[36+16p:37+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11, meta +12/+13
+#define BH_P0 "s[36:37]", "s[38:39]", "s[40:41]", "s44", "s45"
+#define BH_P1 "s[52:53]", "s[54:55]", "s[56:57]", "s60", "s61"
+#define BH_P2 "s[68:69]", "s[70:71]", "s[72:73]", "s76", "s77"
+#define BH_P3 "s[84:85]", "s[86:87]", "s[88:89]", "s92", "s93"
+#define BH_PRO_ALL BH_PRO(0, BH_S0, BH_P0) BH_PRO(1, BH_S1, BH_P1) BH_PRO(2, BH_S0, BH_P2)               \
+  "L_pro3_%=:\n" BH_MAC(3, BH_S1, BH_P3)
 #define BH_SEG_ALL                                                                                       \
-  BH_PAIR_SEG(3, "s[84:85]", "s[86:87]", "s[88:89]", "s[90:91]", "s92", "s93")                            \
-  BH_PAIR_SEG(2, "s[68:69]", "s[70:71]", "s[72:73]", "s[74:75]", "s76", "s77")                            \
-  BH_PAIR_SEG(1, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", "s60", "s61")                            \
-  BH_PAIR_SEG(0, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "s44", "s45")
+  BH_SEG(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEG(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)             \
+  BH_SEG(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0) BH_LAST("L_seg0_%=", BH_NOMASK, BH_S0, "s[42:43]")
+#define BH_SEGM_ALL                                                                                      \
+  BH_SEGM(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEGM(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)           \
+  BH_SEGM(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0) BH_LAST("L_segm0_%=", BH_FM, BH_S0, "s[42:43]")          \
+  "s_branch L_pop_%=\n"
 #define BH_ARMS_ALL                                                                                      \
-  BH_PAIR_ARMS(3, "L_seg2_%=", "s[90:91]", "s94", "s96", "s95", "s97")                                    \
-  BH_PAIR_ARMS(2, "L_seg1_%=", "s[74:75]", "s78", "s80", "s79", "s81")                                    \
-  BH_PAIR_ARMS(1, "L_seg0_%=", "s[58:59]", "s62", "s64", "s63", "s65")                                    \
-  BH_PAIR_ARMS(0, "L_pop_%=", "s[42:43]", "s46", "s48", "s47", "s49")
-// jump table in the lanes of v60: lane c = entry offset (from L_seg3) of a block of c children; lanes >= 8
-// keep 0 = the 4-pair entry (such a block also trips the "> 8 children" redo); read with one v_readlane
-#define BH_TBL(c, L) "s_mov_b32 s33, " L "-L_seg3_%=\n v_writelane_b32 v60, s33, " #c "\n"
+  BH_ARMS_(3, "s[10:11]", "s94", "s96", "s95", "s97") BH_ARMS_(2, "s[14:15]", "s78", "s80", "s79", "s81") \
+  BH_ARMS_(1, "s[10:11]", "s62", "s64", "s63", "s65") BH_ARMS_(0, "s[14:15]", "s46", "s48", "s47", "s49")
+// jump table in the lanes of v52: lane c = entry offset (from L_pro0) of a block of c children; lanes >= 8
+// keep the 4-pair entry (such a block also trips the "> 8 children" redo); read with one v_readlane
+#define BH_TBL(c, L) "s_mov_b32 s33, " L "-L_pro0_%=\n v_writelane_b32 v52, s33, " #c "\n"
 #define BH_TBL_ALL                                                                                       \
-  "v_mov_b32 v60, 0\n"                                                                                    \
-  BH_TBL(0, "L_end_%=") BH_TBL(1, "L_seg0_%=") BH_TBL(2, "L_seg0_%=") BH_TBL(3, "L_seg1_%=")               \
-  BH_TBL(4, "L_seg1_%=") BH_TBL(5, "L_seg2_%=") BH_TBL(6, "L_seg2_%=")
+  "s_mov_b32 s33, L_pro3_%=-L_pro0_%=\n v_mov_b32 v52, s33\n"                                             \
+  BH_TBL(0, "L_end_%=") BH_TBL(1, "L_pro0_%=") BH_TBL(2, "L_pro0_%=") BH_TBL(3, "L_pro1_%=")               \
+  BH_TBL(4, "L_pro1_%=") BH_TBL(5, "L_pro2_%=") BH_TBL(6, "L_pro2_%=")
 
 // Returns false if the 64-entry cross-lane stack overflowed or a block with more than 8 children was met
 // (unsplit cell of > 8 bodies); ax..az are then invalid and the caller redoes the wave.
@@ -473,17 +497,17 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
   asm volatile(
       "s_mov_b64 s[28:29], exec\n"
       "s_mov_b64 s[20:21], %[base]\n"
-      "v_mov_b32 v32, %[px]\n"
-      "v_mov_b32 v33, %[py]\n"
-      "v_mov_b32 v34, %[pz]\n"
-      "v_mov_b32 v35, 0\n"
-      "v_mov_b32 v36, %[eps2]\n"
-      "v_mov_b32 v37, %[eps2]\n"
-      "v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n v_mov_b32 v52, 0\n v_mov_b32 v53, 0\n v_mov_b32 v54, 0\n v_mov_b32 v55, 0\n"
-      "v_mov_b32 v56, 0\n v_mov_b32 v57, 0\n v_mov_b32 v58, 0\n v_mov_b32 v59, 0\n"
+      "v_mov_b32 v16, %[px]\n"
+      "v_mov_b32 v17, %[py]\n"
+      "v_mov_b32 v18, %[pz]\n"
+      "v_mov_b32 v19, 0\n"
+      "v_mov_b32 v20, %[eps2]\n"
+      "v_mov_b32 v21, %[eps2]\n"
+      "v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
+      "v_mov_b32 v48, 0\n v_mov_b32 v49, 0\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n"
       "s_getpc_b64 s[22:23]\n"
       "L_here_%=:\n"
-      "s_add_u32 s22, s22, L_seg3_%=-L_here_%=\n"
+      "s_add_u32 s22, s22, L_pro0_%=-L_here_%=\n"
       "s_addc_u32 s23, s23, 0\n"
       BH_TBL_ALL
       "s_mov_b32 s30, 0\n"
@@ -497,10 +521,10 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "L_pop_%=:\n"
       "s_sub_u32 s30, s30, 1\n"
       "s_cbranch_scc1 L_done_%=\n"
-      "v_readlane_b32 s33, v57, s30\n"  // the count first: it is the lane select of the table read below,
-      "v_readlane_b32 s32, v56, s30\n"  // which must come >= 4 instructions after the VALU write of it
-      "v_readlane_b32 s34, v58, s30\n"
-      "v_readlane_b32 s35, v59, s30\n"
+      "v_readlane_b32 s33, v49, s30\n"  // the count first: it is the lane select of the table read below,
+      "v_readlane_b32 s32, v48, s30\n"  // which must come >= 4 instructions after the VALU write of it
+      "v_readlane_b32 s34, v50, s30\n"
+      "v_readlane_b32 s35, v51, s30\n"
       "s_lshl_b32 s32, s32, 5\n"
       "L_block_%=:\n"
       ".if %c[use_budget]\n"
@@ -514,36 +538,39 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
       "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
       "L_small_%=:\n"
-      "v_readlane_b32 s33, v60, s33\n"
+      "v_readlane_b32 s33, v52, s33\n"
       "s_mov_b64 exec, s[34:35]\n"
       "s_add_u32 s24, s22, s33\n"
       "s_addc_u32 s25, s23, 0\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_setpc_b64 s[24:25]\n"
+      BH_PRO_ALL
       BH_SEG_ALL
       "L_end_%=:\n"  // also the entry of a block of 0 children (never built; every table offset is >= 0)
       "s_branch L_pop_%=\n"
+      BH_SEGM_ALL
       BH_ARMS_ALL
       "L_done_%=:\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_mov_b64 exec, s[28:29]\n"
-      "v_add_f32 %[ax], v50, v51\n"
-      "v_add_f32 %[ay], v52, v53\n"
-      "v_add_f32 %[az], v54, v55\n"
+      "v_add_f32 %[ax], v42, v43\n"
+      "v_add_f32 %[ay], v44, v45\n"
+      "v_add_f32 %[az], v46, v47\n"
       "s_mov_b32 %[maxsp], s31\n"
       "s_mov_b32 %[maxc], s16\n"
       "s_mov_b32 %[left], s17\n"
       : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left)
       : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
         [eps2] "s"(eps2), [budget] "s"(budget), [use_budget] "n"(BUDGET ? 1 : 0)
-      : "memory", "vcc", "scc", "m0", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25",
-        "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41",
-        "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",
-        "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
-        "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
-        "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v32", "v33", "v34", "v35", "v36", "v37",
-        "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
-        "v54", "v55", "v56", "v57", "v58", "v59", "v60");
+      : "memory", "vcc", "scc", "m0", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21",
+        "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
+        "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+        "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v16", "v17",
+        "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",
+        "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
+        "v50", "v51", "v52");
   limit_hit = BUDGET && left < 0;
   return maxsp <= 64 && maxc <= 8;
 }

@@ -162,7 +162,7 @@ struct bh_ctx {
 // Entries <= root + bodies + cells + one pad per cell <= 3n.
 #define BH_REC_CAP(n) (3 * (n) + 8)
 #define BH_BLOCK0 2  // first child block
-#define BH_FORCE_BLOCK_DEFAULT 256
+#define BH_FORCE_BLOCK_DEFAULT 64  // one wave per workgroup: a CU slot frees as soon as its wave retires (-2 % at 1M)
 #define BH_BBOX_BLOCKS 1024
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
 #define BH_SORT_ITEMS 16
