@@ -19,7 +19,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_VECTOR_TFLOPS = 157.3  # MI355X peak FP32 vector rate (same guide): 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
+
+# Issue cost of the force walk's instruction FORMS: cycles one SIMD needs per wave64 instruction with 8 waves
+# resident, measured on MI355X by tools/ubench_forms.hip / tools/ubench_issue.hip (loop overhead removed);
+# committed output: profiles/r02_ubench/ubench_forms.txt, ubench_issue.txt.  Only two-source all-VGPR VOP2 runs
+# at the 2.3-cycle full rate; SGPR operands, three sources, SGPR results and packed fp32 cost 3.8-4.3.
+ISSUE_CYCLES = {"pk_add_sgpr": 3.78, "pk_mul": 3.78, "pk_fma": 4.30, "cmp_e64": 4.30, "cndmask_e64": 4.30,
+                "rsq": 7.76, "lane_rw": 2.80, "scalar": 2.20}
+ISSUE_PROVENANCE = "committed profile r02_ubench (tools/ubench_forms.hip, tools/ubench_issue.hip on MI355X)"
 
 
 def b_alg(V, O, P, n):
@@ -29,16 +38,17 @@ def b_alg(V, O, P, n):
 
 
 def load_traffic(n, theta):
-    """HBM bytes per force launch from committed PMC counters (profiles/), or None."""
+    """(HBM bytes per force launch, provenance) from the committed PMC passes under profiles/, or (None, None).
+    Not measured by this run: rocprofv3 counters cannot be read from inside the benchmark."""
     path = os.path.join(ROOT, "profiles", "force_traffic.json")
     try:
         t = json.load(open(path))
-        for rec in t.get("records", []):
+        for rec in reversed(t.get("records", [])):
             if rec.get("n") == n and abs(rec.get("theta", -1) - theta) < 1e-6:
-                return rec.get("hbm_bytes_per_launch")
+                return rec.get("hbm_bytes_per_launch"), f"committed profile {rec.get('profile')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=10):
@@ -60,48 +70,79 @@ def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=10):
     return gbs
 
 
-def load_valu_insts(n, theta):
-    """VALU instructions per force launch from the committed SQ counter pass (profiles/), or None."""
-    if n != 1_000_000 or abs(theta - 0.5) > 1e-6:
-        return None
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_v4", "force_fast_kernel_sq.json")))
-        return float(t["counters"]["SQ_INSTS_VALU"]["mean"])
-    except Exception:
-        return None
+def issue_roofline(ws, simds, launch_ms):
+    """Issue-rate floor of one force launch from the walk's own event counters (bh_force_walk_stats, counted in
+    THIS run) priced with the per-form issue costs above.  Instruction counts follow csrc/bh_force.hip:
+    a pair = 3 v_pk_add + 3 v_pk_fma + 2 v_cmp + 2 v_rsq + 3 v_pk_mul + 3 v_pk_fma (+ 2 v_cndmask if a record was
+    opened) and 4 scalar; a block = 5 v_readlane + 4 s_load + 11 scalar; a push = 4 v_writelane + 5 scalar."""
+    c = ISSUE_CYCLES
+    pairs, blocks, masked, waves = float(ws.pairs), float(ws.blocks), float(ws.masked_pairs), float(ws.waves)
+    pushes = blocks - waves
+    pair_cycles = 3 * c["pk_add_sgpr"] + 6 * c["pk_fma"] + 2 * c["cmp_e64"] + 2 * c["rsq"] + 3 * c["pk_mul"]
+    valu_insts = 16 * pairs + 2 * masked + 5 * blocks + 4 * pushes
+    valu_cycles = pair_cycles * pairs + 2 * c["cndmask_e64"] * masked + c["lane_rw"] * (5 * blocks + 4 * pushes)
+    scalar_insts = 4 * pairs + 15 * blocks + 5 * pushes
+    clock_hz = ws.clock_ghz * 1e9
+    floor_valu_ms = valu_cycles / simds / clock_hz * 1e3
+    floor_all_ms = (valu_cycles + c["scalar"] * scalar_insts) / simds / clock_hz * 1e3
+    return {
+        "counted_this_run": {"waves": int(waves), "record_pairs": int(pairs), "blocks": int(blocks),
+                             "pairs_with_opened_record": int(masked)},
+        "valu_insts_per_launch": valu_insts, "scalar_insts_per_launch": scalar_insts,
+        "cycles_per_pair_valu": pair_cycles, "issue_cycles_per_form": c, "issue_cycles_provenance": ISSUE_PROVENANCE,
+        "clock_ghz_in_kernel": ws.clock_ghz, "simds": simds,
+        "floor_ms_valu_only": floor_valu_ms, "floor_ms_valu_plus_scalar": floor_all_ms,
+        "kernel_ms": launch_ms, "frac_of_valu_floor": floor_valu_ms / launch_ms,
+        "frac_of_valu_plus_scalar_floor": floor_all_ms / launch_ms,
+        "wave_lifetime_ms": {"mean": ws.wave_cycles_mean / clock_hz * 1e3, "max": ws.wave_cycles_max / clock_hz * 1e3},
+    }
 
 
-def cpu_baseline(pkg, n, theta, ic, budget_s=25.0):
-    """The CPU oracle ("port": this repo's restatement of the reference recurrence — the reference
-    has no CPU path) timed on this box's host cores on the same workload: whole steps, all stages,
-    OpenMP over all cores, until ~budget_s of wall time is used (at least one step)."""
-    import oracle as O
-    O.build()
-    cores = O.max_threads()
+def _oracle_steps(O, n, theta, ic, nthreads, budget_s, max_steps):
     p = O.params(theta=theta)
     st = O.Oracle(n, p)
     st.upload(*ic)
     t0 = time.time()
-    steps = 0
     per = []
     while True:
         t1 = time.time()
-        st.step(1, order=O.ORDER_PREORDER)
+        st.step(1, order=O.ORDER_PREORDER, nthreads=nthreads)
         per.append(time.time() - t1)
-        steps += 1
-        if time.time() - t0 + per[-1] > budget_s or steps >= 5:
+        if time.time() - t0 + per[-1] > budget_s or len(per) >= max_steps:
             break
     tm = st.times()
     cnt = st.counts()
     st.close()
-    t_step = min(per)
-    return {
+    return min(per), len(per), tm, cnt
+
+
+def cpu_baseline(pkg, n, theta, ic, budget_s=16.0):
+    """The CPU oracle ("port": this repo's restatement of the reference recurrence — the reference has no CPU
+    path; gcc -O3, iterative walk, OpenMP) timed on this box's host cores: whole steps, all stages.  `value` =
+    the bench workload on all cores; plus BASELINE.json configs[0] (65,536 bodies) on all cores and on ONE
+    thread.  Bounded: about 25 s of CPU wall time in total."""
+    import oracle as O
+    O.build()
+    cores = O.max_threads()
+    t_step, steps, tm, cnt = _oracle_steps(O, n, theta, ic, 0, budget_s, 5)
+    out = {
         "value": n / t_step, "unit": "particles/s/step", "cores": cores, "kind": "port",
         "sample": f"{steps} whole step(s) of the same {n}-body theta={theta} workload, all stages, "
                   f"OpenMP x{cores}; best step {t_step:.3f} s (force {tm['force']:.3f} s)",
         "ms_per_step": t_step * 1e3,
         "oracle_counts_per_body": {"V": cnt["V"] / n, "O": cnt["O"] / n, "P": cnt["P"] / n},
     }
+    n1 = 65536
+    ic1 = pkg.plummer(n1, seed=42)
+    ta, sa, tma, _ = _oracle_steps(O, n1, 0.5, ic1, 0, 3.0, 10)
+    t1, s1, tm1, _ = _oracle_steps(O, n1, 0.5, ic1, 1, 6.0, 3)
+    out["config0_65536_bodies_theta0.5"] = {
+        "all_cores": {"value": n1 / ta, "unit": "particles/s/step", "cores": cores, "ms_per_step": ta * 1e3,
+                      "sample": f"best of {sa} whole steps (force {tma['force'] * 1e3:.1f} ms)"},
+        "one_thread": {"value": n1 / t1, "unit": "particles/s/step", "cores": 1, "ms_per_step": t1 * 1e3,
+                       "sample": f"best of {s1} whole steps (force {tm1['force'] * 1e3:.1f} ms)"},
+    }
+    return out
 
 
 def main():
@@ -248,28 +289,40 @@ def main():
             V, O, P = [(a + b) / 2.0 for a, b in zip(counts0, counts1)]
             bytes_alg = b_alg(V, O, P, n_total)
             avg_force_ms = float(np.mean(f_ms))
-            achieved = bytes_alg / (avg_force_ms * 1e-3) / 1e9
-            traffic = load_traffic(n_total, args.theta)
-            valu = load_valu_insts(n_total, args.theta)
+            ws = eng.force_walk_stats()          # the walk's event counters + in-kernel clock, counted now
+            props = torch.cuda.get_device_properties(local_rank)
+            issue = issue_roofline(ws, 4 * props.multi_processor_count, avg_force_ms)
+            # useful arithmetic of the recurrence (ref:205-213): 20 flop per interaction actually taken or tested
+            # by a body (V cell MACs + P body interactions): 3 sub, 5 for d2 + eps2, rsq, 2 for the MAC,
+            # 3 for f, 6 for the accumulate
+            useful_tflops = (V + P) * 20.0 / (avg_force_ms * 1e-3) / 1e12
+            traffic, traffic_src = load_traffic(n_total, args.theta)
+            alg_gbs = bytes_alg / (avg_force_ms * 1e-3) / 1e9
             roofline = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "force_fast_kernel",
+                "bound": "valu", "achieved": useful_tflops, "peak": FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                "frac": useful_tflops / FP32_VECTOR_TFLOPS,
+                "traffic": traffic, "traffic_provenance": traffic_src,
+                "kernel": "force_fast_kernel<0,false> (csrc/bh_force.hip, hand-scheduled walk)",
                 "avg_launch_ms": avg_force_ms,
                 "launches_timed": int(len(f_ms)),
-                "algorithmic_bytes_per_launch": bytes_alg,
-                "per_body": {"V": V / n_total, "O": O / n_total, "P": P / n_total,
-                             "bytes": bytes_alg / n_total},
-                "hbm_copy_measured_GBs": measured_copy_bandwidth(torch),
-                "valu_issue_frac": (valu * 4.0 / (1024 * avg_force_ms * 1e-3 * 2.4e9)) if valu else None,
-                "limiter": "instruction issue: 26 instructions (16 VALU) per (record, wave), 57.8M such pairs on "
-                           "1024 SIMDs vs a 21-29 ns memory-free microbenchmark floor of the 15-VALU body "
-                           "(DESIGN.md §4, tools/ubench_valu.hip); valu_issue_frac = committed SQ_INSTS_VALU x 4 cycles / "
-                           "(1024 SIMDs x this run's launch time x 2.4 GHz): the vector ALU is the saturated unit; "
-                           "HBM is ~0.4 % utilised",
-                "note": "algorithmic = per-lane no-reuse bytes of the recurrence (SURVEY 8d); the "
-                        "wave-cooperative kernel fetches each record once per 64 lanes and the tree is "
-                        "cache-resident, so this can exceed the HBM peak; 'traffic' is the measured HBM side",
+                "why_valu": "the walk is bound by VALU instruction ISSUE: every record field arrives in SGPRs, and "
+                            "SGPR-operand / packed / compare / rsq forms issue at 3.8-7.8 cycles per wave64 "
+                            "instruction (full rate 2.3 only for 2-source all-VGPR ops); the 97 %-L2-resident tree "
+                            "keeps HBM at a few per cent (DESIGN.md §4)",
+                "issue": issue,
+                "useful_flop_per_launch": (V + P) * 20.0,
+                "lane_efficiency": (V + P) / max(1.0, 2.0 * float(ws.pairs) * 64.0),
+                "per_body": {"V": V / n_total, "O": O / n_total, "P": P / n_total, "bytes": bytes_alg / n_total},
+                "hbm": {
+                    "algorithmic_bytes_per_launch": bytes_alg, "algorithmic_GBs": alg_gbs,
+                    "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                    "measured_traffic_GBs": (traffic / (avg_force_ms * 1e-3) / 1e9) if traffic else None,
+                    "measured_traffic_over_hbm_peak": (traffic / (avg_force_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "hbm_copy_measured_GBs": measured_copy_bandwidth(torch),
+                    "note": "informational: SURVEY §8(d)'s per-lane no-reuse byte model is not HBM traffic for a "
+                            "wave-cooperative walk (one scalar fetch per record per 64 bodies, tree resident in "
+                            "L2 / Infinity Cache), so it can exceed the HBM peak; the measured side is `traffic`",
+                },
             }
             stages = {"avg_force_ms": avg_force_ms, "avg_step_ms_device": float(np.mean(s_ms)),
                       "last_step_ms": {"bbox": st.ms_bbox, "morton": st.ms_morton, "sort": st.ms_sort,

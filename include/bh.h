@@ -150,6 +150,20 @@ int bh_integrate(bh_ctx* c); /* integrateKernel ref:282                         
 int bh_force_range(bh_ctx* c, int lo, int hi);
 /* same traversal with per-body V/O/P counters; totals land in bh_stats */
 int bh_force_count(bh_ctx* c);
+/* Measurement only: one launch of the default force walk with its event counters switched on (accelerations
+   are not stored).  What the walk issued, summed over all waves — the quantities its issue-rate roofline is
+   priced with (bench.py) — and the shader clock the waves saw while they ran. */
+typedef struct bh_walk_stats {
+  uint64_t waves;        /* 64-body groups                                                            */
+  uint64_t pairs;        /* record pairs evaluated (two records per packed instruction; a block of an
+                            odd number of children evaluates one null record)                         */
+  uint64_t blocks;       /* child blocks popped (= pushes + 1 per wave)                                */
+  uint64_t masked_pairs; /* pairs with an opened record (force half runs with the take masks)          */
+  double clock_ghz;      /* median over the waves of shader cycles / constant-clock time               */
+  double wave_cycles_max, wave_cycles_mean; /* wave lifetime, shader cycles                            */
+  uint64_t reserved[4];
+} bh_walk_stats;
+int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out);
 
 /* ---- data out ---- */
 /* caller (upload) order; any pointer may be NULL */

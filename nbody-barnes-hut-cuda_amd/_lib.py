@@ -43,6 +43,13 @@ class BhStats(C.Structure):
     ]
 
 
+class BhWalkStats(C.Structure):
+    """struct bh_walk_stats: event counters of one launch of the default force walk (measurement)."""
+    _fields_ = [("waves", C.c_uint64), ("pairs", C.c_uint64), ("blocks", C.c_uint64), ("masked_pairs", C.c_uint64),
+                ("clock_ghz", C.c_double), ("wave_cycles_max", C.c_double), ("wave_cycles_mean", C.c_double),
+                ("reserved", C.c_uint64 * 4)]
+
+
 class BhDdSizes(C.Structure):
     """struct bh_dd_sizes: buffer sizes of the domain-decomposed stepping."""
     _fields_ = [(k, C.c_int64) for k in
@@ -73,6 +80,7 @@ SYMBOLS = [
     ("bh_integrate", C.c_int, [_P]),
     ("bh_force_range", C.c_int, [_P, C.c_int, C.c_int]),
     ("bh_force_count", C.c_int, [_P]),
+    ("bh_force_walk_stats", C.c_int, [_P, C.POINTER(BhWalkStats)]),
     ("bh_download", C.c_int, [_P] + [_F] * 6),
     ("bh_download_acc", C.c_int, [_P] + [_F] * 3),
     ("bh_download_bounds", C.c_int, [_P, _F]),

@@ -13,6 +13,9 @@
 
 #include <new>
 
+#include <algorithm>
+#include <vector>
+
 #include "bh_internal.h"
 
 #define BH_HIP(c, call)                       \
@@ -312,6 +315,47 @@ int bh_integrate(bh_ctx* c) {
   BH_NEED(c, BH_ST_FORCE);
   BH_HIP(c, bhk_integrate(c));
   c->stage = BH_ST_UPLOADED;  // positions changed: bbox..force must be redone
+  return BH_OK;
+}
+
+int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
+  if (!out) return BH_ERR_BAD_ARG;
+  BH_NEED(c, BH_ST_COM);
+  if (c->p.strict_fp || c->p.literal_force || c->dd) return BH_ERR_BAD_ARG;  // the default walk only
+  memset(out, 0, sizeof(*out));
+  const size_t W = ((size_t)c->n + 63) / 64;
+  u32* rows = nullptr;
+  BH_HIP(c, hipMalloc((void**)&rows, W * 8 * sizeof(u32)));
+  std::vector<u32> h(W * 8);
+  hipError_t e = hipMemsetAsync(rows, 0, W * 8 * sizeof(u32), c->stream);
+  if (e == hipSuccess) e = bhk_force_walk_stats(c, rows);
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), rows, W * 8 * sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(rows);
+  if (e != hipSuccess) {
+    c->last_hip = (int)e;
+    return BH_ERR_HIP;
+  }
+  std::vector<double> ghz;
+  ghz.reserve(W);
+  double cyc_max = 0, cyc_sum = 0;
+  for (size_t w = 0; w < W; w++) {
+    const u32* r = &h[w * 8];
+    if (r[6] == 0) continue;
+    out->waves++;
+    out->pairs += r[0];
+    out->blocks += r[1];
+    out->masked_pairs += r[2];
+    if (r[5]) ghz.push_back((double)r[4] / ((double)r[5] * 10.0));  // 100 MHz ticks -> ns
+    cyc_max = r[4] > cyc_max ? (double)r[4] : cyc_max;
+    cyc_sum += (double)r[4];
+  }
+  if (!ghz.empty()) {
+    std::nth_element(ghz.begin(), ghz.begin() + ghz.size() / 2, ghz.end());
+    out->clock_ghz = ghz[ghz.size() / 2];
+  }
+  out->wave_cycles_max = cyc_max;
+  out->wave_cycles_mean = out->waves ? cyc_sum / (double)out->waves : 0.0;
   return BH_OK;
 }
 

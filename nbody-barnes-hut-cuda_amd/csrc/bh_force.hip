@@ -439,7 +439,10 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   BH_M8(MB, T1) BH_M9(R0, R1) BH_CHK(qm, MA, MB)
 #define BH_NOMASK(MA, MB) ""
 #define BH_SEG(q, qm, ...) BH_X(BH_SEG_, "L_seg" #q "_%=", BH_NOMASK, qm, __VA_ARGS__)
-#define BH_SEGM(q, qm, ...) BH_X(BH_SEG_, "L_segm" #q "_%=", BH_FM, qm, __VA_ARGS__) "s_branch L_seg" #qm "_%=\n"
+#define BH_STAT_MASKED ".if %c[stats]\n s_add_u32 s31, s31, 1\n .endif\n"
+#define BH_SEGM(q, qm, ...)                                                                              \
+  "L_segm" #q "_%=:\n" BH_STAT_MASKED BH_X(BH_SEG_, "L_segmx" #q "_%=", BH_FM, qm, __VA_ARGS__)           \
+  "s_branch L_seg" #qm "_%=\n"
 #define BH_LAST_(LBL, MASK, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM)                                   \
   LBL ":\n" BH_F1(GM, FR) BH_F2(FR) BH_F3(FR) MASK(FMA, FMB) BH_FA(FDX, "v[42:43]") BH_FA(FDY, "v[44:45]") \
   BH_FA(FDZ, "v[46:47]")
@@ -447,8 +450,10 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_PUSH1(FIRST, META)                                                                            \
   "s_mov_b32 m0, s30\n"                                                                                   \
   "s_add_u32 s30, s30, 1\n"                                                                               \
+  ".if %c[stats] == 0\n"                                                                                  \
   "s_max_u32 s31, s31, s30\n"                                                                             \
   "s_max_u32 s16, s16, " META "\n"                                                                        \
+  ".endif\n"                                                                                              \
   "v_writelane_b32 v48, " FIRST ", m0\n"                                                                  \
   "v_writelane_b32 v49, " META ", m0\n"                                                                   \
   "v_writelane_b32 v50, s26, m0\n"                                                                        \
@@ -472,8 +477,8 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   BH_SEG(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0) BH_LAST("L_seg0_%=", BH_NOMASK, BH_S0, "s[42:43]")
 #define BH_SEGM_ALL                                                                                      \
   BH_SEGM(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEGM(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)           \
-  BH_SEGM(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0) BH_LAST("L_segm0_%=", BH_FM, BH_S0, "s[42:43]")          \
-  "s_branch L_pop_%=\n"
+  BH_SEGM(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0)                                                          \
+  "L_segm0_%=:\n" BH_STAT_MASKED BH_LAST("L_segmx0_%=", BH_FM, BH_S0, "s[42:43]") "s_branch L_pop_%=\n"
 #define BH_ARMS_ALL                                                                                      \
   BH_ARMS_(3, "s[10:11]", "s94", "s96", "s95", "s97") BH_ARMS_(2, "s[14:15]", "s78", "s80", "s79", "s81") \
   BH_ARMS_(1, "s[10:11]", "s62", "s64", "s63", "s65") BH_ARMS_(0, "s[14:15]", "s46", "s48", "s47", "s49")
@@ -489,11 +494,19 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // (unsplit cell of > 8 bodies); ax..az are then invalid and the caller redoes the wave.
 // BUDGET: at most `budget` child blocks are popped (a malformed pool cannot hang the wave); the walk then
 // stops and limit_hit is set.  `root` must be an even record index.
-template <bool BUDGET>
+// STATS (measurement only, result discarded): s16 / s17 / s31 count pairs evaluated / blocks popped / pairs that
+// took the masked path instead of tracking overflow, and the walk is stamped with s_memtime (shader clock)
+// and s_memrealtime (100 MHz); st[0..5] = pairs, blocks, masked pairs, 0, shader cycles, 10-ns ticks.
+template <bool BUDGET, bool STATS = false>
 __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u64 m0, float px, float py,
                                                   float pz, float eps2, float& ax, float& ay, float& az,
-                                                  int budget, bool& limit_hit) {
+                                                  int budget, bool& limit_hit, u32* st = nullptr) {
   int maxsp, maxc, left;
+  u64 t0 = 0, r0 = 0;
+  if (STATS) {
+    t0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
   asm volatile(
       "s_mov_b64 s[28:29], exec\n"
       "s_mov_b64 s[20:21], %[base]\n"
@@ -538,6 +551,13 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
       "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
       "L_small_%=:\n"
+      ".if %c[stats]\n"
+      "s_add_u32 s17, s17, 1\n"   // blocks popped
+      "s_add_u32 s24, s33, 1\n"
+      "s_lshr_b32 s24, s24, 1\n"
+      "s_min_u32 s24, s24, 4\n"
+      "s_add_u32 s16, s16, s24\n"  // pairs evaluated
+      ".endif\n"
       "v_readlane_b32 s33, v52, s33\n"
       "s_mov_b64 exec, s[34:35]\n"
       "s_add_u32 s24, s22, s33\n"
@@ -561,7 +581,8 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_mov_b32 %[left], s17\n"
       : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left)
       : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
-        [eps2] "s"(eps2), [budget] "s"(budget), [use_budget] "n"(BUDGET ? 1 : 0)
+        [eps2] "s"(eps2), [budget] "s"(STATS ? 0 : budget), [use_budget] "n"(BUDGET && !STATS ? 1 : 0),
+        [stats] "n"(STATS ? 1 : 0)
       : "memory", "vcc", "scc", "m0", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21",
         "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
         "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
@@ -571,6 +592,18 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
         "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",
         "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
         "v50", "v51", "v52");
+  if (STATS) {
+    const u64 t1 = __builtin_amdgcn_s_memtime();
+    const u64 r1 = __builtin_amdgcn_s_memrealtime();
+    st[0] = (u32)maxc;   // s16: pairs
+    st[1] = (u32)left;   // s17: blocks
+    st[2] = (u32)maxsp;  // s31: masked pairs
+    st[3] = 0;
+    st[4] = (u32)(t1 - t0);
+    st[5] = (u32)(r1 - r0);
+    limit_hit = false;
+    return true;
+  }
   limit_hit = BUDGET && left < 0;
   return maxsp <= 64 && maxc <= 8;
 }
@@ -616,6 +649,37 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   }
   if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
+}
+
+// measurement only (bh_force_walk_stats): the hand-scheduled walk with its event counters and clock stamps,
+// one row of 8 words per wave; accelerations are not stored
+__global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __restrict__ frec_g,
+                                                               const float4* __restrict__ posm, int n, float eps2,
+                                                               int xcd_mode, u32* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int chunk = block_chunk(xcd_mode);
+  const int wave = chunk * (int)(blockDim.x >> 6) + wib;
+  const int i = wave * 64 + lane;
+  const bool valid = i < n;
+  float px, py, pz;
+  {
+    const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    px = p.x; py = p.y; pz = p.z;
+  }
+  float ax, ay, az;
+  const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
+  if (m0 == 0) return;
+  bool limit;
+  u32 st[6];
+  (void)fast_traverse_asm<false, true>(frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit, st);
+  if (lane == 0) {
+    u32* r = rows + (size_t)wave * 8;
+#pragma unroll
+    for (int k = 0; k < 6; k++) r[k] = st[k];
+    r[6] = (u32)__popcll(m0);
+    r[7] = __float_as_uint(ax + ay + az);  // keeps the walk's arithmetic alive
+  }
 }
 
 // ------------------------------------------------------------------ integrate
@@ -786,6 +850,15 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
                                                                mode, c->info, 0, 0);
     }
   }
+  return hipGetLastError();
+}
+
+hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [ceil(n/64)][8], device */) {
+  int tpb = c->p.force_block;
+  if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
+  const int mode = c->p.xcd_mode == 2 ? 0 : c->p.xcd_mode;
+  const int g2 = (c->n + tpb - 1) / tpb;
+  force_walk_stats_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->n, c->p.eps2, mode, rows);
   return hipGetLastError();
 }
 

@@ -182,6 +182,7 @@ hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream,
                           float4* acc);  // fast kernel from pool record `root`
+hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows);  // measurement: per-wave event counters of the fast walk
 hipError_t bhk_integrate(bh_ctx* c);
 void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 

@@ -144,6 +144,13 @@ class Engine:
     def force_count(self):
         self._ck(lib.bh_force_count(self._h), "bh_force_count")
 
+    def force_walk_stats(self):
+        """-> BhWalkStats: what one launch of the default force walk issued (measurement only)."""
+        from ._lib import BhWalkStats
+        st = BhWalkStats()
+        self._ck(lib.bh_force_walk_stats(self._h, C.byref(st)), "bh_force_walk_stats")
+        return st
+
     def integrate(self):
         self._ck(lib.bh_integrate(self._h), "bh_integrate")
 

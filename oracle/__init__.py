@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libbh_oracle.so")
 
-ORDER_PREORDER, ORDER_BATCHED = 0, 1
+ORDER_PREORDER, ORDER_BATCHED, ORDER_PREORDER_RECURSIVE = 0, 1, 2
 KIND_BODY, KIND_INTERNAL, KIND_MULTI, KIND_PAD = 0, 1, 2, 3
 
 NODE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("m", "f4"), ("s", "f4"),
@@ -73,6 +73,8 @@ def lib():
         L.bho_last_counts.argtypes = [C.c_void_p, _U64, _U64, _U64, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bho_last_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.bho_group_stats.argtypes = [C.c_void_p, _F, C.c_int, C.POINTER(Params), C.c_int, C.c_int, _U64, _U64,
+                                      _U64, _U64]
         L.bho_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -175,6 +177,17 @@ def force(rec, xyzm, p, order=ORDER_PREORDER, lo=0, hi=None, counters=True, nthr
                     O.ctypes.data_as(_U32) if counters else None,
                     P.ctypes.data_as(_U32) if counters else None, int(nthreads))
     return acc, V, O, P
+
+
+def group_stats(rec, xyzm, p, group=64, stride=1):
+    """Work of the shared traversal of `group` consecutive sorted bodies (the GPU kernel's scheme), summed over
+    every stride-th group: -> dict(records, pops, leaf_bodies, groups)."""
+    rec = np.ascontiguousarray(rec)
+    xyzm = _f(xyzm)
+    out = [C.c_uint64() for _ in range(4)]
+    lib().bho_group_stats(rec.ctypes.data, _fp(xyzm), xyzm.shape[0], C.byref(p), int(group), int(stride),
+                          *[C.byref(o) for o in out])
+    return dict(records=out[0].value, pops=out[1].value, leaf_bodies=out[2].value, groups=out[3].value)
 
 
 def integrate(xyzm, vel3, acc4, p):

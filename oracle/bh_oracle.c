@@ -468,6 +468,36 @@ static void walk_pre(fctx* c, int e) {
   }
 }
 
+/* the same pre-order walk without recursion (bench.py's CPU baseline): a frame is the unvisited rest of a
+   child block, so the visit order — hence every sum — is identical to walk_pre's */
+static void walk_pre_iter(fctx* c) {
+  int nxt[64], left[64], sp = 1; /* one frame per level: depth <= 21 + root */
+  nxt[0] = 0; left[0] = 1;
+  while (sp > 0) {
+    const int e = nxt[sp - 1]++;
+    if (--left[sp - 1] == 0) sp--;
+    const bho_node* r = &c->rec[e];
+    if (r->m <= 0.0f) continue; /* ref:203 */
+    BHO_DIST(c, r->x, r->y, r->z);
+    if (r->kind == BHO_KIND_BODY) {
+      BHO_ACCUM(c, r->m);
+      c->P++;
+      continue;
+    }
+    c->V++;
+    if (r->s / dist < c->theta) { /* ref:208 */
+      BHO_ACCUM(c, r->m);
+      continue;
+    }
+    c->O++;
+    if (r->kind == BHO_KIND_INTERNAL) {
+      nxt[sp] = r->first; left[sp] = r->count; sp++;
+    } else {
+      multi_leaf(c, r);
+    }
+  }
+}
+
 static void walk_batched(fctx* c, int first, int count) {
   int opened[8], no = 0;
   for (int k = 0; k < count; k++) {
@@ -511,8 +541,10 @@ void bho_force(const bho_node* rec, const float* xyzm, int lo, int hi, const bho
     c.V = c.O = c.P = 0;
     if (order == BHO_ORDER_BATCHED)
       walk_batched(&c, 0, 1);
-    else
+    else if (order == BHO_ORDER_PREORDER_RECURSIVE)
       walk_pre(&c, 0); /* ref:198 stack = {root} */
+    else
+      walk_pre_iter(&c);
     acc4[4 * (size_t)i + 0] = c.ax; /* ref:222-224 */
     acc4[4 * (size_t)i + 1] = c.ay;
     acc4[4 * (size_t)i + 2] = c.az;

@@ -43,6 +43,7 @@ typedef struct bho_node {
 } bho_node;
 
 #define BHO_ORDER_PREORDER 0 /* depth-first, children ascending, each child finished before the next */
+#define BHO_ORDER_PREORDER_RECURSIVE 2 /* the same order by plain recursion (cross-check of the iterative walk) */
 #define BHO_ORDER_BATCHED 1  /* per opened cell: evaluate all children ascending (accepted ones and
                                 multi-body leaves accumulate at once), then descend into the opened
                                 internal children in DESCENDING order — the GPU kernel's order     */

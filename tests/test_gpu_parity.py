@@ -250,6 +250,27 @@ def test_force_fast_vs_oracle(pkg, orc, n, theta, variant):
     e.close()
 
 
+def test_force_walk_stats_match_the_oracles_group_walk(pkg, orc):
+    """bh_force_walk_stats (the counters bench.py prices the issue-rate roofline with): blocks popped by the
+    64-body waves == pops of the oracle's group walk on the same tree (MAC ties aside), pairs = the records
+    of those blocks two at a time, and the in-kernel clock is a plausible shader clock."""
+    n = 65536
+    ic = pkg.plummer(n, seed=42)
+    e = _engine(pkg, ic)
+    e.tree_stages()
+    ws = e.force_walk_stats()
+    rec = e.download_tree()
+    bodies = e.download_sorted_bodies()
+    p = oparams(orc, e.params)
+    g = orc.group_stats(rec, bodies, p, 64, 1)
+    assert ws.waves == g["groups"] == n // 64
+    assert abs(int(ws.blocks) - g["pops"]) <= 2e-3 * g["pops"]
+    assert 2 * ws.pairs >= g["records"] * (1 - 2e-3) and 2 * ws.pairs <= (g["records"] + g["pops"]) * (1 + 2e-3)
+    assert 0 < ws.masked_pairs < ws.pairs
+    assert 1.0 < ws.clock_ghz < 2.6 and ws.wave_cycles_max >= ws.wave_cycles_mean > 0
+    e.close()
+
+
 def test_force_theta0_is_direct_sum(pkg, orc):
     """theta = 0 opens every cell: the traversal must touch every body exactly once."""
     n = 2048

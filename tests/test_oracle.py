@@ -135,6 +135,18 @@ def test_uncompressed_pairs_overflow_is_reported(orc):
         oracle_pipeline(orc, ic, orc.params(compress=0))
 
 
+def test_iterative_walk_equals_recursive_walk(pkg, orc):
+    """the pre-order walk the CPU baseline times (explicit frames) == plain recursion, bit for bit"""
+    for n, theta in ((5000, 0.5), (20000, 0.3)):
+        ic = pkg.plummer(n, seed=13)
+        p = orc.params(theta=theta)
+        o = oracle_pipeline(orc, ic, p)
+        a = orc.force(o["rec"], o["xyzm"], p, orc.ORDER_PREORDER)
+        b = orc.force(o["rec"], o["xyzm"], p, orc.ORDER_PREORDER_RECURSIVE)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+
+
 def test_path_compression_preserves_forces(pkg, orc):
     """compress=1 (engine tree) vs compress=0 (literal chain cells): same accepted bodies for every
     particle; bit-identical accelerations in pre-order; fewer MAC evaluations."""
