@@ -187,10 +187,14 @@ def main():
     multi = world > 1 or os.environ.get("BH_FORCE_DIST") == "1"
     if multi:
         import torch.distributed as dist
+        # a finite collective timeout: a rank stuck in (or missing from) an exchange ends every rank with a
+        # non-zero exit (torch's watchdog aborts the process) instead of hanging the node
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("BH_COLLECTIVE_TIMEOUT_S", "180")))
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=tmo)
 
     n_total = args.n if args.strong else args.n * world  # default weak scaling: fixed bodies per GPU
     ic = pkg.plummer(n_total, seed=args.seed)  # identical on every rank (counter-based RNG)
@@ -218,13 +222,15 @@ def main():
         # A failure every rank hits alike (the size negotiations are functions of all-gathered data, so
         # capacity errors are) drops all ranks to the replicated scheme together instead of losing the run.
         try:
+            # BH_BENCH_LET_CAP: rehearsal hook (tests/test_gpu_dist.py drives the fallback with a tiny LET capacity)
+            let_cap = int(os.environ["BH_BENCH_LET_CAP"]) if rehearsal and "BH_BENCH_LET_CAP" in os.environ else None
             stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
-                                           xcd_mode=args.xcd_mode,
+                                           xcd_mode=args.xcd_mode, let_cap=let_cap,
                                            force_block=args.force_block, force_variant=args.force_variant)
             eng = stepper.e
             stepper.step(args.warmup)
-        except Exception as ex:  # noqa: BLE001
-            fallback_reason = repr(ex)
+        except bhdist.DomainLeft as ex:  # raised on every rank after the same exchange; anything else is rank-local
+            fallback_reason = repr(ex)   # and must fail the run (a mismatched collective would hang the others)
             print(f"[bench rank {rank}] domain-decomposed stepping failed ({fallback_reason}); "
                   "falling back to the replicated scheme", file=sys.stderr, flush=True)
             dist_mode = "replicated"
@@ -253,7 +259,7 @@ def main():
     else:
         try:
             stepper.step(args.steps)
-        except Exception as ex:  # noqa: BLE001 - collective by construction (see DomainStepper.step)
+        except bhdist.DomainLeft as ex:  # collective by construction (see DomainStepper.step)
             if dist_mode != "domain":
                 raise
             fallback_reason = repr(ex)

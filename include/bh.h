@@ -40,7 +40,9 @@ typedef enum bh_status {
   BH_ERR_POOL_OVERFLOW = -5,/* octree record pool exhausted (cannot happen with
                                the 2n+8 pool; checked anyway, cf. ref:321 D8)     */
   BH_ERR_ORDER = -6,        /* stage called before the stage it depends on         */
-  BH_ERR_SMALL_BUFFER = -7  /* caller buffer too small for a download              */
+  BH_ERR_SMALL_BUFFER = -7, /* caller buffer too small for a download              */
+  BH_ERR_DEVICE_FLAG = -8   /* a device-side sticky flag (BH_FLAG_*, bh_get_stats().status_flags)
+                               is set: results since it was raised are invalid       */
 } bh_status;
 
 /* Physical and structural parameters.  Defaults = the reference's #defines. */
@@ -120,7 +122,9 @@ typedef struct bh_stats {
 #define BH_FLAG_POOL_OVERFLOW 1
 #define BH_FLAG_STACK_OVERFLOW 2
 #define BH_FLAG_SORT_TIMEOUT 4 /* a look-back spin of the radix sort hit its bound: order invalid */
-#define BH_FLAG_TRAVERSAL_LIMIT 128 /* a wave popped > 2^22 cells: malformed record pool, forces invalid */
+#define BH_FLAG_TRAVERSAL_LIMIT 128 /* a wave popped > 2^22 child blocks: malformed record pool, forces invalid */
+#define BH_FLAG_DD_LET_INVALID 64   /* a gathered LET record pointed outside its segment or had > 8 children: the
+                                       record was closed (never opened), forces of this step are invalid      */
 
 /* ---- lifecycle ( <-> cudaMalloc block ref:311-326, cudaFree ref:372-387 ) ---- */
 int bh_abi_version(void);
@@ -182,6 +186,8 @@ int bh_download_mass(bh_ctx* c, float* m);                              /* calle
 int bh_export_visual(bh_ctx* c, float* pos_xyz, float* col_rgb);
 int bh_get_stats(bh_ctx* c, bh_stats* s);
 int bh_set_timing(bh_ctx* c, int on);
+/* waits for the context's stream; BH_ERR_DEVICE_FLAG if a sticky device flag is set (the step loop's check:
+   stack / pool overflow, sort time-out, traversal limit — see BH_FLAG_*) */
 int bh_sync(bh_ctx* c);
 
 /* ---- multi-rank plumbing: raw device views (valid until bh_destroy) ---- */
@@ -296,6 +302,11 @@ int bh_ic_plummer(int n, uint64_t seed, float a, float G,
 /* the reference's rotating thin disc (ref:297-307) with the same RNG */
 int bh_ic_disc(int n, uint64_t seed, float G,
                float* x, float* y, float* z, float* vx, float* vy, float* vz, float* m);
+/* the same disc exactly as the reference BINARY draws it: srand(seed) and the Microsoft C runtime's rand()
+   (the authors' nbody_v5_bench.exe is an MSVC build; RAND_MAX 32767) in the call order of ref:294-308, so
+   that literal_force trajectories can be diffed against the CUDA program's output (seed 42 = ref:294) */
+int bh_ic_disc_msvc(int n, uint32_t seed, float G,
+                    float* x, float* y, float* z, float* vx, float* vy, float* vz, float* m);
 
 #ifdef __cplusplus
 }

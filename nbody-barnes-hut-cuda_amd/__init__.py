@@ -7,11 +7,11 @@ per stage in the reference's order, `Engine.download` <-> the (absent) result re
 All compute runs in libbh.so (hand-written HIP for gfx950); nothing here computes.
 """
 from ._lib import lib, BhParams, BhNode, BhStats, LIB_PATH  # noqa: F401
-from .engine import Engine, BhError, default_params, KIND_BODY, KIND_INTERNAL, KIND_MULTI  # noqa: F401
+from .engine import Engine, BhError, default_params, KIND_BODY, KIND_INTERNAL, KIND_MULTI, KIND_PAD  # noqa: F401
 from .engine import write_text, read_text, read_snapshot  # noqa: F401
-from .ic import plummer, disc  # noqa: F401
+from .ic import plummer, disc, disc_msvc  # noqa: F401
 
 # `dist` (multi-GPU stepping) imports torch; import it explicitly: from <pkg> import dist
 
-__all__ = ["Engine", "BhError", "default_params", "plummer", "disc", "BhParams", "BhNode",
-           "BhStats", "KIND_BODY", "KIND_INTERNAL", "KIND_MULTI", "LIB_PATH"]
+__all__ = ["Engine", "BhError", "default_params", "plummer", "disc", "disc_msvc", "BhParams", "BhNode",
+           "BhStats", "KIND_BODY", "KIND_INTERNAL", "KIND_MULTI", "KIND_PAD", "LIB_PATH"]

@@ -119,6 +119,7 @@ SYMBOLS = [
     ("bh_dd_download", C.c_int, [_P, _F, _F, _F]),
     ("bh_ic_plummer", C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_float] + [_F] * 7),
     ("bh_ic_disc", C.c_int, [C.c_int, C.c_uint64, C.c_float] + [_F] * 7),
+    ("bh_ic_disc_msvc", C.c_int, [C.c_int, C.c_uint32, C.c_float] + [_F] * 7),
 ]
 
 

@@ -63,6 +63,7 @@ const char* bh_strerror(int s) {
     case BH_ERR_POOL_OVERFLOW: return "octree record pool overflow";
     case BH_ERR_ORDER: return "stage called out of order";
     case BH_ERR_SMALL_BUFFER: return "caller buffer too small";
+    case BH_ERR_DEVICE_FLAG: return "device-side error flag set (see bh_get_stats().status_flags)";
     default: return "unknown status";
   }
 }
@@ -91,6 +92,7 @@ static void free_all(bh_ctx* c) {
     free(c->evring);
   }
   if (c->scan_tmp2) (void)hipFree(c->scan_tmp2);
+  if (c->host_flags) (void)hipHostFree(c->host_flags);
   if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
   if (c->ev_pscan) (void)hipEventDestroy(c->ev_pscan);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -175,6 +177,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->er_hi, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->P, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->info, 1) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->host_flags, sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc(&c->scan_tmp, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipMalloc(&c->scan_tmp2, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
@@ -210,9 +213,22 @@ void bh_destroy(bh_ctx* c) {
   free_all(c);
 }
 
+// plain wait, used by the downloads and bh_get_stats (the caller must be able to read the state and the
+// flags themselves while a flag is set)
+static int sync_raw(bh_ctx* c) {
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  return BH_OK;
+}
+
 int bh_sync(bh_ctx* c) {
   if (!c) return BH_ERR_BAD_ARG;
+  // the sticky flags ride on the same synchronisation: 4 bytes into pinned memory, then one wait
+  if (c->host_flags) {
+    *c->host_flags = 0;
+    BH_HIP(c, hipMemcpyAsync(c->host_flags, &c->info->flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
   BH_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->host_flags && *c->host_flags) return BH_ERR_DEVICE_FLAG;
   return BH_OK;
 }
 
@@ -440,7 +456,7 @@ int bh_download(bh_ctx* c, float* x, float* y, float* z, float* vx, float* vy, f
       int s = d2h(c, dst[k], c->stage_buf + k * N, nb);
       if (s) return s;
     }
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_download_acc(bh_ctx* c, float* ax, float* ay, float* az) {
@@ -452,7 +468,7 @@ int bh_download_acc(bh_ctx* c, float* ax, float* ay, float* az) {
   if ((s = d2h(c, ax, c->stage_buf, nb))) return s;
   if ((s = d2h(c, ay, c->stage_buf + N, nb))) return s;
   if ((s = d2h(c, az, c->stage_buf + 2 * N, nb))) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_download_mass(bh_ctx* c, float* m) {
@@ -462,7 +478,7 @@ int bh_download_mass(bh_ctx* c, float* m) {
   BH_HIP(c, bhk_unpack(c, 0));  // slot 6 of the staging buffer = mass in caller order
   int s = d2h(c, m, c->stage_buf + 6 * N, N * sizeof(float));
   if (s) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_export_visual(bh_ctx* c, float* pos_xyz, float* col_rgb) {
@@ -473,7 +489,7 @@ int bh_export_visual(bh_ctx* c, float* pos_xyz, float* col_rgb) {
   int s;
   if ((s = d2h(c, pos_xyz, c->stage_buf, 3 * N * sizeof(float)))) return s;
   if ((s = d2h(c, col_rgb, c->stage_buf + 3 * N, 3 * N * sizeof(float)))) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_download_counters(bh_ctx* c, uint32_t* V, uint32_t* O, uint32_t* P) {
@@ -486,7 +502,7 @@ int bh_download_counters(bh_ctx* c, uint32_t* V, uint32_t* O, uint32_t* P) {
   if ((r = d2h(c, V, s, nb))) return r;
   if ((r = d2h(c, O, s + N, nb))) return r;
   if ((r = d2h(c, P, s + 2 * N, nb))) return r;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_download_bounds(bh_ctx* c, float bounds[6]) {
@@ -494,7 +510,7 @@ int bh_download_bounds(bh_ctx* c, float bounds[6]) {
   if (!bounds) return BH_ERR_BAD_ARG;
   int s = d2h(c, bounds, c->bounds, 6 * sizeof(float));
   if (s) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_download_keys(bh_ctx* c, uint64_t* keys) {
@@ -503,7 +519,7 @@ int bh_download_keys(bh_ctx* c, uint64_t* keys) {
   const int buf = (c->ever & BH_ST_SORT) ? c->key_buf : 0;
   int s = d2h(c, keys, c->keys[buf], (size_t)c->n * sizeof(u64));
   if (s) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_download_order(bh_ctx* c, int32_t* ids) {
@@ -513,7 +529,7 @@ int bh_download_order(bh_ctx* c, int32_t* ids) {
   float4* h = (float4*)malloc(N * sizeof(float4));
   if (!h) return BH_ERR_OOM;
   int s = d2h(c, h, c->velid[c->cur], N * sizeof(float4));
-  if (!s) s = bh_sync(c);
+  if (!s) s = sync_raw(c);
   if (!s)
     for (size_t i = 0; i < N; i++) memcpy(&ids[i], &h[i].w, 4);
   free(h);
@@ -525,13 +541,13 @@ int bh_download_sorted_bodies(bh_ctx* c, float* xyzm) {
   if (!xyzm) return BH_ERR_BAD_ARG;
   int s = d2h(c, xyzm, c->posm[c->cur], (size_t)c->n * sizeof(float4));
   if (s) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 static int fetch_info(bh_ctx* c, bh_devinfo* h) {
   int s = d2h(c, h, c->info, sizeof(bh_devinfo));
   if (s) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries) {
@@ -545,7 +561,7 @@ int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries) {
   if (capacity < hi.n_entries) return BH_ERR_SMALL_BUFFER;
   s = d2h(c, out, c->rec, (size_t)hi.n_entries * sizeof(bh_node));
   if (s) return s;
-  return bh_sync(c);
+  return sync_raw(c);
 }
 
 int bh_get_stats(bh_ctx* c, bh_stats* st) {
@@ -579,7 +595,7 @@ int bh_timing_history(bh_ctx* c, float* ms_force, float* ms_step, int capacity, 
   if (!c || !count) return BH_ERR_BAD_ARG;
   *count = 0;
   if (!c->timing || c->timed_steps == 0) return BH_OK;
-  int s = bh_sync(c);
+  int s = sync_raw(c);
   if (s) return s;
   const long have = c->timed_steps < BH_TIMING_RING ? c->timed_steps : BH_TIMING_RING;
   const long take = have < capacity ? have : capacity;

@@ -539,7 +539,11 @@ __device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restric
     fr.first = blocks0 + dst[c];
     fr.meta = wc;
   } else if (fr.thr2 >= 0.0f) {
-    fr.first = 0;  // never opened by a remote body (conservative test): index unused
+    // no body of another rank can open this cell (conservative test): every one of them accepts it, so the
+    // exported copy is closed outright — same forces, and the receiver never holds an openable record
+    // whose child block it was not given
+    fr.first = 0;
+    fr.thr2 = -1.0f;
   }
   return fr;
 }
@@ -584,6 +588,35 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
   for (int k = 0; k < wv; k++)
     frec_put(send, off + k, reloc(frec_get(frec, fr.first + k), fr.first + k, w, dst, blocks0, rec_cap));
   if ((wv & 1) && off + wv < stride) frec_put(send, off + wv, frec_null());
+}
+
+// Gathered LET segments are records written by OTHER ranks: before any wave walks them, every openable record
+// (thr2 >= 0) of every remote segment must keep its child block inside its own segment's block area, start it
+// on an even record and have 1..8 children.  A record that does not is closed (thr2 = -1: accepted by every body,
+// never opened) and BH_FLAG_DD_LET_INVALID is raised — a malformed or partially written segment then costs a
+// wrong step that the caller is told about, never an out-of-bounds fetch.  (Cycles inside a segment are
+// impossible to rule out locally; the walk's pop budget, BH_FLAG_TRAVERSAL_LIMIT, bounds them.)
+__global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ pool, int seg_base, int stride,
+                                                          int world, int me, bh_devinfo* __restrict__ info) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)world * stride) return;
+  const int q = (int)(t / stride), k = (int)(t - (long long)q * stride);
+  if (q == me || k == 0) return;  // own segment: written by this rank's export; record 0: the header
+  const long long seg0 = (long long)seg_base + (long long)q * stride;
+  // the header's count = records the sender needed: beyond it (or in a segment sent closed because it did
+  // not fit) nothing was written this step and nothing is reachable
+  const int used = frec_get(pool, seg0).first;
+  if (used > stride ? k >= kSegBlocks0 : k >= used) return;
+  const long long e = (long long)seg_base + t;
+  const bh_frec r = frec_get(pool, e);
+  if (!(r.thr2 >= 0.0f)) return;  // not openable
+  const long long lo = seg0 + kSegBlocks0, hi = seg0 + stride;
+  const bool ok = r.meta >= 1 && r.meta <= 8 && (r.first & 1) == 0 && (long long)r.first >= lo &&
+                  (long long)r.first + r.meta <= hi;
+  if (!ok) {
+    reinterpret_cast<float*>(pool)[BH_FREC_DW(e, BH_FF_THR2)] = -1.0f;
+    atomicOr(&info->flags, BH_FLAG_DD_LET_INVALID);
+  }
 }
 
 // ------------------------------------------------------------------ top tree
@@ -1131,6 +1164,9 @@ int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_lo
   if (most) *most = d->host[67];
   if (flags & BH_FLAG_DD_BODIES) return BH_ERR_POOL_OVERFLOW;
   if (nl < 2 || nl > n_cap) return BH_ERR_POOL_OVERFLOW;
+  // any other sticky flag was raised by the PREVIOUS step (pieces / pool / stack / sort / traversal / LET):
+  // its forces were invalid; the flags are already on the host here, so reporting them costs nothing
+  if (flags) return BH_ERR_DEVICE_FLAG;
   dd_set_n(c, nl);
   return BH_OK;
 }
@@ -1210,6 +1246,12 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
                              hipMemcpyDeviceToHost, c->stream));
   BH_HIP(c, hipEventRecord(d->ev_let, c->stream));
   d->let_copy_pending = true;
+  {
+    const long long recs = (long long)d->world * stride;
+    dd_validate_kernel<<<(unsigned)((recs + 255) / 256), 256, 0, c->stream>>>(d->pool, d->seg_base, stride, d->world,
+                                                                            d->rank, c->info);
+    BH_HIP(c, hipGetLastError());
+  }
   if (d->split) {  // same structure as the own pass's tree: re-emit the records only
     BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_top1, 0));
     dd_top_emit_kernel<<<(kTopCap + 255) / 256, 256, 0, c->stream>>>(

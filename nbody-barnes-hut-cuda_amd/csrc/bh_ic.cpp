@@ -100,4 +100,33 @@ int bh_ic_disc(int n, uint64_t seed, float G, float* x, float* y, float* z, floa
   return BH_OK;
 }
 
+// The reference BINARY's disc: srand(seed) + the Microsoft C runtime's rand() — the authors' nbody_v5_bench.exe
+// is an MSVC build — in the call order of ref:294-308, with the source's own arithmetic
+// (`(float)rand() / RAND_MAX` in float, RAND_MAX = 32767; `* 2.0f * M_PI` and the cos/sin products in double).
+// MSVC rand(): state = state * 214013 + 2531011; return (state >> 16) & 0x7fff.  With seed 42 and
+// bh_params.literal_force = 1 the trajectories can be diffed against the CUDA binary's output.
+int bh_ic_disc_msvc(int n, uint32_t seed, float G, float* x, float* y, float* z, float* vx, float* vy,
+                    float* vz, float* m) {
+  if (n < 1 || !x || !y || !z || !vx || !vy || !vz || !m) return BH_ERR_BAD_ARG;
+  uint32_t state = seed;  // srand(42) ref:294
+  auto rnd = [&state]() -> float {
+    state = state * 214013u + 2531011u;
+    return (float)(int)((state >> 16) & 0x7fffu) / 32767.0f;  // (float)rand() / RAND_MAX
+  };
+  for (int i = 0; i < n; i++) {
+    const float r = 200.0f + rnd() * 1500.0f;                            // ref:297
+    const float a = (float)((double)(rnd() * 2.0f) * kPi);               // ref:298
+    x[i] = (float)((double)r * cos((double)a));                          // ref:299
+    y[i] = (float)((double)r * sin((double)a));                          // ref:300
+    z[i] = (rnd() - 0.5f) * (r * 0.05f);                                 // ref:301
+    m[i] = 2.0f + rnd() * 5.0f;                                          // ref:302
+    const float approx_mass_inside = 50000.0f + r * 100.0f;              // ref:303
+    const float v_mag = sqrtf(G * approx_mass_inside / r);               // ref:304
+    vx[i] = (float)(-sin((double)a) * (double)v_mag);                    // ref:305
+    vy[i] = (float)(cos((double)a) * (double)v_mag);                     // ref:306
+    vz[i] = (rnd() - 0.5f) * 2.0f;                                       // ref:307
+  }
+  return BH_OK;
+}
+
 }  // extern "C"

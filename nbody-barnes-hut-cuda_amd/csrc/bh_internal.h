@@ -133,6 +133,7 @@ struct bh_ctx {
   int rec_cap;
   bh_d4* P;       // [n+1] fp64 exclusive prefix of (m, m x, m y, m z) over sorted bodies
   bh_devinfo* info;
+  int* host_flags;  // pinned: bh_sync reads the sticky flags through it
 
   // scan scratch
   void* scan_tmp;

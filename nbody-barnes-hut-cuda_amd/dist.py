@@ -147,6 +147,12 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
         return e.download_order()
 
 
+class DomainLeft(RuntimeError):
+    """Raised by DomainStepper.step ON EVERY RANK after the same exchange (a rank-local failure announced through
+    the X4 header, or a LET beyond let_cap decided from all-gathered counts): the only exception a caller may
+    answer collectively, e.g. by switching every rank to another scheme.  Anything else is rank-local."""
+
+
 class DomainStepper:
     """One rank of the domain-decomposed step: this rank owns the bodies of one Morton-key range,
     builds only their octree, imports the other ranks' locally-essential records and traverses the
@@ -312,7 +318,7 @@ class DomainStepper:
                         self.lets[:64].view(torch.int32)[10] = -1       # header count < 0: "this rank failed" (record 0 of a
                         # digest pair: field `first` is dword 10, csrc/bh_internal.h)
                         c.all_gather(seg, self.lets[:stride * 32])
-                        raise RuntimeError(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
+                        raise DomainLeft(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
                     e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
                     c.all_gather(seg, self.lets[:stride * 32])          # X4: LET records, in place
                     self._mark(4)
@@ -321,12 +327,12 @@ class DomainStepper:
                     ok, counts = e.dd_let_check(stride, P)
                     self.let_counts = counts
                     if int(counts.min()) < 0:
-                        raise RuntimeError(f"rank {int(counts.argmin())} left the domain-decomposed step")
+                        raise DomainLeft(f"rank {int(counts.argmin())} left the domain-decomposed step")
                     need = int(counts.max())
                     if ok:
                         break
                     if need > self.let_cap:
-                        raise RuntimeError(f"LET of {need} records exceeds let_cap {self.let_cap}")
+                        raise DomainLeft(f"LET of {need} records exceeds let_cap {self.let_cap}")
                     self.let_retries += 1
                     self.stride = min(self.let_cap, _round_up(need * 1.25, 256))
                 # every rank sees the same counts, so every rank picks the same next stride

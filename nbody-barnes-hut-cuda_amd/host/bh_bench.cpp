@@ -4,7 +4,8 @@
 // initial conditions, allocate, upload, run a frame loop timing every step, print the same
 // `Frame | Trajanje (ms) | FPS` table (:351,:366), free.  With no arguments it reproduces the
 // reference's run shape: disc IC, N = 500000 (:31), 1000 frames (:353).
-//   bh_bench [--n N] [--steps K] [--warmup W] [--ic disc|plummer] [--seed S] [--theta T]
+//   bh_bench [--n N] [--steps K] [--warmup W] [--ic disc|msvc|plummer] [--seed S] [--theta T]
+//            (--ic msvc: the disc exactly as the MSVC-built reference binary draws it, srand(seed) + rand())
 //            [--leaf-cap C] [--strict] [--quiet] [--device D]
 //            [--literal-force]   the root-monopole force the CUDA binary literally computes
 //            [--dump FILE]       final state in the older generation's text format (output_bh.txt:1-4)
@@ -36,7 +37,7 @@ int main(int argc, char** argv) {
   int frames = 1000;  // ref:353
   int warmup = 0;
   int device = 0;
-  bool plummer = false, quiet = false;
+  bool plummer = false, msvc = false, quiet = false;
   const char* dump_path = nullptr;  // final state, older generation's text format (output_bh.txt:1-4)
   const char* snap_path = nullptr;  // lossless binary snapshot (checkpoint)
   unsigned long long seed = 42;  // ref:294 srand(42)
@@ -51,7 +52,11 @@ int main(int argc, char** argv) {
     else if (arg("--theta")) p.theta = (float)atof(argv[++i]);
     else if (arg("--leaf-cap")) p.leaf_cap = atoi(argv[++i]);
     else if (arg("--device")) device = atoi(argv[++i]);
-    else if (arg("--ic")) plummer = !strcmp(argv[++i], "plummer");
+    else if (arg("--ic")) {
+      ++i;
+      plummer = !strcmp(argv[i], "plummer");
+      msvc = !strcmp(argv[i], "msvc");
+    }
     else if (arg("--dump")) dump_path = argv[++i];
     else if (arg("--snapshot")) snap_path = argv[++i];
     else if (!strcmp(argv[i], "--literal-force")) p.literal_force = 1;  // what the CUDA binary computes (D1)
@@ -67,6 +72,8 @@ int main(int argc, char** argv) {
   std::vector<float> x(N), y(N), z(N), vx(N), vy(N), vz(N), m(N);
   if (plummer)
     CK(bh_ic_plummer(N, seed, 400.0f, p.G, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
+  else if (msvc)  // ref:294-308 with the Microsoft C runtime's rand(): the binary's own initial conditions
+    CK(bh_ic_disc_msvc(N, (uint32_t)seed, p.G, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
   else
     CK(bh_ic_disc(N, seed, p.G, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
 
@@ -85,7 +92,7 @@ int main(int argc, char** argv) {
   for (int frame = 0; frame < frames; frame++) {
     const double t0 = now_ms();
     CK(bh_step(c));
-    CK(bh_sync(c));
+    CK(bh_sync(c));  // also the step loop's error check: BH_ERR_DEVICE_FLAG if a sticky device flag is set
     const double ms = now_ms() - t0;
     CK(bh_get_stats(c, &st));
     sum += ms;
@@ -95,7 +102,7 @@ int main(int argc, char** argv) {
   const double avg = sum / (frames > 0 ? frames : 1);
   printf("------------------------------------------\n");
   printf("N=%d ic=%s theta=%.2f steps=%d avg %.3f ms/step  %.3e particles/s/step\n", N,
-         plummer ? "plummer" : "disc", p.theta, frames, avg, (double)N / (avg * 1e-3));
+         plummer ? "plummer" : (msvc ? "disc(msvc rand)" : "disc"), p.theta, frames, avg, (double)N / (avg * 1e-3));
   printf("last step stages (ms): bbox %.3f morton %.3f sort %.3f build %.3f com %.3f force %.3f integrate %.3f | "
          "cells %d entries %d depth %d flags %d | avg force %.3f ms\n",
          st.ms_bbox, st.ms_morton, st.ms_sort, st.ms_build, st.ms_com, st.ms_force, st.ms_integrate,

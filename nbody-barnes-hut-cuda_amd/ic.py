@@ -36,3 +36,13 @@ def disc(n, seed=42, G=0.5):
     if st != 0:
         raise ValueError(lib.bh_strerror(st).decode())
     return tuple(arrs)
+
+
+def disc_msvc(n, seed=42, G=0.5):
+    """The disc exactly as the reference binary draws it: srand(seed) + MSVC rand(), call order of
+    nbody_v5_bench.cu:294-308 (for diffing literal_force trajectories against nbody_v5_bench.exe)."""
+    arrs = _alloc(n)
+    st = lib.bh_ic_disc_msvc(int(n), int(seed), float(G), *_ptrs(arrs))
+    if st != 0:
+        raise ValueError(lib.bh_strerror(st).decode())
+    return tuple(arrs)

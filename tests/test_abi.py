@@ -43,7 +43,7 @@ def test_default_params_are_reference_constants(pkg):
 
 def test_strerror(pkg):
     assert pkg.lib.bh_strerror(0) == b"ok"
-    for s in range(-7, 0):
+    for s in range(-8, 0):
         assert pkg.lib.bh_strerror(s) not in (b"ok", b"unknown status")
     assert pkg.lib.bh_strerror(-99) == b"unknown status"
 
@@ -98,6 +98,34 @@ def test_ic_disc_matches_reference_formulae(pkg):
     assert np.allclose(np.hypot(vx, vy), vmag, rtol=1e-5)
     assert np.all(x * vy - y * vx > 0)              # all rotate the same way
     assert np.all(np.abs(vz) <= 1.0)
+
+
+def test_ic_disc_msvc_reproduces_srand42_rand(pkg):
+    """bh_ic_disc_msvc = srand(42) + the Microsoft C runtime's rand() in the call order of
+    nbody_v5_bench.cu:294-308.  The first values of that LCG (state = state*214013 + 2531011,
+    rand = (state >> 16) & 0x7fff, seed 42) are a published known answer: 175, 400, 17869, 30056, 16083."""
+    def msvc(seed, k):
+        s, out = seed, []
+        for _ in range(k):
+            s = (s * 214013 + 2531011) & 0xFFFFFFFF
+            out.append((s >> 16) & 0x7FFF)
+        return out
+    assert msvc(42, 5) == [175, 400, 17869, 30056, 16083]
+    n = 1000
+    x, y, z, vx, vy, vz, m = pkg.disc_msvc(n, seed=42)
+    rnd = (np.array(msvc(42, 5 * n), np.float32) / np.float32(32767.0)).reshape(n, 5)   # (float)rand() / RAND_MAX
+    f = np.float32
+    r = f(200.0) + rnd[:, 0] * f(1500.0)                                   # ref:297
+    a = ((rnd[:, 1] * f(2.0)).astype(np.float64) * np.pi).astype(f)        # ref:298
+    assert np.array_equal(x, (r.astype(np.float64) * np.cos(a.astype(np.float64))).astype(f))   # ref:299
+    assert np.array_equal(y, (r.astype(np.float64) * np.sin(a.astype(np.float64))).astype(f))   # ref:300
+    assert np.array_equal(z, (rnd[:, 2] - f(0.5)) * (r * f(0.05)))          # ref:301
+    assert np.array_equal(m, f(2.0) + rnd[:, 3] * f(5.0))                   # ref:302
+    vmag = np.sqrt(f(0.5) * (f(50000.0) + r * f(100.0)) / r).astype(f)      # ref:303-304
+    assert np.array_equal(vx, (-np.sin(a.astype(np.float64)) * vmag.astype(np.float64)).astype(f))   # ref:305
+    assert np.array_equal(vy, (np.cos(a.astype(np.float64)) * vmag.astype(np.float64)).astype(f))    # ref:306
+    assert np.array_equal(vz, (rnd[:, 4] - f(0.5)) * f(2.0))                # ref:307
+    assert r.min() >= 200.0 and r.max() <= 1700.0
 
 
 def test_ic_bad_args(pkg):

@@ -236,3 +236,78 @@ def test_dd_abi_argument_and_order_checks():
             e.dd_force()
         with pytest.raises(BhError):
             e.dd_upload(*pkg.plummer(60000, seed=1), np.arange(60000, dtype=np.int32))  # above the capacity
+
+
+def test_dd_malformed_let_record_is_closed_and_reported():
+    """hang/fault safety of the first unattended multi-GPU run: a gathered LET record whose child block
+    points outside its own segment is closed by the validation pass of bh_dd_top (never opened), the sticky
+    flag BH_FLAG_DD_LET_INVALID is raised, bh_sync returns BH_ERR_DEVICE_FLAG, and the next step's
+    bh_dd_migrate_apply refuses to go on.  (The corrupted pointer stays inside the pool, so even a missing
+    check could not fault the box.)"""
+    import torch
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    n, world = 60000, 2
+    ic = pkg.plummer(n, seed=7)
+    order = bhdist.global_morton_order(pkg, ic, 0)
+    group = bhdist.LocalGroup(world)
+    stream = torch.cuda.Stream(0)
+    res, errs = [None] * world, []
+
+    class CorruptingComm(bhdist.LocalComm):
+        hits = 0
+
+        def all_gather(self, out, send):
+            g = self.g
+            g.slots[self.rank] = send
+            g.barrier.wait()
+            k = send.numel()
+            o = out.view(-1)
+            for q in range(self.world):
+                o[q * k:(q + 1) * k].copy_(g.slots[q].view(-1))
+            if self.rank == 0 and k % 64 == 0:      # X4 (the only payload that is whole 64-byte digest pairs)
+                seg = o[k:2 * k].view(torch.int32).view(-1, 16)           # rank 1's segment, one row per pair
+                thr = seg.view(torch.float32)[:, 8]
+                cand = torch.nonzero((thr[300:] >= 0) & (seg[300:, 12] > 0))  # an openable record of the block area
+                if len(cand) > 0:   # (a segment sent closed because it did not fit carries no blocks: wait for the retry)
+                    seg[300 + int(cand[0]), 10] = 2                       # child block -> the local tree's first block
+                    CorruptingComm.hits += 1
+            g.barrier.wait()
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = CorruptingComm(group, r)
+            st = bhdist.DomainStepper(pkg, ic, comm, 0, stream=stream, order=order)
+            group.barrier.wait()
+            st.step(1)
+            status = 0
+            try:
+                st.e.sync()
+            except pkg.BhError as ex:
+                status = ex.status
+            flags = st.e.stats().status_flags
+            nxt = None
+            if r == 0:
+                try:
+                    # the next step would stop at the migration phase: drive that entry point alone
+                    st.e.dd_cube_pack(st.x1s.data_ptr())
+                except pkg.BhError as ex:  # pragma: no cover - cube_pack itself does not check flags
+                    nxt = ex.status
+            res[r] = (status, flags, nxt)
+            group.barrier.wait()
+            st.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append((r, ex))
+            group.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0][1]
+    assert CorruptingComm.hits >= 1
+    assert res[0][0] == -8 and res[0][1] & 64, res        # BH_ERR_DEVICE_FLAG, BH_FLAG_DD_LET_INVALID
+    assert res[1] [0] == 0 and res[1][1] == 0, res        # the other rank saw well-formed segments

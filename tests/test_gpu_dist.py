@@ -65,6 +65,29 @@ def test_bench_two_ranks_rehearsal(mode):
         assert len(out["config"]["domain"]["let_records_per_rank"]) == 2
 
 
+def test_bench_two_ranks_domain_fallback_is_collective():
+    """a LET that cannot fit (tiny let_cap) makes DomainStepper raise DomainLeft on EVERY rank after the same
+    exchange; bench.py answers it by moving both ranks to the replicated scheme together, reports
+    `domain_fallback`, and still finishes in lockstep (no rank is left inside a collective)"""
+    env = dict(os.environ)
+    env["BH_BENCH_REHEARSAL"] = "1"
+    env["BH_DIST_MODE"] = "domain"
+    env["BH_BENCH_LET_CAP"] = "2048"
+    env["BH_COLLECTIVE_TIMEOUT_S"] = "120"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--bodies", "100000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "DomainLeft" in out["config"]["domain_fallback"]
+    assert "replicated" in out["config"]["parallelism"]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_domain_stepper_multiprocess_one_gpu(world, tmp_path):
     """the real multi-process flow of the domain-decomposed step (torch.distributed, one process and
