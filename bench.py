@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--xcd-mode", type=int, default=0, help="tuning: block->chunk placement (bh_params.xcd_mode)")
     ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
     ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
+    ap.add_argument("--graph", action="store_true",
+                    help="time bh_step replayed as a HIP graph (no per-stage event records inside the timed region; "
+                         "the force-launch time of the roofline block then comes from 10 extra timed-stage steps)")
     ap.add_argument("--force-variant", type=int, default=0,
                     help="A/B: 0 = hand-scheduled force walk (default), 1 = compiler-scheduled walk")
     args = ap.parse_args()
@@ -213,7 +216,7 @@ def main():
         e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
                                         xcd_mode=args.xcd_mode,
                                         leaf_cap=args.leaf_cap, force_block=args.force_block,
-                                        force_variant=args.force_variant)
+                                        force_variant=args.force_variant, step_graph=1 if args.graph else 0)
         e.upload(*ic)
         return e, st
 
@@ -248,7 +251,7 @@ def main():
         eng.force_count()
         s = eng.stats()
         counts0 = (s.count_V, s.count_O, s.count_P)
-    eng.set_timing(not multi)  # per-step hipEvent pairs on the engine's stream (1-GPU path)
+    eng.set_timing(not multi and not args.graph)  # per-step hipEvent pairs on the engine's stream (1-GPU path)
 
     if dist_mode == "domain" and rank == 0:
         stepper.set_profile(True)   # per-phase event pairs on rank 0's stream (a few microseconds per step)
@@ -286,6 +289,10 @@ def main():
         roofline = None
         stages = None
         if not multi:
+            if args.graph:   # the timed region ran as graph replays: stage times from 10 further, plainly launched steps
+                eng.set_timing(True)
+                eng.step(10)
+                eng.sync()
             f_ms, s_ms = eng.timing_history()
             eng.set_timing(False)
             eng.tree_stages()

@@ -74,7 +74,12 @@ typedef struct bh_params {
                             trajectories against nbody_v5_bench.exe                              */
   int32_t force_block;   /* threads per workgroup of the default force kernel: 64, 128 or 256
                             (0 = library default); waves never cooperate, speed only           */
-  int32_t reserved[2];
+  int32_t step_graph;    /* bh_step: 0 = launch its kernels one by one (default), 1 = replay the step as a HIP
+                            graph, one per ping-pong parity of the body arrays (measured slower on ROCm 7.2:
+                            DESIGN.md)                                                                  */
+  int32_t force_group;   /* bodies per wave of the default force kernel: 64, 32 (upper lanes idle), or
+                            0 = 32 for launches of <= 98,304 bodies (at most ~1.5 waves per SIMD), else 64;
+                            speed only                                                               */
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:

@@ -19,7 +19,7 @@ class BhParams(C.Structure):
         ("leaf_cap", C.c_int32), ("max_depth", C.c_int32), ("key_bits", C.c_int32),
         ("strict_fp", C.c_int32), ("force_variant", C.c_int32), ("xcd_mode", C.c_int32),
         ("sort_variant", C.c_int32), ("literal_force", C.c_int32), ("force_block", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("step_graph", C.c_int32), ("force_group", C.c_int32),
     ]
 
 

@@ -616,15 +616,18 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
                                                          const float4* __restrict__ posm,
                                                          float4* __restrict__ acc, int lo, int hi, float G,
                                                          float eps2, int xcd_mode,
-                                                         bh_devinfo* __restrict__ info, int root, int budget) {
+                                                         bh_devinfo* __restrict__ info, int root, int budget,
+                                                         int group) {
   cfloat_t* frec = (cfloat_t*)frec_g;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int chunk = block_chunk(xcd_mode);
   // waves never cooperate, so the workgroup may be 1, 2 or 4 waves (bh_params.force_block): a CU
-  // slot is released when its LAST wave retires, and per-wave work varies by +-30 %
-  const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * 64 + lane;
-  const bool valid = i < hi;
+  // slot is released when its LAST wave retires, and per-wave work varies by +-30 %.
+  // group = bodies per wave: 64, or 32 (upper lanes idle) when the launch would not even put two waves on
+  // a SIMD — half the bodies walk a smaller union of records and two waves per SIMD hide each other's latency
+  const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * group + lane;
+  const bool valid = lane < group && i < hi;
   float px, py, pz;
   {
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
@@ -807,6 +810,12 @@ __global__ __launch_bounds__(256) void unpack_u32x3_kernel(const u32* __restrict
 
 }  // namespace
 
+// bodies per wave of the fast walk: 32 when 64 would leave most SIMDs with at most one wave (1024 SIMDs)
+static int force_group(const bh_ctx* c, int bodies) {
+  if (c->p.force_group == 32 || c->p.force_group == 64) return c->p.force_group;
+  return bodies <= 64 * 1024 + 32 * 1024 ? 32 : 64;
+}
+
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
   if (hi <= lo) return hipSuccess;
   const int blocks = (hi - lo + 255) / 256;
@@ -836,18 +845,19 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       }
       int tpb = c->p.force_block;  // 64, 128 or 256 threads per workgroup (0 = default)
       if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
-      int g2 = (hi - lo + tpb - 1) / tpb;
+      const int group = force_group(c, hi - lo);
+      int g2 = ((hi - lo + group - 1) / group * 64 + tpb - 1) / tpb;
       if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
       static const bool debug_budget = getenv("BH_FORCE_BUDGET") != nullptr;  // bring-up aid: bounded walk
       if (debug_budget)
         force_fast_kernel<0, true><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                              mode, c->info, 0, kTraversalBudget);
+                                                              mode, c->info, 0, kTraversalBudget, group);
       else if (c->p.force_variant == 1)
         force_fast_kernel<1, false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                               mode, c->info, 0, 0);
+                                                               mode, c->info, 0, 0, group);
       else
         force_fast_kernel<0, false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                               mode, c->info, 0, 0);
+                                                               mode, c->info, 0, 0, group);
     }
   }
   return hipGetLastError();
@@ -869,16 +879,17 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
   const int mode = c->p.xcd_mode == 2 ? 0 : c->p.xcd_mode;
-  const int g2 = (hi - lo + tpb - 1) / tpb;
+  const int group = force_group(c, hi - lo);
+  const int g2 = ((hi - lo + group - 1) / group * 64 + tpb - 1) / tpb;
   // a wave pops one child block per opened cell: no wave of a well-formed pool can pop more blocks than
   // the pool has records, so this bound never fires on valid data and always ends a walk over a cycle
   const int budget = kTraversalBudget;
   if (c->p.force_variant == 1)
     force_fast_kernel<1, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
-                                                       c->p.eps2, mode, c->info, root, budget);
+                                                       c->p.eps2, mode, c->info, root, budget, group);
   else
     force_fast_kernel<0, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
-                                                       c->p.eps2, mode, c->info, root, budget);
+                                                       c->p.eps2, mode, c->info, root, budget, group);
   return hipGetLastError();
 }
 

@@ -109,9 +109,8 @@ struct bh_ctx {
   // onesweep sort (bh_sort_onesweep.hip)
   u32* sw_hist;    // [8][256] global digit totals of every pass
   u64* sw_status;  // [passes][ntiles][256] look-back granules {tag|state|count}
-  u32* sw_ticket;  // [8] monotonic tile tickets, one counter per pass
+  u32* sw_ticket;  // [0..7] tile tickets of the passes (cleared at the end of every sort), [8] sort calls so far
   u32 sort_calls;
-  u32 sort_ticket_base;  // tickets handed out per pass counter so far (the tile count may change between calls)
   int sort_tiles;
 
   // bbox
@@ -150,6 +149,11 @@ struct bh_ctx {
   // counters (bh_force_count)
   u32 *cV, *cO, *cP;
   u64 tV, tO, tP;
+
+  // bh_step as a HIP graph, one per parity of `cur` at entry (bh_api.hip)
+  hipGraphExec_t gexec[2];
+  int g_keybuf[2];
+  bool graph_failed;
 
   // timing
   bool timing;

@@ -57,8 +57,11 @@ __global__ __launch_bounds__(kThreads) void onesweep_hist_kernel(const u64* __re
 __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
     const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
     u32* __restrict__ vout, int n, int shift, const u32* __restrict__ ghist_pass,
-    u64* __restrict__ status, u32* __restrict__ ticket, u32 ticket_base, u32 tag, int first_pass,
+    u64* __restrict__ status, u32* __restrict__ ticket, const u32* __restrict__ call_ptr, int first_pass,
     bh_devinfo* __restrict__ info) {
+  // tag = number of this sort call, kept on the device (sw_ticket[8], advanced by the gather kernel that ends
+  // every sort) so that the kernel arguments of a step never change: bh_step replays as a HIP graph
+  const u32 tag = (*call_ptr + 1u) & 0x3fffffffu;
   __shared__ u32 wcnt[4][256];
   __shared__ u32 gbase[256];
   __shared__ u32 toff[256];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
   __shared__ u64 stage[kTile];  // 32 KB: the tile in digit order (keys, then values as u32)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);  // tickets restart at 0: the gather kernel clears them
 #pragma unroll
   for (int q = 0; q < 4; q++) wcnt[q][threadIdx.x] = 0;
   __syncthreads();
@@ -231,10 +234,14 @@ __global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ pe
                                                       const float4* __restrict__ velid_in,
                                                       float4* __restrict__ posm_out,
                                                       float4* __restrict__ velid_out, int n,
-                                                      u32* __restrict__ sw_hist) {
-  // last kernel of the sort: leave the digit totals cleared for the next call (saves a memset launch)
-  if (blockIdx.x == 0)
+                                                      u32* __restrict__ sw_hist, u32* __restrict__ sw_ticket) {
+  // last kernel of the sort: leave the digit totals and the tile tickets cleared for the next call and
+  // advance the call number (saves a memset launch, keeps every kernel argument of the step constant)
+  if (blockIdx.x == 0) {
     for (int t = threadIdx.x; t < 8 * 256; t += 256) sw_hist[t] = 0u;
+    if (threadIdx.x < 8) sw_ticket[threadIdx.x] = 0u;
+    if (threadIdx.x == 8) sw_ticket[8] += 1u;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u32 j = perm[i];
@@ -250,20 +257,18 @@ hipError_t bhk_sort_onesweep(bh_ctx* c) {
   const int passes = (c->p.key_bits + 7) / 8;
   // sw_hist is zero here: cleared at creation and by the gather kernel of the previous call
   onesweep_hist_kernel<<<ntiles, kThreads, 0, c->stream>>>(c->keys[0], n, passes, c->sw_hist);
-  const u32 call = c->sort_calls++;
-  const u32 tag = (call + 1u) & 0x3fffffffu;
+  c->sort_calls++;
   int src = 0;
   for (int p = 0; p < passes; p++) {
     onesweep_pass_kernel<<<ntiles, kThreads, 0, c->stream>>>(
         c->keys[src], c->vals[src], c->keys[src ^ 1], c->vals[src ^ 1], n, 8 * p, c->sw_hist + p * 256,
-        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, c->sort_ticket_base, tag, p == 0, c->info);
+        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, c->sw_ticket + 8, p == 0, c->info);
     src ^= 1;
   }
-  c->sort_ticket_base += (u32)ntiles;
   c->key_buf = src;
   const int blocks = (n + 255) / 256;
   gather2_kernel<<<blocks, 256, 0, c->stream>>>(c->vals[src], c->posm[c->cur], c->velid[c->cur],
-                                                 c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], n, c->sw_hist);
+                                                 c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], n, c->sw_hist, c->sw_ticket);
   c->cur ^= 1;
   return hipGetLastError();
 }

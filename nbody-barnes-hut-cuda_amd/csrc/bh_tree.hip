@@ -639,69 +639,81 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
                                                   const float4* __restrict__ posm,
                                                   const bh_d4* __restrict__ P) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int E = min(info->n_entries, rec_cap);
+  const int E = min(info->n_entries, rec_cap);  // even: root + padding + blocks of even length
+  if ((e & ~63) >= E) return;                   // whole wave beyond the tree
+  // every lane builds the digest of its entry (a null digest for padding and beyond E); lanes 2p and 2p+1
+  // then write the 64-byte pair of records 2p, 2p+1 with four 16-byte stores (pair layout: bh_internal.h)
+  bh_frec fr = frec_null();
+  if (e < E) {
+    const int lo = er_lo[e], hi = er_hi[e];
+    const bh_node r = rec[e];
+    if (r.kind != BH_KIND_PAD) {
+      float4 o;
+      if (r.kind == BH_KIND_BODY) {
+        o = posm[lo];
+      } else {
+        const bh_d4 p1 = P[hi], p0 = P[lo];
+        const double M = p1.m - p0.m;
+        const double sx = p1.x - p0.x, sy = p1.y - p0.y, sz = p1.z - p0.z;
+        const float mass = (float)M;
+        o.w = mass;
+        if (mass > 1e-6f) {  // ref:180
+          o.x = (float)(sx / M);
+          o.y = (float)(sy / M);
+          o.z = (float)(sz / M);
+        } else {
+          o.x = (float)sx;
+          o.y = (float)sy;
+          o.z = (float)sz;
+        }
+      }
+      // x,y,z,m are the first 16 bytes of the record
+      *reinterpret_cast<float4*>(&rec[e]) = o;
+      fr.x = o.x; fr.y = o.y; fr.z = o.z;
+      const bool massive = o.w > 0.0f;  // ref:203: records with mass <= 0 are skipped
+      fr.gm = massive ? G * o.w : 0.0f;
+      if (!massive || r.kind == BH_KIND_BODY) {
+        fr.thr2 = -1.0f;
+      } else {
+        const float t = r.s / theta;  // theta = 0 -> +inf: never accepted
+        fr.thr2 = t * t;
+      }
+      fr.first = r.first;
+      fr.meta = r.count;
+      if (r.kind == BH_KIND_MULTI) {
+        // an unsplit multi-body cell is, for the fast kernel, a cell whose children are its bodies: their
+        // digests form a child block at BH_BODY_DIGEST (even start; a null digest follows an odd count);
+        // only the slots of such bodies are ever written or read
+        fr.first = BH_BODY_DIGEST(rec_cap, lo, lo);
+        for (int b = lo; b < hi; b++) {
+          const float4 q = posm[b];
+          bh_frec br;
+          br.x = q.x; br.y = q.y; br.z = q.z;
+          br.gm = q.w > 0.0f ? G * q.w : 0.0f;
+          br.thr2 = -1.0f;
+          br.first = b;
+          br.meta = 1;
+          br.pad = 0;
+          frec_put(frec, BH_BODY_DIGEST(rec_cap, lo, b), br);
+        }
+        if ((hi - lo) & 1) frec_put(frec, BH_BODY_DIGEST(rec_cap, lo, hi), frec_null());
+      }
+    }
+  }
+  // partner's digest (the other record of the pair)
+  bh_frec q;
+  q.x = __shfl_xor(fr.x, 1, 64); q.y = __shfl_xor(fr.y, 1, 64); q.z = __shfl_xor(fr.z, 1, 64);
+  q.gm = __shfl_xor(fr.gm, 1, 64); q.thr2 = __shfl_xor(fr.thr2, 1, 64);
+  q.first = __shfl_xor(fr.first, 1, 64); q.meta = __shfl_xor(fr.meta, 1, 64);
   if (e >= E) return;
-  const int lo = er_lo[e], hi = er_hi[e];
-  const int kind = rec[e].kind;
-  if (kind == BH_KIND_PAD) {  // padding entry: a null digest (accepted by every body, zero force)
-    frec_put(frec, e, frec_null());
-    return;
+  float4* pair = reinterpret_cast<float4*>(frec) + (size_t)(e >> 1) * 4;
+  if ((e & 1) == 0) {  // slot 0 writes x0 x1 y0 y1 | z0 z1 gm0 gm1
+    pair[0] = make_float4(fr.x, q.x, fr.y, q.y);
+    pair[1] = make_float4(fr.z, q.z, fr.gm, q.gm);
+  } else {             // slot 1 writes thr0 thr1 first0 first1 | meta0 meta1 pad pad
+    pair[2] = make_float4(q.thr2, fr.thr2, __int_as_float(q.first), __int_as_float(fr.first));
+    pair[3] = make_float4(__int_as_float(q.meta), __int_as_float(fr.meta), 0.0f, 0.0f);
   }
-  float4 o;
-  if (kind == BH_KIND_BODY) {
-    o = posm[lo];
-  } else {
-    const bh_d4 p1 = P[hi], p0 = P[lo];
-    const double M = p1.m - p0.m;
-    const double sx = p1.x - p0.x, sy = p1.y - p0.y, sz = p1.z - p0.z;
-    const float mass = (float)M;
-    o.w = mass;
-    if (mass > 1e-6f) {  // ref:180
-      o.x = (float)(sx / M);
-      o.y = (float)(sy / M);
-      o.z = (float)(sz / M);
-    } else {
-      o.x = (float)sx;
-      o.y = (float)sy;
-      o.z = (float)sz;
-    }
-  }
-  // x,y,z,m are the first 16 bytes of the record
-  *reinterpret_cast<float4*>(&rec[e]) = o;
-  // digest for the fast force kernel (see bh_force.hip; pair layout: bh_internal.h)
-  const bh_node r = rec[e];
-  bh_frec fr;
-  fr.x = o.x; fr.y = o.y; fr.z = o.z;
-  const bool massive = o.w > 0.0f;  // ref:203: records with mass <= 0 are skipped
-  fr.gm = massive ? G * o.w : 0.0f;
-  if (!massive || r.kind == BH_KIND_BODY) {
-    fr.thr2 = -1.0f;
-  } else {
-    const float t = r.s / theta;  // theta = 0 -> +inf: never accepted
-    fr.thr2 = t * t;
-  }
-  fr.first = r.first;
-  fr.meta = r.count;
-  fr.pad = 0;
-  if (r.kind == BH_KIND_MULTI) {
-    // an unsplit multi-body cell is, for the fast kernel, a cell whose children are its bodies: their
-    // digests form a child block at BH_BODY_DIGEST (even start; a null digest follows an odd count);
-    // only the slots of such bodies are ever written or read
-    fr.first = BH_BODY_DIGEST(rec_cap, lo, lo);
-    for (int b = lo; b < hi; b++) {
-      const float4 q = posm[b];
-      bh_frec br;
-      br.x = q.x; br.y = q.y; br.z = q.z;
-      br.gm = q.w > 0.0f ? G * q.w : 0.0f;
-      br.thr2 = -1.0f;
-      br.first = b;
-      br.meta = 1;
-      br.pad = 0;
-      frec_put(frec, BH_BODY_DIGEST(rec_cap, lo, b), br);
-    }
-    if ((hi - lo) & 1) frec_put(frec, BH_BODY_DIGEST(rec_cap, lo, hi), frec_null());
-  }
-  frec_put(frec, e, fr);
 }
 
 }  // namespace

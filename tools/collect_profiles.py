@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 outputs that tools_profile.sh / tools_sq.sh left under gpurun_out/ into the
+"""Turn the rocprofv3 outputs that tools/profile.sh (and tools/sq_force.sh) left under gpurun_out/ into the
 committed summaries of profiles/<tag>/ (newest run of each directory):
 python tools/collect_profiles.py r01_v4"""
 import collections, csv, glob, json, os, shutil, sys
@@ -51,12 +51,18 @@ if fk:
     fetch, write = pmc[k]["FETCH_SIZE"]["mean_KiB"], pmc[k]["WRITE_SIZE"]["mean_KiB"]
     rec = {"n": 1000000, "theta": 0.5, "kernel": "force_fast_kernel", "FETCH_SIZE_KiB": fetch,
            "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "calibration_KiB": cal,
-           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools_profile.sh), mean over the "
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile.sh), mean over the "
                   "force launches of `bench.py --steps 5`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE "
                   "counts 64 B per 128-B request (MI355X_MICROARCH.md HBM section). Calibrated in the same run: keys_kernel "
                   "reads 16 MB and integrate_kernel reads 48 MB (FETCH_SIZE reports half of each); WRITE_SIZE is exact.",
            "profile": tag}
-    json.dump({"round": 1, "records": [rec]}, open(os.path.join(ROOT, "profiles", "force_traffic.json"), "w"), indent=1)
+    path = os.path.join(ROOT, "profiles", "force_traffic.json")
+    try:
+        old = json.load(open(path)).get("records", [])
+    except Exception:
+        old = []
+    old = [r for r in old if r.get("profile") != tag]
+    json.dump({"records": old + [rec]}, open(path, "w"), indent=1)
     print("force HBM bytes/launch", rec["hbm_bytes_per_launch"])
 
 sq = {}
