@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbh.so")
+# BH_LIB_PATH: A/B measurement of an alternative build (tools/) without overwriting the product library
+LIB_PATH = os.environ.get("BH_LIB_PATH") or os.path.join(_HERE, "libbh.so")
 
 
 class BhParams(C.Structure):
