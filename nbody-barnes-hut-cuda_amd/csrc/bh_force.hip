@@ -478,10 +478,14 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_SEGM_ALL                                                                                      \
   BH_SEGM(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEGM(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)           \
   BH_SEGM(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0)                                                          \
-  "L_segm0_%=:\n" BH_STAT_MASKED BH_LAST("L_segmx0_%=", BH_FM, BH_S0, "s[42:43]") "s_branch L_pop_%=\n"
+  "L_segm0_%=:\n" BH_STAT_MASKED BH_LAST("L_segmx0_%=", BH_FM, BH_S0, "s[42:43]") BH_POP_TAIL
 #define BH_ARMS_ALL                                                                                      \
   BH_ARMS_(3, "s[10:11]", "s94", "s96", "s95", "s97") BH_ARMS_(2, "s[14:15]", "s78", "s80", "s79", "s81") \
   BH_ARMS_(1, "s[10:11]", "s62", "s64", "s63", "s65") BH_ARMS_(0, "s[14:15]", "s46", "s48", "s47", "s49")
+// end of a block: pop the next one (the test of L_pop folded into the loop-back branch)
+#define BH_POP_TAIL "s_sub_u32 s30, s30, 1\n s_cbranch_scc0 L_popb_%=\n s_branch L_done_%=\n"
+// a block of <= 4 children is two cache lines (always fetching four measured +1 %)
+#define BH_SMALL_TEST "s_cmp_gt_u32 s33, 4\n s_cbranch_scc0 L_small_%=\n"
 // jump table in the lanes of v52: lane c = entry offset (from L_pro0) of a block of c children; lanes >= 8
 // keep the 4-pair entry (such a block also trips the "> 8 children" redo); read with one v_readlane
 #define BH_TBL(c, L) "s_mov_b32 s33, " L "-L_pro0_%=\n v_writelane_b32 v52, s33, " #c "\n"
@@ -534,6 +538,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "L_pop_%=:\n"
       "s_sub_u32 s30, s30, 1\n"
       "s_cbranch_scc1 L_done_%=\n"
+      "L_popb_%=:\n"
       "v_readlane_b32 s33, v49, s30\n"  // the count first: it is the lane select of the table read below,
       "v_readlane_b32 s32, v48, s30\n"  // which must come >= 4 instructions after the VALU write of it
       "v_readlane_b32 s34, v50, s30\n"
@@ -546,8 +551,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       ".endif\n"
       "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"
       "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"
-      "s_cmp_gt_u32 s33, 4\n"
-      "s_cbranch_scc0 L_small_%=\n"
+      BH_SMALL_TEST
       "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
       "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
       "L_small_%=:\n"
@@ -567,7 +571,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       BH_PRO_ALL
       BH_SEG_ALL
       "L_end_%=:\n"  // also the entry of a block of 0 children (never built; every table offset is >= 0)
-      "s_branch L_pop_%=\n"
+      BH_POP_TAIL
       BH_SEGM_ALL
       BH_ARMS_ALL
       "L_done_%=:\n"
