@@ -240,7 +240,8 @@ typedef struct bh_dd_sizes {
   int64_t top_base;     /* pool index of the top-tree root                                       */
 } bh_dd_sizes;
 
-/* sizes for a context created with capacity n_cap bodies */
+/* sizes for a context created with capacity n_cap bodies; world <= 13 (the top tree holds 4096 pieces and a rank
+   contributes at most 294, so it cannot overflow) */
 int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* out);
 /* switch a context (created with n = body capacity) to domain-decomposed stepping; `pool` is a
    caller-owned device buffer of pool_records x 32 B that becomes the context's record pool */

@@ -980,7 +980,10 @@ void bh_dd_free(bh_ctx* c) {
 extern "C" {
 
 int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) {
-  if (!o || n_cap < 1 || world < 1 || world > 64 || mig_cap < 1) return BH_ERR_BAD_ARG;
+  // a rank contributes at most 2 spines x 21 levels x 7 = 294 pieces, the top tree holds kTopMax = 4096 of them:
+  // up to 13 ranks can never overflow it (one node has 8 GPUs); more are refused here rather than risking the
+  // BH_FLAG_DD_PIECES error in the middle of a run
+  if (!o || n_cap < 1 || world < 1 || world > kTopMax / 294 || mig_cap < 1) return BH_ERR_BAD_ARG;
   const long long let_min = kSegBlocks0;
   if (let_cap < let_min || (let_cap & 1)) return BH_ERR_BAD_ARG;  // segments hold whole digest pairs
   long long rec_cap = (long long)BH_FREC_POOL(BH_REC_CAP((long long)n_cap), n_cap);  // tree + body digests

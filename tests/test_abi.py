@@ -152,3 +152,5 @@ def test_dd_query_sizes_are_host_side_and_consistent():
     assert lib.bh_dd_query(n_cap, world, mig_cap, BH_DD_PIECE_CAP, C.byref(sz)) == -1      # stride below the minimum
     assert lib.bh_dd_query(20_000_000, 8, 1 << 20, 30_000_000, C.byref(sz)) == -1          # pool beyond 4 GiB
     assert lib.bh_dd_query(0, 8, 1024, 4096, C.byref(sz)) == -1
+    assert lib.bh_dd_query(100_000, 14, 1024, 200_000, C.byref(sz)) == -1   # > 13 ranks could overflow the 4096-piece top tree
+    assert lib.bh_dd_query(100_000, 13, 1024, 200_000, C.byref(sz)) == 0
