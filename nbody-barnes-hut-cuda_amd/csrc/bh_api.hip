@@ -84,7 +84,7 @@ static void free_all(bh_ctx* c) {
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sw_hist, c->sw_status,
                   c->sw_ticket, c->bbox_partial,
                   c->bounds, c->d8, c->ksamp, c->pa, c->pb, c->pn,
-                  c->cb, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
+                  c->cb, c->ttot, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -173,7 +173,8 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->ksamp, (size_t)2048 + 8) == hipSuccess;
   ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
-  ok = ok && dalloc(&c->cb, N + 1) == hipSuccess;
+  ok = ok && dalloc(&c->cb, N + 4) == hipSuccess;
+  ok = ok && dalloc(&c->ttot, 2 * (N / 1024 + 2)) == hipSuccess;
   ok = ok && dalloc(&c->rec, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->frec, BH_FREC_POOL(c->rec_cap, N)) == hipSuccess;  // tree digests + body digests
   ok = ok && dalloc(&c->er_lo, (size_t)c->rec_cap) == hipSuccess;

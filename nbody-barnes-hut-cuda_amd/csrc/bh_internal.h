@@ -123,7 +123,9 @@ struct bh_ctx {
   int* pa;        // [n] first body of the cell whose first child boundary is j
   int* pb;        // [n] end body of that cell
   int* pn;        // [n] its child count (0: j represents no emitted cell)
-  int* cb;        // [n+1] exclusive scan of pn; cb[n] = records - 1
+  int* cb;        // [n] offset of the cell's child block inside its 1024-pair tile (exclusive scan of the
+                  // even-rounded pn within the tile)
+  int* ttot;      // [2 * (n / 1024 + 2)] child entries per pair tile, then (large n only) their exclusive prefix
   bh_node* rec;   // [rec_cap] tree records (canonical: ABI download, strict/counting kernels)
   bh_frec* frec;  // [BH_FREC_POOL] digests for the fast force kernel (written by COM, pair layout): tree records,
                   // then BH_BODY_DIGEST slots (used only for the bodies of unsplit multi-body cells)
@@ -170,8 +172,10 @@ struct bh_ctx {
 #define BH_FORCE_BLOCK_DEFAULT 64  // one wave per workgroup: a CU slot frees as soon as its wave retires (-2 % at 1M)
 #define BH_BBOX_BLOCKS 1024
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
-#define BH_SORT_ITEMS 16
-#define BH_SORT_TILE (256 * BH_SORT_ITEMS)
+#ifndef BH_SORT_TILE
+#define BH_SORT_TILE 4096  // keys per sort tile
+#endif
+#define BH_SORT_ITEMS (BH_SORT_TILE / 256)  // per thread in the 256-thread kernels
 
 // ---- launchers (each enqueues on c->stream and returns hipGetLastError()) ----
 hipError_t bhk_pack(bh_ctx* c);                       // stage_buf SoA -> posm/velid

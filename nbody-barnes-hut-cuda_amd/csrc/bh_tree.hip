@@ -192,12 +192,6 @@ __device__ __forceinline__ int key_lower_bound(const u64* __restrict__ k, int n,
   return lo;
 }
 
-__global__ __launch_bounds__(256) void ksample_kernel(const u64* __restrict__ k, int n, int ss,
-                                                      u64* __restrict__ samp, int ns) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < ns) samp[i] = k[(size_t)i << ss];
-}
-
 // child boundaries of cell [a,b) at the level whose digit shift is dsh:
 // pos[v] = first j in [a,b) with digit(k[j]) >= v
 __device__ __forceinline__ void child_bounds(const u64* __restrict__ k, int a, int b, int dsh,
@@ -225,9 +219,11 @@ __device__ __forceinline__ void child_bounds(const u64* __restrict__ k, int a, i
   }
 }
 
-// d[j] = leading octal digits shared by keys j-1 and j (0..B); d[0] = d[n] = -1 (sentinels)
+// d[j] = leading octal digits shared by keys j-1 and j (0..B); d[0] = d[n] = -1 (sentinels);
+// samp[] = every 2^ss-th key (bisection seeds of the wide-cell searches)
 __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int n, int B,
-                                                  signed char* __restrict__ d, bh_devinfo* __restrict__ info) {
+                                                  signed char* __restrict__ d, int ss, u64* __restrict__ samp,
+                                                  bh_devinfo* __restrict__ info) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0) {  // first kernel of the build: tree statistics restart; the sticky flags (4th word) survive
     info->n_internal = 0;
@@ -235,7 +231,9 @@ __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int
     info->max_level = 0;
   }
   if (j > n) return;
-  d[j] = (j == 0 || j == n) ? (signed char)-1 : (signed char)common_digits(k[j - 1], k[j], B);
+  const u64 kj = (j < n) ? k[j] : 0ull;
+  if (j < n && (j & ((1 << ss) - 1)) == 0) samp[j >> ss] = kj;
+  d[j] = (j == 0 || j == n) ? (signed char)-1 : (signed char)common_digits(k[j - 1], kj, B);
 }
 
 // Cell of pair j at level L = d[j]:   start a = nearest i < j with d[i] < L,
@@ -309,8 +307,10 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
                                                     const signed char* __restrict__ d, int n, int B, int D,
                                                     int cap, const u64* __restrict__ ksamp, int ns, int ss,
                                                     int* __restrict__ pa, int* __restrict__ pb,
-                                                    int* __restrict__ pn, bh_devinfo* __restrict__ info) {
+                                                    int* __restrict__ pn, int* __restrict__ cb,
+                                                    int* __restrict__ ttot, bh_devinfo* __restrict__ info) {
   __shared__ u64 s_samp[kSampMax];
+  __shared__ __attribute__((aligned(16))) int pnl[kPairTile];  // child counts of the tile's pairs
   __shared__ u64 m[kPairLevels][kPairWords];
   __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
   const int t0 = blockIdx.x * kPairTile;
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   __shared__ int wide[kPairTile];  // window slots of the pairs whose cell leaves the window
   __shared__ int nwide;
   if (threadIdx.x == 0) nwide = 0;
+  for (int q = threadIdx.x; q < kPairTile; q += 256) pnl[q] = 0;
   __syncthreads();
 
   int cells = 0, maxl = 0;
@@ -356,10 +357,12 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
         maxl = max(maxl, L + 1);
       }
     }
-    if (deferred)
+    if (deferred) {
       wide[atomicAdd(&nwide, 1)] = p;  // list order is irrelevant: results are keyed by j
-    else
+    } else {
       pn[j] = nc;
+      pnl[p - kPairTile] = nc;
+    }
   }
   __syncthreads();
   // phase 2: wide cells by key search, 8 lanes per pair (lane v = octant v), all pairs of the
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       }
       if (sub == 0) {
         pn[j] = nc;
+        pnl[p - kPairTile] = nc;
         if (nc) {
           pa[j] = a;
           pb[j] = b;
@@ -400,6 +404,37 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
         }
       }
     }
+  }
+  // Child-block offsets: one contiguous block per cell, in pair order, every block starting at an even entry
+  // (an odd block is followed by a padding entry).  The tile scans its own counts here and publishes its total;
+  // emit_kernel turns the <= n/1024 totals into tile bases itself (no separate scan pass over n values).
+  __shared__ int s_ws[4];
+  __syncthreads();
+  {
+    const int q0 = threadIdx.x * 4;
+    const int4 c4 = *reinterpret_cast<const int4*>(pnl + q0);
+    const int v0 = (c4.x + 1) & ~1, v1 = (c4.y + 1) & ~1, v2 = (c4.z + 1) & ~1, v3 = (c4.w + 1) & ~1;
+    const int sum = v0 + v1 + v2 + v3;
+    int incl = sum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int u = __shfl_up(incl, dd, 64);
+      if (lane >= dd) incl += u;
+    }
+    const int wv = threadIdx.x >> 6;
+    if (lane == 63) s_ws[wv] = incl;
+    __syncthreads();
+    int ex = incl - sum;
+    for (int q = 0; q < wv; q++) ex += s_ws[q];
+    const int j0 = t0 + q0;
+    if (j0 + 3 < n) {
+      *reinterpret_cast<int4*>(cb + j0) = make_int4(ex, ex + v0, ex + v0 + v1, ex + v0 + v1 + v2);
+    } else {
+      if (j0 < n) cb[j0] = ex;
+      if (j0 + 1 < n) cb[j0 + 1] = ex + v0;
+      if (j0 + 2 < n) cb[j0 + 2] = ex + v0 + v1;
+    }
+    if (threadIdx.x == 255) ttot[blockIdx.x] = ex + sum;
   }
   // tree statistics: reduce in LDS, then ONE pair of global atomics per block (a global atomic per
   // thread put ~31K same-address atomics in a row: 90 of this kernel's 116 us at 1M bodies).
@@ -422,8 +457,13 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
 }
 
 // classify the child cell [c0,c1) of a cell at level L and fill the topology fields of its record
+// entry offset of the child block of the cell whose representative pair is j
+#define BH_CB(j) (tpre[(j) >> 10] + cb[j])
+static_assert(kPairTile == 1024, "BH_CB shifts by 10");
+
 __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, int D, int cap, float s0,
                                               const int* __restrict__ pn, const int* __restrict__ cb,
+                                              const int* tpre,
                                               int c0, int c1, int child_level, int n = 0,
                                               const u64* samp = nullptr, int ns = 0, int ss = 0) {
   bh_node r;
@@ -467,7 +507,7 @@ __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, 
     }
   }
   r.kind = BH_KIND_INTERNAL;
-  r.first = BH_BLOCK0 + cb[l];
+  r.first = BH_BLOCK0 + BH_CB(l);
   r.count = pn[l];
   r.s = ldexpf(s0, -Lb);
   return r;
@@ -478,7 +518,8 @@ __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, 
 // strictly inside the child, and that first bit is the child's representative pair
 __device__ __forceinline__ bh_node make_child_win(u64 (*m)[kPairWords], int base, int B, int D, int cap,
                                                   float s0, const int* __restrict__ pn,
-                                                  const int* __restrict__ cb, int c0, int c1, int L) {
+                                                  const int* __restrict__ cb, const int* tpre, int c0, int c1,
+                                                  int L) {
   bh_node r;
   r.x = r.y = r.z = r.m = 0.0f;
   const int cnt = c1 - c0;
@@ -508,7 +549,7 @@ __device__ __forceinline__ bh_node make_child_win(u64 (*m)[kPairWords], int base
     return r;
   }
   r.kind = BH_KIND_INTERNAL;
-  r.first = BH_BLOCK0 + cb[base + jr];
+  r.first = BH_BLOCK0 + BH_CB(base + jr);
   r.count = pn[base + jr];
   r.s = ldexpf(s0, -Lb);
   return r;
@@ -522,12 +563,17 @@ __device__ __forceinline__ bh_node pad_entry() {
   return r;
 }
 
+// LDS_SCAN: the block turns the per-tile totals of pairs_kernel into tile bases itself (exclusive scan of
+// ntiles <= kEmitScanMax values in LDS); otherwise ttot[tp_off ..] holds the bases already (large n).
+constexpr int kEmitScanMax = 4096;
+template <bool LDS_SCAN>
 __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
                                                    const signed char* __restrict__ d, int n, int B, int D,
                                                    int cap, const u64* __restrict__ ksamp, int ns, int ss,
                                                    const int* __restrict__ pa,
                                                    const int* __restrict__ pb, const int* __restrict__ pn,
                                                    const int* __restrict__ cb,
+                                                   const int* __restrict__ ttot, int ntiles, int tp_off,
                                                    const float* __restrict__ bounds,
                                                    bh_node* __restrict__ rec, int* __restrict__ er_lo,
                                                    int* __restrict__ er_hi, int rec_cap,
@@ -535,6 +581,36 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   __shared__ u64 s_samp[kSampMax];
   __shared__ u64 m[kPairLevels][kPairWords];
   __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
+  extern __shared__ int s_tpre[];  // LDS_SCAN: [ntiles + 1] tile bases
+  const int* tpre = ttot + tp_off;
+  if (LDS_SCAN) {
+    __shared__ int s_ws[4];
+    for (int q = threadIdx.x; q < ntiles; q += 256) s_tpre[q] = ttot[q];
+    __syncthreads();
+    const int per = (ntiles + 255) >> 8;
+    const int q0 = threadIdx.x * per, q1 = min(q0 + per, ntiles);
+    int sum = 0;
+    for (int q = q0; q < q1; q++) sum += s_tpre[q];
+    int incl = sum;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int u = __shfl_up(incl, dd, 64);
+      if (lane >= dd) incl += u;
+    }
+    if (lane == 63) s_ws[wv] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int q = 0; q < wv; q++) run += s_ws[q];
+    for (int q = q0; q < q1; q++) {
+      const int v = s_tpre[q];
+      s_tpre[q] = run;
+      run += v;
+    }
+    if (threadIdx.x == 255) s_tpre[ntiles] = run;
+    tpre = s_tpre;
+    // (the barrier inside build_window orders these writes before the first use)
+  }
   const int t0 = blockIdx.x * kPairTile;
   const int base = t0 - kPairTile;
   build_window(d, n, base, m, dl);
@@ -549,10 +625,10 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     const int j = base + p;
     if (j >= n) break;
     if (j == 0) {  // root record (ref:65-81 initRootKernel)
-      const int E = BH_BLOCK0 + cb[n];
+      const int E = BH_BLOCK0 + tpre[ntiles];
       info->n_entries = E;
       if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
-      rec[0] = make_child(k, B, D, cap, s0, pn, cb, 0, n, 0);
+      rec[0] = make_child(k, B, D, cap, s0, pn, cb, tpre, 0, n, 0);
       er_lo[0] = 0;
       er_hi[0] = n;
       rec[1] = pad_entry();  // child blocks start at even entries (BH_BLOCK0)
@@ -561,7 +637,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     }
     const int nc = pn[j];
     if (nc == 0) continue;
-    int e = BH_BLOCK0 + cb[j];
+    int e = BH_BLOCK0 + BH_CB(j);
     if (e + nc > rec_cap) continue;  // cannot happen (records <= 2n); flagged by thread 0 if it did
     const int a = pa[j], b = pb[j];
     const int L = dl[p];
@@ -574,7 +650,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     const u64* mle = m[L + 1];
     int c0 = qa, c1 = p;
     for (;;) {
-      rec[e] = make_child_win(m, base, B, D, cap, s0, pn, cb, c0, c1, L);
+      rec[e] = make_child_win(m, base, B, D, cap, s0, pn, cb, tpre, c0, c1, L);
       er_lo[e] = base + c0;
       er_hi[e] = base + c1;
       e++;
@@ -611,16 +687,16 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       const bool nonempty = nxt > l;
       const u64 grp = (__ballot(nonempty) >> (lane & ~7)) & 0xffull;
       if (nonempty) {
-        const int e = BH_BLOCK0 + cb[j] + __popcll(grp & ((1ull << sub) - 1ull));
+        const int e = BH_BLOCK0 + BH_CB(j) + __popcll(grp & ((1ull << sub) - 1ull));
         if (e < rec_cap) {
-          rec[e] = make_child(k, B, D, cap, s0, pn, cb, l, nxt, L + 1, n, s_samp, ns, ss);
+          rec[e] = make_child(k, B, D, cap, s0, pn, cb, tpre, l, nxt, L + 1, n, s_samp, ns, ss);
           er_lo[e] = l;
           er_hi[e] = nxt;
         }
       }
       if (sub == 0) {
         const int nc = __popcll(grp);
-        const int e = BH_BLOCK0 + cb[j] + nc;
+        const int e = BH_BLOCK0 + BH_CB(j) + nc;
         if ((nc & 1) && e < rec_cap) {
           rec[e] = pad_entry();
           er_lo[e] = er_hi[e] = 0;
@@ -758,21 +834,27 @@ hipError_t bhk_keys(bh_ctx* c) {
 hipError_t bhk_build(bh_ctx* c) {
   const int n = c->n;
   const u64* k = c->keys[c->key_buf];
-  lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8, c->info);
   // every 2^ss-th key, at most kSampMax of them: bisection seeds of the wide-cell searches
   int ss = 12;
   while (((n + (1 << ss) - 1) >> ss) > kSampMax) ss++;
   const int ns = (n + (1 << ss) - 1) >> ss;
-  ksample_kernel<<<(ns + 255) / 256, 256, 0, c->stream>>>(k, n, ss, c->ksamp, ns);
-  pairs_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
-                                                                        c->ksamp, ns, ss, c->pa, c->pb, c->pn,
-                                                                        c->info);
-  const hipError_t e = bhk_scan_i32_even(c, c->pn, c->cb, n);  // child-block offsets (even: 64-byte aligned); cb[n] = entries - 2
-  if (e != hipSuccess) return e;
-  emit_kernel<<<(n + kPairTile - 1) / kPairTile, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap,
-                                                                       c->ksamp, ns, ss, c->pa,
-                                                                       c->pb, c->pn, c->cb, c->bounds, c->rec,
-                                                                       c->er_lo, c->er_hi, c->rec_cap, c->info);
+  lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info);
+  const int ntiles = (n + kPairTile - 1) / kPairTile;
+  pairs_kernel<<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
+                                              c->pn, c->cb, c->ttot, c->info);
+  // child-block offsets = tile base + offset in the tile (cb[], written by pairs_kernel)
+  if (ntiles <= kEmitScanMax) {
+    emit_kernel<true><<<ntiles, 256, (size_t)(ntiles + 1) * sizeof(int), c->stream>>>(
+        k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, ntiles, 0,
+        c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
+  } else {
+    const int tp_off = n / 1024 + 2;
+    const hipError_t e = bhk_scan_i32(c, c->ttot, c->ttot + tp_off, ntiles, nullptr);
+    if (e != hipSuccess) return e;
+    emit_kernel<false><<<ntiles, 256, 0, c->stream>>>(
+        k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off,
+        c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
+  }
   return hipGetLastError();
 }
 

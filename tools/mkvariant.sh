@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build an alternative libbh.so with extra compiler flags into tools/bin/libs/<name>.so (never the product
+# library); select it at run time with BH_LIB_PATH.   tools/mkvariant.sh look32 -DBH_OS_LOOK=32
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+pkg=$root/nbody-barnes-hut-cuda_amd
+out=$root/tools/bin/libs; bld=$root/tools/bin/build_$name
+mkdir -p $out $bld
+flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -fno-slp-vectorize -I$root/include -I$pkg/csrc"
+pids=()
+for f in bh_api bh_scan bh_sort bh_sort_onesweep bh_tree bh_force bh_dd; do
+  /opt/rocm/bin/hipcc $flags "$@" -c $pkg/csrc/$f.hip -o $bld/$f.o 2> $bld/$f.log & pids+=($!)
+done
+for f in bh_ic bh_io; do
+  /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -I$root/include -I$pkg/csrc -c $pkg/csrc/$f.cpp -o $bld/$f.o 2> $bld/$f.log & pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $bld/*.o
+echo built $out/$name.so
