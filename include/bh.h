@@ -64,9 +64,12 @@ typedef struct bh_params {
   int32_t xcd_mode;      /* fast force kernels, block -> body-chunk placement (speed only):
                             0 = one contiguous eighth of the Morton order per XCD, 1 = identity,
                             2 = runs of 16 chunks per XCD dealt round-robin                       */
-  int32_t sort_variant;  /* 0 = one kernel per radix pass with decoupled look-back (default),
-                            1 = histogram + scan + scatter kernels per pass (no inter-workgroup
-                            hand-off at all; A/B and fallback)                                     */
+  int32_t sort_variant;  /* 0 = automatic (default): splitter sort (one partition pass + per-bucket LDS
+                            sort) when the bodies are still in an earlier step's key order and fit,
+                            else 2;  1 = histogram + scan + scatter kernels per radix pass (no
+                            inter-workgroup hand-off at all; A/B and fallback);  2 = one kernel per
+                            radix pass with decoupled look-back;  3 = splitter sort on any input (tests).
+                            All are stable sorts: identical results                                 */
   int32_t literal_force; /* 1 = reproduce the reference BINARY instead of its intent: the force on
                             every body is the root monopole G*M*(COM-p)/(|COM-p|^2+eps2)^(3/2),
                             which is what computeForceKernel literally evaluates (`idx < n`

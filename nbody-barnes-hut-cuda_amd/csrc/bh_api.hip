@@ -82,7 +82,7 @@ static void free_all(bh_ctx* c) {
   }
   void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sw_hist, c->sw_status,
-                  c->sw_ticket, c->bbox_partial,
+                  c->sw_ticket, c->sp_keys, c->sp_count, c->bbox_partial,
                   c->bounds, c->d8, c->ksamp, c->pa, c->pb, c->pn,
                   c->cb, c->ttot, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
@@ -111,7 +111,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   if (n < 1 || n > (1 << 30) / 2) return BH_ERR_BAD_ARG;
   if (p.key_bits != 63 && p.key_bits != 30) return BH_ERR_BAD_ARG;
   if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0 ||
-      p.force_variant < 0 || p.force_variant > 1)
+      p.force_variant < 0 || p.force_variant > 1 || p.sort_variant < 0 || p.sort_variant > 3)
     return BH_ERR_BAD_ARG;
 
   int ndev = 0;
@@ -162,6 +162,9 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->sw_hist, (size_t)8 * 256) == hipSuccess;
   ok = ok && dalloc(&c->sw_status, (size_t)8 * c->sort_tiles * 256) == hipSuccess;
   ok = ok && dalloc(&c->sw_ticket, (size_t)16) == hipSuccess;
+  ok = ok && dalloc(&c->sp_keys, (size_t)256) == hipSuccess;
+  ok = ok && dalloc(&c->sp_count, (size_t)512) == hipSuccess;
+  ok = ok && hipMemset(c->sp_count, 0, 512 * sizeof(u32)) == hipSuccess;
   // look-back granules and tickets start at zero once; they are never cleared afterwards
   // (granules carry the sort-call tag, tickets are monotonic)
   ok = ok && hipMemset(c->sw_status, 0, (size_t)8 * c->sort_tiles * 256 * sizeof(u64)) == hipSuccess;
@@ -258,6 +261,7 @@ int bh_upload(bh_ctx* c, const float* x, const float* y, const float* z, const f
   for (int k = 0; k < 7; k++)
     BH_HIP(c, hipMemcpyAsync(c->stage_buf + k * N, src[k], nb, hipMemcpyHostToDevice, c->stream));
   c->cur = 0;
+  c->order_hint = false;  // caller order: nothing for the splitter sort to exploit
   BH_HIP(c, bhk_pack(c));
   BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));  // clears the sticky flags
   BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));

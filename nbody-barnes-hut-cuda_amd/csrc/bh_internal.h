@@ -112,6 +112,13 @@ struct bh_ctx {
   u32* sw_ticket;  // [0..7] tile tickets of the passes (cleared at the end of every sort), [8] sort calls so far
   u32 sort_calls;
   int sort_tiles;
+  // splitter sort (bh_sort_onesweep.hip, bhk_sort_split)
+  u64* sp_keys;     // [256] sorted splitters, padded with ~0
+  u32* sp_count;    // [2][256] bucket sizes, double-buffered by call parity (the sort clears the other half)
+  int sp_par;
+  bool keys_split;  // keys[0] and sp_count[sp_par] come from keys_split_kernel and no sort has consumed them
+  bool order_hint;  // the bodies are stored in the key order of an earlier sort (set by every sort, cleared by
+                    // uploads): what makes evenly spaced bodies good splitters
 
   // bbox
   float* bbox_partial;  // [BH_BBOX_BLOCKS][6]
@@ -185,7 +192,10 @@ hipError_t bhk_bbox_raw(bh_ctx* c, float* out6);  // local min/max only
 hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int stride_floats);
 hipError_t bhk_keys(bh_ctx* c);
 hipError_t bhk_sort(bh_ctx* c);                       // radix sort + gather
-hipError_t bhk_sort_onesweep(bh_ctx* c);              // default implementation (bh_sort_onesweep.hip)
+hipError_t bhk_sort_onesweep(bh_ctx* c);              // radix implementation (bh_sort_onesweep.hip)
+bool bhk_sort_split_eligible(const bh_ctx* c);        // splitter sort: keys + bucket counts, then partition + local sort
+hipError_t bhk_keys_split(bh_ctx* c);
+hipError_t bhk_sort_split(bh_ctx* c);
 hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);

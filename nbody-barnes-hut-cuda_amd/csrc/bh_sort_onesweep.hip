@@ -20,6 +20,7 @@
 //       - every spin is bounded; on timeout the kernel sets BH_FLAG_SORT_TIMEOUT and goes on
 //         (wrong order, loudly reported) instead of hanging the device.
 #include "bh_internal.h"
+#include "bh_keys.h"
 
 namespace {
 
@@ -87,15 +88,61 @@ __global__ __launch_bounds__(kHistThreads) void onesweep_hist_kernel(const u64* 
   }
 }
 
+// One granule row of look-back: kN independent loads `stride` tiles apart starting at tile tt, consumed in
+// order.  Accepts states >= min_state; returns how many granules were consumed and sets `hit` when one of
+// them closed the walk (state 2 always; state 3 / tile <= floor when `close_on_3`).
+template <int kN>
+__device__ __forceinline__ int lookback_round(const u64* __restrict__ status, int t, int tt, int stride,
+                                              int floor_tile, u32 tag, u32 min_state, bool close_on_3,
+                                              u32& excl, bool& closed, bool& inclusive) {
+  u64 e[kN];
+#pragma unroll
+  for (int q = 0; q < kN; q++)
+    e[q] = (tt - q * stride >= floor_tile)
+               ? __hip_atomic_load(status + (size_t)(tt - q * stride) * 256 + t, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT)
+               : 0ull;
+  int used = 0;
+#pragma unroll
+  for (int q = 0; q < kN; q++) {
+    if (closed || used != q) continue;  // stop at the first granule that is not ready
+    const u32 hi = (u32)(e[q] >> 32);
+    const u32 st = hi & 3u;
+    if (tt - q * stride < floor_tile || (hi >> 2) != tag || st < min_state) continue;
+    excl += (u32)e[q];
+    used = q + 1;
+    if (st == 2u) closed = inclusive = true;
+    if ((st == 3u && close_on_3) || tt - q * stride == floor_tile) closed = true;
+  }
+  return used;
+}
+
+// number of splitters <= key (sp[] ascending, padded with ~0): the bucket of the key, 0..255
+__device__ __forceinline__ u32 splitter_bucket(const u64* sp, u64 key) {
+  u32 lo = 0;
+#pragma unroll
+  for (u32 step = 128; step >= 1; step >>= 1)
+    if (sp[lo + step - 1] <= key) lo += step;
+  return lo;
+}
+
+// SPLIT = false: one LSD radix pass, digit = 8 key bits at `shift`.
+// SPLIT = true : the partition pass of the splitter sort (bhk_sort_split below): "digit" = the key's bucket
+//                among the <= 255 sorted splitters, ghist_pass = the bucket totals counted by keys_split_kernel.
+template <bool SPLIT>
 __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
     const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
     u32* __restrict__ vout, int n, int shift, const u32* __restrict__ ghist_pass,
     u64* __restrict__ status, u32* __restrict__ ticket, const u32* __restrict__ call_ptr, int first_pass,
-    bh_devinfo* __restrict__ info) {
+    bh_devinfo* __restrict__ info, const u64* __restrict__ splitters) {
+  __shared__ u64 s_sp[SPLIT ? 256 : 1];
+  if (SPLIT && threadIdx.x < 256) s_sp[threadIdx.x] = splitters[threadIdx.x];
+#define OS_DIGIT(k) (SPLIT ? splitter_bucket(s_sp, (k)) : ((u32)((k) >> shift) & 255u))
   // tag = number of this sort call, kept on the device (sw_ticket[8], advanced by the gather kernel that ends
   // every sort) so that the kernel arguments of a step never change: bh_step replays as a HIP graph
   const u32 tag = (*call_ptr + 1u) & 0x3fffffffu;
   __shared__ u32 wcnt[kWaves][256];
+  __shared__ u32 th[256];
   __shared__ u32 gbase[256];
   __shared__ u32 toff[256];
   __shared__ u32 dsum[4];
@@ -105,6 +152,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);  // tickets restart at 0: the gather kernel clears them
   for (int q = threadIdx.x; q < kWaves * 256; q += kThreads) (&wcnt[0][0])[q] = 0;
+  if (threadIdx.x < 256) th[threadIdx.x] = 0;
   __syncthreads();
   const int tile = (int)s_tile;
   OS_STAMP(0)
@@ -120,11 +168,51 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
     key[r] = valid ? kin[i] : ~0ull;
     val[r] = valid ? (first_pass ? (u32)i : vin[i]) : 0u;
   }
+  // ---- 1. the tile's digit counts FIRST (one LDS atomic per key, or per wave when its 64 keys share the
+  // digit), published before the ranking: by the time the ranking is done the neighbours' counts have
+  // crossed the fabric (a publication takes ~1 us to become visible to another XCD) and the look-back below
+  // reads them without spinning.
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
     const int i = base + r * 64 + lane;
     const bool valid = i < n;
-    const u32 g = (u32)(key[r] >> shift) & 255u;
+    const u32 g = OS_DIGIT(key[r]);
+    const u64 act = __ballot(valid);
+    if (act == 0ull) continue;
+    const int l0 = __ffsll((long long)act) - 1;
+    const u32 g0 = __shfl(g, l0, 64);
+    if (__ballot(valid && g != g0) == 0ull) {
+      if (lane == l0) atomicAdd(&th[g0], (u32)__popcll(act));
+    } else if (valid) {
+      atomicAdd(&th[g], 1u);
+    }
+  }
+  __syncthreads();
+  // threads 0..255 own one digit each (the first four waves); the other waves only keep the barriers company
+  const bool dig = threadIdx.x < 256;
+  const int t = threadIdx.x & 255;  // digit
+  // Two-level look-back.  When n / tile ~ number of CUs every tile is resident at once and nobody has an
+  // inclusive prefix early: a plain look-back then reads O(tiles) granule rows per tile (61 MB per pass at 1M
+  // keys, more than the keys).  Instead tiles form groups of kGroup; a tile first sums the counts of its own
+  // group's earlier tiles (consecutive rows, ONE round of independent loads) and publishes that as state 3
+  // (group-inclusive), then walks back over the LAST tile of every earlier group only (rows kGroup apart),
+  // which carry state 3 or 2.  States: 1 = count, 3 = group-inclusive, 2 = inclusive.
+  constexpr int kGroup = BH_OS_GROUP, kLook = BH_OS_LOOK;
+  const int gs = tile - tile % kGroup;
+  const u32 h = dig ? th[t] : 0u;
+  u64* mine = status + (size_t)tile * 256 + t;
+  u32 excl = 0, spins = 0;
+  bool done = (tile == 0), fail = false;
+  if (dig)
+    __hip_atomic_store(mine, pack_granule(tag, tile == 0 ? 2u : (tile == gs ? 3u : 1u), h), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- 2. rank the keys: wave64 match-any with 8 ballots, wave-private counters combined in wave order
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int i = base + r * 64 + lane;
+    const bool valid = i < n;
+    const u32 g = OS_DIGIT(key[r]);
     u64 mask = __ballot(valid);
 #pragma unroll
     for (int bit = 0; bit < 8; bit++) {
@@ -140,157 +228,79 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
   }
   __syncthreads();
   OS_STAMP(1)
-  {
-    // threads 0..255 own one digit each (the first four waves); the other waves only keep the barriers company
-    const bool dig = threadIdx.x < 256;
-    const int t = threadIdx.x & 255;  // digit
-    u32 h = 0, excl = 0;
-    if (dig) {
+  if (dig) {
+    u32 run = 0;
 #pragma unroll
-      for (int q = 0; q < kWaves; q++) {
-        const u32 cq = wcnt[q][t];
-        wcnt[q][t] = h;  // keys of digit t in the earlier waves of this tile
-        h += cq;
-      }
-      // Publish this tile's count, then resolve the exclusive prefix over the earlier tiles.  When n / tile ~
-      // number of CUs every tile is resident at once and nobody has an inclusive prefix early: a plain
-      // look-back then reads O(tiles) granule rows per tile (61 MB per pass at 1M keys, more than the keys).
-      // Two levels instead: tiles form groups of kGroup; a tile first sums the counts of its own group's
-      // earlier tiles (consecutive rows) and publishes that as state 3 (group-inclusive), then walks back over
-      // the LAST tile of every earlier group only (rows kGroup apart), which carry state 3 or 2.
-      constexpr int kLook = BH_OS_LOOK, kGroup = BH_OS_GROUP;
-      u64* mine = status + (size_t)tile * 256 + t;
-      const int gs = tile - tile % kGroup;
-      u32 spins = 0;
-      bool done = false, fail = false;
-      if (tile == 0) {
-        done = true;
-      } else if (tile == gs) {
-        __hip_atomic_store(mine, pack_granule(tag, 3u, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __hip_atomic_store(mine, pack_granule(tag, 1u, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int tt = tile - 1;
-        bool grp = false;
-        while (!grp && !fail) {
-          u64 e[kLook];
-#pragma unroll
-          for (int q = 0; q < kLook; q++)
-            e[q] = (tt - q >= gs) ? __hip_atomic_load(status + (size_t)(tt - q) * 256 + t, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT)
-                                  : 0ull;
-          int used = 0;
-#pragma unroll
-          for (int q = 0; q < kLook; q++) {
-            if (grp || used != q) continue;  // stop at the first unpublished granule
-            const u32 hi = (u32)(e[q] >> 32);
-            if (tt - q < gs || (hi >> 2) != tag || (hi & 3u) == 0u) continue;
-            excl += (u32)e[q];
-            used = q + 1;
-            if ((hi & 3u) == 2u) done = true;
-            if ((hi & 3u) >= 2u || tt - q == gs) grp = true;
-          }
-          tt -= used;
-          if (!grp && used == 0) {
-            if (++spins > kSpinLimit) fail = true;
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        if (!done && !fail)
-          __hip_atomic_store(mine, pack_granule(tag, 3u, excl + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (gs == 0) done = true;  // group 0: group-inclusive is inclusive
-      {
-        int tt = gs - 1;  // last tile of the previous group
-        while (!done && !fail) {
-          u64 e[kLook];
-#pragma unroll
-          for (int q = 0; q < kLook; q++)
-            e[q] = (tt - q * kGroup >= 0) ? __hip_atomic_load(status + (size_t)(tt - q * kGroup) * 256 + t,
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                          : 0ull;
-          int used = 0;
-#pragma unroll
-          for (int q = 0; q < kLook; q++) {
-            if (done || used != q) continue;  // stop at the first granule that is not (group-)inclusive yet
-            const u32 hi = (u32)(e[q] >> 32);
-            if (tt - q * kGroup < 0 || (hi >> 2) != tag || (hi & 3u) < 2u) continue;
-            excl += (u32)e[q];
-            used = q + 1;
-            if ((hi & 3u) == 2u || tt - q * kGroup < kGroup) done = true;  // group 0's state 3 is inclusive too
-          }
-          tt -= used * kGroup;
-          if (!done && used == 0) {
-            if (++spins > kSpinLimit) fail = true;
-            __builtin_amdgcn_s_sleep(1);
-          }
+    for (int q = 0; q < kWaves; q++) {
+      const u32 cq = wcnt[q][t];
+      wcnt[q][t] = run;  // keys of digit t in the earlier waves of this tile
+      run += cq;
+    }
+    // ---- 3. own group: rows tile-1 .. gs
+    if (tile != gs) {
+      int tt = tile - 1;
+      bool grp = false, incl = false;
+      while (!grp && !fail) {
+        const int used = lookback_round<kGroup - 1>(status, t, tt, 1, gs, tag, 1u, true, excl, grp, incl);
+        tt -= used;
+        if (!grp && used == 0) {
+          if (++spins > kSpinLimit) fail = true;
+          __builtin_amdgcn_s_sleep(1);
         }
       }
-      OS_STAMP(2)
-      if (fail) atomicOr(&info->flags, BH_FLAG_SORT_TIMEOUT);
-      __hip_atomic_store(mine, pack_granule(tag, 2u, excl + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done = incl;
+      if (!done && !fail)
+        __hip_atomic_store(mine, pack_granule(tag, 3u, excl + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // digit base = exclusive scan of the 256 global digit totals of this pass
-    const u32 dv = dig ? ghist_pass[t] : 0u;
-    u32 incl = dv;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const u32 u = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += u;
-    }
-    if (dig && lane == 63) dsum[w] = incl;
-    __syncthreads();
-    u32 wp = 0;
-    for (int q = 0; q < (w & 3); q++) wp += dsum[q];
-    const u32 gpos = wp + incl - dv + excl;  // global position of this tile's first key of digit t
-    // tile-local digit offsets: exclusive scan of the tile's digit counts
-    u32 inc2 = h;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const u32 u = __shfl_up(inc2, d, 64);
-      if (lane >= d) inc2 += u;
-    }
-    __syncthreads();  // dsum is reused
-    if (dig && lane == 63) dsum[w] = inc2;
-    __syncthreads();
-    u32 wp2 = 0;
-    for (int q = 0; q < (w & 3); q++) wp2 += dsum[q];
-    const u32 lo = wp2 + inc2 - h;
-    if (dig) {
-      toff[t] = lo;
-      gbase[t] = gpos - lo;  // global position = gbase[digit] + index in the tile's digit-sorted order
-    }
+    if (gs == 0) done = true;  // group 0: group-inclusive is inclusive
   }
+  OS_STAMP(2)
+  // ---- 4. everything that does not need the prefix over the earlier groups, while the state-3 granules
+  // travel: digit bases, tile-local offsets, the tile staged through LDS in digit order (so that each digit's
+  // run leaves as one contiguous, coalesced global write instead of scattered 8-byte stores)
+  const u32 dv = dig ? ghist_pass[t] : 0u;
+  u32 incl = dv;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += u;
+  }
+  if (dig && lane == 63) dsum[w] = incl;
   __syncthreads();
-  OS_STAMP(3)
-  // Stage the tile through LDS in digit order so that each digit's run leaves as one contiguous
-  // (coalesced) global write instead of 16 scattered 8-byte stores; keys first, then the values
-  // through the same buffer.
+  u32 wp = 0;
+  for (int q = 0; q < (w & 3); q++) wp += dsum[q];
+  const u32 gpos0 = wp + incl - dv;  // global position of the first key of digit t (all tiles)
+  u32 inc2 = h;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 u = __shfl_up(inc2, d, 64);
+    if (lane >= d) inc2 += u;
+  }
+  __syncthreads();  // dsum is reused
+  if (dig && lane == 63) dsum[w] = inc2;
+  __syncthreads();
+  u32 wp2 = 0;
+  for (int q = 0; q < (w & 3); q++) wp2 += dsum[q];
+  const u32 lo = wp2 + inc2 - h;  // tile-local offset of digit t
+  if (dig) toff[t] = lo;
+  __syncthreads();
   const int nvalid = min(kTile, n - tile * kTile);
   u32 lp[kItems];
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
     const int i = base + r * 64 + lane;
-    const u32 g = (u32)(key[r] >> shift) & 255u;
+    const u32 g = OS_DIGIT(key[r]);
     lp[r] = toff[g] + wcnt[w][g] + rk[r];
     if (i < n) stage[lp[r]] = key[r];
   }
   __syncthreads();
-  u32 gp[kItems];
+  u64 k2[kItems];
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
     const int idx = r * kThreads + (int)threadIdx.x;
-    gp[r] = 0xffffffffu;
-    if (idx < nvalid) {
-      const u64 k = stage[idx];
-      const u32 pos = gbase[(u32)(k >> shift) & 255u] + (u32)idx;
-      if (pos < (u32)n) {  // always true unless a look-back timed out
-        kout[pos] = k;
-        gp[r] = pos;
-      }
-    }
+    k2[r] = (idx < nvalid) ? stage[idx] : ~0ull;
   }
   __syncthreads();
-  OS_STAMP(4)
   u32* stage32 = reinterpret_cast<u32*>(stage);
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
@@ -298,12 +308,47 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
     if (i < n) stage32[lp[r]] = val[r];
   }
   __syncthreads();
+  u32 v2[kItems];
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
     const int idx = r * kThreads + (int)threadIdx.x;
-    if (gp[r] != 0xffffffffu) vout[gp[r]] = stage32[idx];
+    v2[r] = (idx < nvalid) ? stage32[idx] : 0u;
+  }
+  OS_STAMP(3)
+  // ---- 5. earlier groups: their last tiles, kGroup rows apart
+  if (dig) {
+    int tt = gs - 1;
+    while (!done && !fail) {
+      bool closed = false, incl2 = false;
+      const int used = lookback_round<kLook>(status, t, tt, kGroup, kGroup - 1, tag, 2u, false, excl, closed, incl2);
+      tt -= used * kGroup;
+      done = closed;
+      if (!done && used == 0) {
+        if (++spins > kSpinLimit) fail = true;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (fail) atomicOr(&info->flags, BH_FLAG_SORT_TIMEOUT);
+    if (tile != 0)
+      __hip_atomic_store(mine, pack_granule(tag, 2u, excl + h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gbase[t] = gpos0 + excl - lo;  // global position = gbase[digit] + index in the tile's digit-sorted order
+  }
+  __syncthreads();
+  OS_STAMP(4)
+  // ---- 6. the coalesced global writes
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int idx = r * kThreads + (int)threadIdx.x;
+    if (idx < nvalid) {
+      const u32 pos = gbase[OS_DIGIT(k2[r])] + (u32)idx;
+      if (pos < (u32)n) {  // always true unless a look-back timed out
+        kout[pos] = k2[r];
+        vout[pos] = v2[r];
+      }
+    }
   }
   OS_STAMP(5)
+#undef OS_DIGIT
 }
 
 __global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ perm,
@@ -326,6 +371,326 @@ __global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ pe
   velid_out[i] = velid_in[j];
 }
 
+
+// =====================================================================================================
+// Splitter sort (bhk_sort_split): the sort of a STEP whose bodies are still stored in the previous step's key
+// order.  At ~1M keys a radix pass is latency, not bandwidth (launch + look-back + the ranking chain: ~21 us
+// of which ~3 us is data movement), so eight passes cost ~0.2 ms.  Instead:
+//   1. keys_split_kernel  computes the keys AND picks <= 255 splitters — the keys of the bodies at evenly spaced
+//      positions of the (nearly sorted) body array, so the buckets come out nearly equal — and counts the
+//      bucket sizes;
+//   2. ONE partition pass (onesweep_pass_kernel<true>) moves every key to its bucket, stably;
+//   3. local_sort_kernel: one workgroup per bucket sorts it entirely in LDS (stable LSD radix over the digit
+//      positions that actually vary inside the bucket), writes the sorted keys and gathers the bodies.
+// Three kernels instead of eleven; result bit-identical to the radix sort (both are stable).  A bucket that does
+// not fit LDS (order drifted a lot, or forced on random input) is sorted by its workgroup through global
+// memory: slow, correct.  Not used for the first sort after an upload (no order to exploit).
+constexpr int kLsThreads = 512;
+constexpr int kLsWaves = kLsThreads / 64;
+constexpr int kLsCap = 8192;  // keys per bucket sorted in LDS
+constexpr int kLsItems = kLsCap / kLsThreads;
+
+template <int B>
+__global__ __launch_bounds__(256) void keys_split_kernel(const float4* __restrict__ posm,
+                                                         const float* __restrict__ bounds, int n, int nb,
+                                                         u64* __restrict__ keys, u64* __restrict__ splitters,
+                                                         u32* __restrict__ bcount) {
+  __shared__ u64 raw[256];
+  __shared__ u64 sp[256];
+  __shared__ u32 cnt[256];
+  const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
+  const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
+  const int tid = threadIdx.x, lane = tid & 63;
+  // splitter t+1 = key of the body stored at position (t+1) n / nb; unused slots sort to the end
+  u64 sk = ~0ull;
+  if (tid < nb - 1) {
+    const float4 q = posm[(int)(((u64)(tid + 1) * (u64)n) / (u64)nb)];
+    sk = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
+  }
+  raw[tid] = sk;
+  cnt[tid] = 0;
+  __syncthreads();
+  int rank = 0;
+  for (int c = 0; c < 256; c++) {
+    const u64 o = raw[c];
+    rank += (o < sk || (o == sk && c < tid)) ? 1 : 0;
+  }
+  sp[rank] = sk;
+  __syncthreads();
+  if (blockIdx.x == 0) splitters[tid] = sp[tid];
+  const int base = blockIdx.x * kTile;
+#pragma unroll 4
+  for (int r = 0; r < kHistItems; r++) {
+    const int i = base + r * kHistThreads + tid;
+    const bool valid = i < n;
+    u64 k = 0ull;
+    if (valid) {
+      const float4 q = posm[i];
+      k = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
+      keys[i] = k;
+    }
+    const u32 g = splitter_bucket(sp, k);
+    const u64 act = __ballot(valid);
+    if (act == 0ull) continue;
+    const int l0 = __ffsll((long long)act) - 1;
+    const u32 g0 = __shfl(g, l0, 64);
+    if (__ballot(valid && g != g0) == 0ull) {
+      if (lane == l0) atomicAdd(&cnt[g0], (u32)__popcll(act));
+    } else if (valid) {
+      atomicAdd(&cnt[g], 1u);
+    }
+  }
+  __syncthreads();
+  if (cnt[tid]) atomicAdd(&bcount[tid], cnt[tid]);
+}
+
+// exclusive scan of one value per thread over the first 256 threads of the block (4 waves); all threads call
+__device__ __forceinline__ u32 scan256(u32 v, u32* dsum, u32* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u32 incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += u;
+  }
+  __syncthreads();  // dsum may still be in use
+  if (w < 4 && lane == 63) dsum[w] = incl;
+  __syncthreads();
+  u32 wp = 0;
+  for (int q = 0; q < (w & 3); q++) wp += dsum[q];
+  if (total) *total = dsum[0] + dsum[1] + dsum[2] + dsum[3];
+  return wp + incl - v;
+}
+
+// rank 64 keys of a wave by digit: returns the number of earlier keys (in this wave's earlier rows and in the
+// lower lanes of this row) with the same digit, and bumps the wave-private counter
+__device__ __forceinline__ u32 wave_rank(u32 g, bool valid, u32* wc, u64 lt) {
+  u64 mask = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < 8; bit++) {
+    const bool b = (g >> bit) & 1u;
+    const u64 bb = __ballot(b);
+    mask &= b ? bb : ~bb;
+  }
+  const u32 rank = (u32)__popcll(mask & lt);
+  u32 prev = 0;
+  if (valid) prev = wc[g];
+  if (valid && rank == 0) wc[g] = prev + (u32)__popcll(mask);
+  return prev + rank;
+}
+
+__global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
+    u64* kbuf, u32* vbuf,    // the partitioned keys / values (scratch of the slow path)
+    u64* kout, u32* vout,    // sorted keys / permutation
+    const u32* __restrict__ bcount, u32* __restrict__ bcount_next,
+    const float4* __restrict__ posm_in, const float4* __restrict__ velid_in, float4* __restrict__ posm_out,
+    float4* __restrict__ velid_out, u32* __restrict__ sw_ticket) {
+  __shared__ u64 skey[kLsCap];
+  __shared__ u32 sval[kLsCap];
+  __shared__ u32 wcnt[kLsWaves][256];
+  __shared__ u32 toff[256];
+  __shared__ u32 dsum[4];
+  __shared__ u64 s_diff[kLsWaves];
+  __shared__ u32 s_start, s_size;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.x;
+  const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  {
+    const u32 cv = (tid < 256) ? bcount[tid] : 0u;
+    const u32 ex = scan256(cv, dsum, nullptr);
+    if (tid == b) {
+      s_start = ex;
+      s_size = cv;
+    }
+  }
+  if (b == 0) {
+    // last kernel of the sort: leave the next call's bucket counters and the partition pass's tile ticket
+    // cleared, advance the call number (tag of the look-back granules)
+    if (tid < 256) bcount_next[tid] = 0u;
+    if (tid == 0) {
+      sw_ticket[0] = 0u;
+      sw_ticket[8] += 1u;
+    }
+  }
+  __syncthreads();
+  const int start = (int)s_start, size = (int)s_size;
+  if (size == 0) return;
+
+  if (size <= kLsCap) {
+    // ---- the bucket in registers, blocked by wave: wave w owns positions [w chunk, (w+1) chunk)
+    const int chunk = ((size + kLsThreads - 1) / kLsThreads) * 64;
+    const int nit = chunk / 64;
+    const int wbase = w * chunk;
+    u64 key[kLsItems];
+    u32 val[kLsItems];
+    u64 diff = 0ull;
+    const u64 k0 = kbuf[start];
+#pragma unroll
+    for (int r = 0; r < kLsItems; r++) {
+      key[r] = ~0ull;
+      val[r] = 0u;
+      if (r < nit) {
+        const int idx = wbase + r * 64 + lane;
+        if (idx < size) {
+          key[r] = kbuf[start + idx];
+          val[r] = vbuf[start + idx];
+          diff |= key[r] ^ k0;
+        }
+      }
+    }
+    // digit positions that vary inside the bucket (the keys of a bucket share their leading bits)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) diff |= __shfl_xor(diff, d, 64);
+    if (lane == 0) s_diff[w] = diff;
+    __syncthreads();
+    diff = 0ull;
+#pragma unroll
+    for (int q = 0; q < kLsWaves; q++) diff |= s_diff[q];
+
+#pragma unroll 1
+    for (int p = 0; p < 8; p++) {
+      const int shift = 8 * p;
+      if (((diff >> shift) & 255ull) == 0ull) continue;  // block-uniform
+      for (int q = tid; q < kLsWaves * 256; q += kLsThreads) (&wcnt[0][0])[q] = 0;
+      __syncthreads();
+      u32 rk[kLsItems];
+#pragma unroll
+      for (int r = 0; r < kLsItems; r++) {
+        rk[r] = 0;
+        if (r < nit) {
+          const int idx = wbase + r * 64 + lane;
+          rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, idx < size, wcnt[w], lt);
+        }
+      }
+      __syncthreads();
+      u32 h = 0;
+      if (tid < 256) {
+#pragma unroll
+        for (int q = 0; q < kLsWaves; q++) {
+          const u32 cq = wcnt[q][tid];
+          wcnt[q][tid] = h;
+          h += cq;
+        }
+      }
+      const u32 lo = scan256(h, dsum, nullptr);
+      if (tid < 256) toff[tid] = lo;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kLsItems; r++) {
+        if (r < nit) {
+          const int idx = wbase + r * 64 + lane;
+          if (idx < size) {
+            const u32 g = (u32)(key[r] >> shift) & 255u;
+            const u32 lp = toff[g] + wcnt[w][g] + rk[r];
+            skey[lp] = key[r];
+            sval[lp] = val[r];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kLsItems; r++) {
+        if (r < nit) {
+          const int idx = wbase + r * 64 + lane;
+          if (idx < size) {
+            key[r] = skey[idx];
+            val[r] = sval[idx];
+          }
+        }
+      }
+      // (the barrier at the top of the next pass, or none needed after the last, orders these reads)
+    }
+#pragma unroll
+    for (int r = 0; r < kLsItems; r++) {
+      if (r < nit) {
+        const int idx = wbase + r * 64 + lane;
+        if (idx < size) {
+          const u32 v = val[r];
+          kout[start + idx] = key[r];
+          vout[start + idx] = v;
+          posm_out[start + idx] = posm_in[v];
+          velid_out[start + idx] = velid_in[v];
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- a bucket that does not fit LDS: stable LSD radix over all 8 digits by this one workgroup, ping-pong
+  // between the bucket's own ranges of (kbuf, vbuf) and (kout, vout); 4096-key chunks in order, running
+  // per-digit cursors in LDS.  Slow (one CU), only for buckets the splitters failed to balance.
+  u64* sk = kbuf + start;
+  u32* sv = vbuf + start;
+  u64* dk = kout + start;
+  u32* dv = vout + start;
+  u32* cur = toff;
+  u32* cbase = reinterpret_cast<u32*>(skey);  // [256]
+#pragma unroll 1
+  for (int p = 0; p < 8; p++) {
+    const int shift = 8 * p;
+    if (tid < 256) cur[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < size; i += kLsThreads) atomicAdd(&cur[(u32)(sk[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    const u32 hv = (tid < 256) ? cur[tid] : 0u;
+    const u32 ex = scan256(hv, dsum, nullptr);
+    if (tid < 256) cur[tid] = ex;
+    __syncthreads();
+    constexpr int kChunk = kLsThreads * 8;
+#pragma unroll 1
+    for (int c0 = 0; c0 < size; c0 += kChunk) {
+      for (int q = tid; q < kLsWaves * 256; q += kLsThreads) (&wcnt[0][0])[q] = 0;
+      __syncthreads();
+      u64 key[8];
+      u32 val[8], rk[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int idx = c0 + w * 512 + r * 64 + lane;
+        const bool valid = idx < size;
+        key[r] = valid ? sk[idx] : ~0ull;
+        val[r] = valid ? sv[idx] : 0u;
+        rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, valid, wcnt[w], lt);
+      }
+      __syncthreads();
+      if (tid < 256) {
+        u32 h = 0;
+#pragma unroll
+        for (int q = 0; q < kLsWaves; q++) {
+          const u32 cq = wcnt[q][tid];
+          wcnt[q][tid] = h;
+          h += cq;
+        }
+        cbase[tid] = cur[tid];
+        cur[tid] += h;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int idx = c0 + w * 512 + r * 64 + lane;
+        if (idx < size) {
+          const u32 g = (u32)(key[r] >> shift) & 255u;
+          const u32 pos = cbase[g] + wcnt[w][g] + rk[r];
+          dk[pos] = key[r];
+          dv[pos] = val[r];
+        }
+      }
+      __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    u64* tk = sk; sk = dk; dk = tk;
+    u32* tv = sv; sv = dv; dv = tv;
+  }
+  // eight passes: the sorted bucket is back in (kbuf, vbuf)
+  for (int i = tid; i < size; i += kLsThreads) {
+    const u32 v = sv[i];
+    kout[start + i] = sk[i];
+    vout[start + i] = v;
+    posm_out[start + i] = posm_in[v];
+    velid_out[start + i] = velid_in[v];
+  }
+}
+
 }  // namespace
 
 #ifdef BH_OS_TRACE
@@ -333,6 +698,57 @@ extern "C" int bh_debug_os_trace(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_trace), sizeof(g_os_trace));
 }
 #endif
+
+// number of buckets of the splitter sort: ~512 keys each for small n, at most 256
+static int split_buckets(int n) {
+  int nb = (n + 511) / 512;
+  return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+}
+
+// The splitter sort needs the bodies in (about) key order and buckets that fit LDS with room for drift.
+bool bhk_sort_split_eligible(const bh_ctx* c) {
+  const int v = c->p.sort_variant;
+  if (v != 0 && v != 3) return false;
+  if (c->dd || c->p.step_graph == 1) return false;
+  if (c->n > 256 * 6144) return false;
+  return v == 3 || c->order_hint;
+}
+
+hipError_t bhk_keys_split(bh_ctx* c) {
+  const int n = c->n;
+  u32* bc = c->sp_count + 256 * (c->sp_par & 1);
+  if (c->keys_split) {  // counted before and never consumed by a sort: start over
+    const hipError_t e = hipMemsetAsync(bc, 0, 256 * sizeof(u32), c->stream);
+    if (e != hipSuccess) return e;
+  }
+  const int nb = split_buckets(n);
+  if (c->B == 10)
+    keys_split_kernel<10><<<c->sort_tiles, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, nb, c->keys[0],
+                                                                 c->sp_keys, bc);
+  else
+    keys_split_kernel<21><<<c->sort_tiles, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, nb, c->keys[0],
+                                                                 c->sp_keys, bc);
+  c->keys_split = true;
+  return hipGetLastError();
+}
+
+hipError_t bhk_sort_split(bh_ctx* c) {
+  const int n = c->n;
+  const int par = c->sp_par & 1;
+  u32* bc = c->sp_count + 256 * par;
+  c->sort_calls++;
+  onesweep_pass_kernel<true><<<c->sort_tiles, kThreads, 0, c->stream>>>(
+      c->keys[0], c->vals[0], c->keys[1], c->vals[1], n, 0, bc, c->sw_status, c->sw_ticket, c->sw_ticket + 8, 1,
+      c->info, c->sp_keys);
+  local_sort_kernel<<<split_buckets(n), kLsThreads, 0, c->stream>>>(
+      c->keys[1], c->vals[1], c->keys[0], c->vals[0], bc, c->sp_count + 256 * (par ^ 1), c->posm[c->cur],
+      c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket);
+  c->key_buf = 0;
+  c->cur ^= 1;
+  c->sp_par ^= 1;
+  c->keys_split = false;
+  return hipGetLastError();
+}
 
 hipError_t bhk_sort_onesweep(bh_ctx* c) {
   const int n = c->n;
@@ -343,9 +759,9 @@ hipError_t bhk_sort_onesweep(bh_ctx* c) {
   c->sort_calls++;
   int src = 0;
   for (int p = 0; p < passes; p++) {
-    onesweep_pass_kernel<<<ntiles, kThreads, 0, c->stream>>>(
+    onesweep_pass_kernel<false><<<ntiles, kThreads, 0, c->stream>>>(
         c->keys[src], c->vals[src], c->keys[src ^ 1], c->vals[src ^ 1], n, 8 * p, c->sw_hist + p * 256,
-        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, c->sw_ticket + 8, p == 0, c->info);
+        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, c->sw_ticket + 8, p == 0, c->info, nullptr);
     src ^= 1;
   }
   c->key_buf = src;

@@ -822,6 +822,12 @@ hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int str
 }
 
 hipError_t bhk_keys(bh_ctx* c) {
+  if (bhk_sort_split_eligible(c)) return bhk_keys_split(c);  // keys + splitters + bucket counts in one kernel
+  if (c->keys_split) {  // bucket counts of keys that no sort consumed: void them
+    const hipError_t e = hipMemsetAsync(c->sp_count + 256 * (c->sp_par & 1), 0, 256 * sizeof(u32), c->stream);
+    if (e != hipSuccess) return e;
+    c->keys_split = false;
+  }
   const int n = c->n;
   const int blocks = (n + 255) / 256;
   if (c->B == 10)

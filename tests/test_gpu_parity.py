@@ -49,12 +49,13 @@ def test_keys_bit_exact(pkg, orc, n, key_bits):
     e.close()
 
 
-@pytest.mark.parametrize("sort_variant", [0, 1])
+@pytest.mark.parametrize("sort_variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("key_bits", [63, 30])
 @pytest.mark.parametrize("n", [1, 2, 65, 4096, 4097, 65536, 300001])
 def test_sort_stable_permutation(pkg, orc, n, key_bits, sort_variant):
-    """both radix-sort implementations (0 = one kernel per pass with decoupled look-back,
-    1 = histogram/scan/scatter) == the oracle's stable merge sort, exact permutation"""
+    """every sort implementation (0 = automatic, 1 = histogram/scan/scatter radix passes, 2 = one kernel per
+    radix pass with look-back, 3 = splitter sort forced on caller-order input) == the oracle's stable merge
+    sort, exact permutation"""
     ic = pkg.plummer(n, seed=3)
     e = _engine(pkg, ic, key_bits=key_bits, max_depth=key_bits // 3, sort_variant=sort_variant)
     e.bbox(); e.morton(); e.sort()
@@ -71,7 +72,7 @@ def test_sort_stable_permutation(pkg, orc, n, key_bits, sort_variant):
     e.close()
 
 
-@pytest.mark.parametrize("sort_variant", [0, 1])
+@pytest.mark.parametrize("sort_variant", [0, 1, 2, 3])
 def test_sort_many_ties_and_repeated_calls(pkg, orc, sort_variant):
     """heavy ties (grid input, 30-bit keys) and 20 consecutive sorts on one context: the look-back
     table is never cleared between calls (tagged granules, monotonic tickets)"""
@@ -86,6 +87,46 @@ def test_sort_many_ties_and_repeated_calls(pkg, orc, sort_variant):
         assert np.array_equal(e.download_keys(), sk), it
     assert e.stats().status_flags == 0
     e.close()
+
+
+@pytest.mark.parametrize("n,shuffle", [(1000000, True), (1000000, False), (1500000, False), (200000, True)])
+def test_splitter_sort_bucket_paths(pkg, orc, n, shuffle):
+    """splitter sort forced (sort_variant 3): on caller-order (random) input a good part of the 256 buckets
+    exceeds the 8192 keys that fit LDS and goes through the one-workgroup global-memory path; on input that is
+    already in key order every bucket takes the LDS path.  Both == the oracle's stable sort."""
+    ic = pkg.plummer(n, seed=11)
+    b = orc.bbox(*ic[:3])
+    keys = orc.keys(*ic[:3], b, 63)
+    if not shuffle:  # present the bodies in key order, as a step leaves them
+        _, p0 = orc.sort(keys)
+        ic = tuple(a[p0] for a in ic)
+        keys = orc.keys(*ic[:3], b, 63)
+    e = _engine(pkg, ic, sort_variant=3)
+    e.bbox(); e.morton(); e.sort()
+    sk, perm = orc.sort(keys)
+    assert np.array_equal(e.download_keys(), sk)
+    assert np.array_equal(e.download_order(), perm)
+    bodies = e.download_sorted_bodies()
+    assert np.array_equal(bodies[:, 0], ic[0][perm])
+    assert e.stats().status_flags == 0
+    e.close()
+
+
+def test_splitter_sort_in_steps(pkg, orc):
+    """automatic choice: the first sort after an upload is the radix sort, later steps use the splitter sort;
+    the body order after 6 steps equals that of a context pinned to the radix sort, bit for bit"""
+    ic = pkg.plummer(120000, seed=5)
+    out = []
+    for sv in (0, 2):
+        e = _engine(pkg, ic, sort_variant=sv)
+        for _ in range(6):
+            e.step()
+        out.append((e.download_order(), e.download_sorted_bodies(), e.download_keys()))
+        assert e.stats().status_flags == 0
+        e.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1].tobytes() == out[1][1].tobytes()
+    assert np.array_equal(out[0][2], out[1][2])
 
 
 def _check_tree(pkg, orc, ic, **kw):

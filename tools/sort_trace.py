@@ -1,6 +1,6 @@
 """design study: per-tile phase timeline of the onesweep pass kernel (library built with -DBH_OS_TRACE,
-selected with BH_LIB_PATH).  Stamps: 0 ticket, 1 ranked, 2 look-back done (digit 0), 3 offsets ready,
-4 keys scattered, 5 end.  Prints, per pass, the spread of start times and the median / max of every phase."""
+selected with BH_LIB_PATH).  Stamps: 0 ticket, 1 counted + ranked, 2 own group summed (digit 0),
+3 offsets + staging done, 4 earlier groups summed, 5 end.  Prints, per pass, the spread of start times and the median / max of every phase."""
 import sys, os, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +25,7 @@ for p in range(8):
     us = (t - t0) / 100.0
     d = np.diff(us, axis=1)
     print(f"pass {p}: tiles {nt} start spread {us[:,0].max():.2f} us, end max {us[:,5].max():.2f} us")
-    for k, name in enumerate(["load+rank", "lookback", "offsets", "scatter keys", "scatter vals"]):
+    for k, name in enumerate(["load+rank", "own group", "offs+stage", "earlier grps", "global write"]):
         print(f"   {name:13s} median {np.median(d[:,k]):6.2f}  max {d[:,k].max():6.2f}  (abs end median {np.median(us[:,k+1]):6.2f})")
     if p == 3:
         idx = np.argsort(us[:, 5])[-5:]
