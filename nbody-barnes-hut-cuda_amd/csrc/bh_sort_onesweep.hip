@@ -47,8 +47,12 @@ static_assert(kThreads >= 256 && kThreads % 256 == 0 && kTile % kThreads == 0, "
 __device__ unsigned long long g_os_trace[8][4096][8];
 #define OS_STAMP(k) \
   if (threadIdx.x == 0 && tile < 4096) g_os_trace[shift >> 3][tile][k] = wall_clock64();
+__device__ unsigned long long g_ls_trace[256][16];
+#define LS_STAMP(k, v) \
+  if (threadIdx.x == 0) g_ls_trace[blockIdx.x][k] = (v);
 #else
 #define OS_STAMP(k)
+#define LS_STAMP(k, v)
 #endif
 
 __device__ __forceinline__ u64 pack_granule(u32 tag, u32 state, u32 value) {
@@ -86,6 +90,28 @@ __global__ __launch_bounds__(kHistThreads) void onesweep_hist_kernel(const u64* 
     const u32 v = h[p][threadIdx.x];
     if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], v);
   }
+}
+
+// rank 64 keys of a wave by digit: returns the number of earlier keys (in this wave's earlier rows and in the
+// lower lanes of this row) with the same digit, and bumps the wave-private counter.  Match-any over the 8
+// digit bits; per bit: sign-extended bit field, ballot, two 3-input booleans = 4 VALU — the ranking is VALU-issue
+// bound, so the instruction count is the cost.
+__device__ __forceinline__ u32 wave_rank(u32 g, bool valid, u32* wc, u32 lt_lo, u32 lt_hi) {
+  const u64 vb = __ballot(valid);
+  u32 xlo = 0u, xhi = 0u;  // lanes whose digit differs from mine in some bit
+#pragma unroll
+  for (int bit = 0; bit < 8; bit++) {
+    const u32 bm = (u32)__builtin_amdgcn_sbfe((int)g, bit, 1);  // all ones iff the bit is set
+    const u64 bb = __ballot(bm != 0u);
+    xlo = __builtin_amdgcn_bitop3_b32(xlo, (u32)bb, bm, 0xf6);          // x | (bb ^ bm): gfx950 3-input boolean
+    xhi = __builtin_amdgcn_bitop3_b32(xhi, (u32)(bb >> 32), bm, 0xf6);
+  }
+  const u32 mlo = ~xlo & (u32)vb, mhi = ~xhi & (u32)(vb >> 32);
+  const u32 rank = (u32)__popc(mlo & lt_lo) + (u32)__popc(mhi & lt_hi);
+  u32 prev = 0;
+  if (valid) prev = wc[g];
+  if (valid && rank == 0) wc[g] = prev + (u32)__popc(mlo) + (u32)__popc(mhi);
+  return prev + rank;
 }
 
 // One granule row of look-back: kN independent loads `stride` tiles apart starting at tile tt, consumed in
@@ -126,6 +152,16 @@ __device__ __forceinline__ u32 splitter_bucket(const u64* sp, u64 key) {
   return lo;
 }
 
+// The splitters are the keys of evenly spaced bodies of the array being partitioned, so the body at position i
+// almost always belongs to bucket ~ i nb / n: two independent LDS reads confirm the guess; the 8-step search
+// runs only for the rows where some lane's guess fails (bucket boundaries, bodies that moved far).
+__device__ __forceinline__ u32 splitter_bucket_guess(const u64* sp, u64 key, int i, float nb_over_n) {
+  const u32 gq = min((u32)((float)i * nb_over_n), 255u);
+  const u64 a = gq ? sp[gq - 1] : 0ull, b = sp[gq];
+  if (a <= key && key < b) return gq;
+  return splitter_bucket(sp, key);
+}
+
 // SPLIT = false: one LSD radix pass, digit = 8 key bits at `shift`.
 // SPLIT = true : the partition pass of the splitter sort (bhk_sort_split below): "digit" = the key's bucket
 //                among the <= 255 sorted splitters, ghist_pass = the bucket totals counted by keys_split_kernel.
@@ -134,10 +170,12 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
     const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout,
     u32* __restrict__ vout, int n, int shift, const u32* __restrict__ ghist_pass,
     u64* __restrict__ status, u32* __restrict__ ticket, const u32* __restrict__ call_ptr, int first_pass,
-    bh_devinfo* __restrict__ info, const u64* __restrict__ splitters) {
+    bh_devinfo* __restrict__ info, const u64* __restrict__ splitters, float nb_over_n) {
   __shared__ u64 s_sp[SPLIT ? 256 : 1];
+  __shared__ unsigned char sdig[SPLIT ? kTile : 1];  // the staged keys' buckets (cheaper than searching again)
   if (SPLIT && threadIdx.x < 256) s_sp[threadIdx.x] = splitters[threadIdx.x];
-#define OS_DIGIT(k) (SPLIT ? splitter_bucket(s_sp, (k)) : ((u32)((k) >> shift) & 255u))
+  u32 dg[SPLIT ? kItems : 1];
+#define OS_DIGIT(r) (SPLIT ? dg[r] : ((u32)(key[r] >> shift) & 255u))
   // tag = number of this sort call, kept on the device (sw_ticket[8], advanced by the gather kernel that ends
   // every sort) so that the kernel arguments of a step never change: bh_step replays as a HIP graph
   const u32 tag = (*call_ptr + 1u) & 0x3fffffffu;
@@ -168,6 +206,12 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
     key[r] = valid ? kin[i] : ~0ull;
     val[r] = valid ? (first_pass ? (u32)i : vin[i]) : 0u;
   }
+  if (SPLIT) {
+    __syncthreads();  // s_sp
+#pragma unroll
+    for (int r = 0; r < kItems; r++)
+      dg[SPLIT ? r : 0] = splitter_bucket_guess(s_sp, key[r], base + r * 64 + lane, nb_over_n);
+  }
   // ---- 1. the tile's digit counts FIRST (one LDS atomic per key, or per wave when its 64 keys share the
   // digit), published before the ranking: by the time the ranking is done the neighbours' counts have
   // crossed the fabric (a publication takes ~1 us to become visible to another XCD) and the look-back below
@@ -176,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
   for (int r = 0; r < kItems; r++) {
     const int i = base + r * 64 + lane;
     const bool valid = i < n;
-    const u32 g = OS_DIGIT(key[r]);
+    const u32 g = OS_DIGIT(r);
     const u64 act = __ballot(valid);
     if (act == 0ull) continue;
     const int l0 = __ffsll((long long)act) - 1;
@@ -211,20 +255,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
     const int i = base + r * 64 + lane;
-    const bool valid = i < n;
-    const u32 g = OS_DIGIT(key[r]);
-    u64 mask = __ballot(valid);
-#pragma unroll
-    for (int bit = 0; bit < 8; bit++) {
-      const bool b = (g >> bit) & 1u;
-      const u64 bb = __ballot(b);
-      mask &= b ? bb : ~bb;
-    }
-    const u32 rank = (u32)__popcll(mask & lt);
-    u32 prev = 0;
-    if (valid) prev = wcnt[w][g];
-    rk[r] = prev + rank;
-    if (valid && rank == 0) wcnt[w][g] = prev + (u32)__popcll(mask);
+    rk[r] = wave_rank(OS_DIGIT(r), i < n, wcnt[w], (u32)lt, (u32)(lt >> 32));
   }
   __syncthreads();
   OS_STAMP(1)
@@ -289,9 +320,12 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
     const int i = base + r * 64 + lane;
-    const u32 g = OS_DIGIT(key[r]);
+    const u32 g = OS_DIGIT(r);
     lp[r] = toff[g] + wcnt[w][g] + rk[r];
-    if (i < n) stage[lp[r]] = key[r];
+    if (i < n) {
+      stage[lp[r]] = key[r];
+      if (SPLIT) sdig[lp[r]] = (unsigned char)g;
+    }
   }
   __syncthreads();
   u64 k2[kItems];
@@ -299,6 +333,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
   for (int r = 0; r < kItems; r++) {
     const int idx = r * kThreads + (int)threadIdx.x;
     k2[r] = (idx < nvalid) ? stage[idx] : ~0ull;
+    if (SPLIT) dg[SPLIT ? r : 0] = (idx < nvalid) ? (u32)sdig[idx] : 0u;
   }
   __syncthreads();
   u32* stage32 = reinterpret_cast<u32*>(stage);
@@ -340,7 +375,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
   for (int r = 0; r < kItems; r++) {
     const int idx = r * kThreads + (int)threadIdx.x;
     if (idx < nvalid) {
-      const u32 pos = gbase[OS_DIGIT(k2[r])] + (u32)idx;
+      const u32 pos = gbase[SPLIT ? dg[SPLIT ? r : 0] : ((u32)(k2[r] >> shift) & 255u)] + (u32)idx;
       if (pos < (u32)n) {  // always true unless a look-back timed out
         kout[pos] = k2[r];
         vout[pos] = v2[r];
@@ -390,46 +425,58 @@ constexpr int kLsWaves = kLsThreads / 64;
 constexpr int kLsCap = 8192;  // keys per bucket sorted in LDS
 constexpr int kLsItems = kLsCap / kLsThreads;
 
+constexpr int kKsThreads = 1024;  // x 4 keys: 4 waves per SIMD hide the LDS round trips of the bucket lookups
 template <int B>
-__global__ __launch_bounds__(256) void keys_split_kernel(const float4* __restrict__ posm,
-                                                         const float* __restrict__ bounds, int n, int nb,
-                                                         u64* __restrict__ keys, u64* __restrict__ splitters,
-                                                         u32* __restrict__ bcount) {
+__global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __restrict__ posm,
+                                                               const float* __restrict__ bounds, int n, int nb,
+                                                               float nb_over_n, u64* __restrict__ keys,
+                                                               u64* __restrict__ splitters,
+                                                               u32* __restrict__ bcount) {
   __shared__ u64 raw[256];
   __shared__ u64 sp[256];
   __shared__ u32 cnt[256];
   const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
   const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
   const int tid = threadIdx.x, lane = tid & 63;
+  // the tile's own keys first (their loads overlap the splitter work)
+  const int base = blockIdx.x * kTile;
+  u64 k[kTile / kKsThreads];
+#pragma unroll
+  for (int r = 0; r < kTile / kKsThreads; r++) {
+    const int i = base + r * kKsThreads + tid;
+    k[r] = 0ull;
+    if (i < n) {
+      const float4 q = posm[i];
+      k[r] = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
+      keys[i] = k[r];
+    }
+  }
   // splitter t+1 = key of the body stored at position (t+1) n / nb; unused slots sort to the end
   u64 sk = ~0ull;
   if (tid < nb - 1) {
     const float4 q = posm[(int)(((u64)(tid + 1) * (u64)n) / (u64)nb)];
     sk = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
   }
-  raw[tid] = sk;
-  cnt[tid] = 0;
-  __syncthreads();
-  int rank = 0;
-  for (int c = 0; c < 256; c++) {
-    const u64 o = raw[c];
-    rank += (o < sk || (o == sk && c < tid)) ? 1 : 0;
+  if (tid < 256) {
+    raw[tid] = sk;
+    cnt[tid] = 0;
   }
-  sp[rank] = sk;
   __syncthreads();
-  if (blockIdx.x == 0) splitters[tid] = sp[tid];
-  const int base = blockIdx.x * kTile;
-#pragma unroll 4
-  for (int r = 0; r < kHistItems; r++) {
-    const int i = base + r * kHistThreads + tid;
-    const bool valid = i < n;
-    u64 k = 0ull;
-    if (valid) {
-      const float4 q = posm[i];
-      k = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
-      keys[i] = k;
+  if (tid < 256) {
+    int rank = 0;
+    for (int c = 0; c < 256; c++) {
+      const u64 o = raw[c];
+      rank += (o < sk || (o == sk && c < tid)) ? 1 : 0;
     }
-    const u32 g = splitter_bucket(sp, k);
+    sp[rank] = sk;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 256) splitters[tid] = sp[tid];
+#pragma unroll
+  for (int r = 0; r < kTile / kKsThreads; r++) {
+    const int i = base + r * kKsThreads + tid;
+    const bool valid = i < n;
+    const u32 g = splitter_bucket_guess(sp, k[r], i, nb_over_n);
     const u64 act = __ballot(valid);
     if (act == 0ull) continue;
     const int l0 = __ffsll((long long)act) - 1;
@@ -441,7 +488,7 @@ __global__ __launch_bounds__(256) void keys_split_kernel(const float4* __restric
     }
   }
   __syncthreads();
-  if (cnt[tid]) atomicAdd(&bcount[tid], cnt[tid]);
+  if (tid < 256 && cnt[tid]) atomicAdd(&bcount[tid], cnt[tid]);
 }
 
 // exclusive scan of one value per thread over the first 256 threads of the block (4 waves); all threads call
@@ -460,23 +507,6 @@ __device__ __forceinline__ u32 scan256(u32 v, u32* dsum, u32* total) {
   for (int q = 0; q < (w & 3); q++) wp += dsum[q];
   if (total) *total = dsum[0] + dsum[1] + dsum[2] + dsum[3];
   return wp + incl - v;
-}
-
-// rank 64 keys of a wave by digit: returns the number of earlier keys (in this wave's earlier rows and in the
-// lower lanes of this row) with the same digit, and bumps the wave-private counter
-__device__ __forceinline__ u32 wave_rank(u32 g, bool valid, u32* wc, u64 lt) {
-  u64 mask = __ballot(valid);
-#pragma unroll
-  for (int bit = 0; bit < 8; bit++) {
-    const bool b = (g >> bit) & 1u;
-    const u64 bb = __ballot(b);
-    mask &= b ? bb : ~bb;
-  }
-  const u32 rank = (u32)__popcll(mask & lt);
-  u32 prev = 0;
-  if (valid) prev = wc[g];
-  if (valid && rank == 0) wc[g] = prev + (u32)__popcll(mask);
-  return prev + rank;
 }
 
 __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
@@ -514,6 +544,8 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
   }
   __syncthreads();
   const int start = (int)s_start, size = (int)s_size;
+  LS_STAMP(0, wall_clock64())
+  LS_STAMP(4, (unsigned long long)size)
   if (size == 0) return;
 
   if (size <= kLsCap) {
@@ -546,23 +578,34 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
     diff = 0ull;
 #pragma unroll
     for (int q = 0; q < kLsWaves; q++) diff |= s_diff[q];
+    LS_STAMP(1, wall_clock64())
+    LS_STAMP(5, diff)
 
 #pragma unroll 1
     for (int p = 0; p < 8; p++) {
       const int shift = 8 * p;
       if (((diff >> shift) & 255ull) == 0ull) continue;  // block-uniform
+#ifdef BH_OS_TRACE
+      const bool tr = (p == 1);
+#define LS_PSTAMP(k) if (tr) { LS_STAMP(k, wall_clock64()) }
+#else
+#define LS_PSTAMP(k)
+#endif
+      LS_PSTAMP(8)
       for (int q = tid; q < kLsWaves * 256; q += kLsThreads) (&wcnt[0][0])[q] = 0;
       __syncthreads();
+      LS_PSTAMP(9)
       u32 rk[kLsItems];
 #pragma unroll
       for (int r = 0; r < kLsItems; r++) {
         rk[r] = 0;
         if (r < nit) {
           const int idx = wbase + r * 64 + lane;
-          rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, idx < size, wcnt[w], lt);
+          rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, idx < size, wcnt[w], (u32)lt, (u32)(lt >> 32));
         }
       }
       __syncthreads();
+      LS_PSTAMP(10)
       u32 h = 0;
       if (tid < 256) {
 #pragma unroll
@@ -575,6 +618,7 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
       const u32 lo = scan256(h, dsum, nullptr);
       if (tid < 256) toff[tid] = lo;
       __syncthreads();
+      LS_PSTAMP(11)
 #pragma unroll
       for (int r = 0; r < kLsItems; r++) {
         if (r < nit) {
@@ -588,6 +632,7 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
         }
       }
       __syncthreads();
+      LS_PSTAMP(12)
 #pragma unroll
       for (int r = 0; r < kLsItems; r++) {
         if (r < nit) {
@@ -598,8 +643,10 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
           }
         }
       }
+      LS_PSTAMP(13)
       // (the barrier at the top of the next pass, or none needed after the last, orders these reads)
     }
+    LS_STAMP(2, wall_clock64())
 #pragma unroll
     for (int r = 0; r < kLsItems; r++) {
       if (r < nit) {
@@ -613,6 +660,7 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
         }
       }
     }
+    LS_STAMP(3, wall_clock64())
     return;
   }
 
@@ -649,7 +697,7 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
         const bool valid = idx < size;
         key[r] = valid ? sk[idx] : ~0ull;
         val[r] = valid ? sv[idx] : 0u;
-        rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, valid, wcnt[w], lt);
+        rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, valid, wcnt[w], (u32)lt, (u32)(lt >> 32));
       }
       __syncthreads();
       if (tid < 256) {
@@ -697,6 +745,9 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
 extern "C" int bh_debug_os_trace(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_trace), sizeof(g_os_trace));
 }
+extern "C" int bh_debug_ls_trace(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_trace), sizeof(g_ls_trace));
+}
 #endif
 
 // number of buckets of the splitter sort: ~512 keys each for small n, at most 256
@@ -723,11 +774,11 @@ hipError_t bhk_keys_split(bh_ctx* c) {
   }
   const int nb = split_buckets(n);
   if (c->B == 10)
-    keys_split_kernel<10><<<c->sort_tiles, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, nb, c->keys[0],
-                                                                 c->sp_keys, bc);
+    keys_split_kernel<10><<<c->sort_tiles, kKsThreads, 0, c->stream>>>(
+        c->posm[c->cur], c->bounds, n, nb, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
   else
-    keys_split_kernel<21><<<c->sort_tiles, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, nb, c->keys[0],
-                                                                 c->sp_keys, bc);
+    keys_split_kernel<21><<<c->sort_tiles, kKsThreads, 0, c->stream>>>(
+        c->posm[c->cur], c->bounds, n, nb, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
   c->keys_split = true;
   return hipGetLastError();
 }
@@ -739,7 +790,7 @@ hipError_t bhk_sort_split(bh_ctx* c) {
   c->sort_calls++;
   onesweep_pass_kernel<true><<<c->sort_tiles, kThreads, 0, c->stream>>>(
       c->keys[0], c->vals[0], c->keys[1], c->vals[1], n, 0, bc, c->sw_status, c->sw_ticket, c->sw_ticket + 8, 1,
-      c->info, c->sp_keys);
+      c->info, c->sp_keys, (float)split_buckets(n) / (float)n);
   local_sort_kernel<<<split_buckets(n), kLsThreads, 0, c->stream>>>(
       c->keys[1], c->vals[1], c->keys[0], c->vals[0], bc, c->sp_count + 256 * (par ^ 1), c->posm[c->cur],
       c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket);
@@ -761,7 +812,7 @@ hipError_t bhk_sort_onesweep(bh_ctx* c) {
   for (int p = 0; p < passes; p++) {
     onesweep_pass_kernel<false><<<ntiles, kThreads, 0, c->stream>>>(
         c->keys[src], c->vals[src], c->keys[src ^ 1], c->vals[src ^ 1], n, 8 * p, c->sw_hist + p * 256,
-        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, c->sw_ticket + 8, p == 0, c->info, nullptr);
+        c->sw_status + (size_t)p * ntiles * 256, c->sw_ticket + p, c->sw_ticket + 8, p == 0, c->info, nullptr, 0.0f);
     src ^= 1;
   }
   c->key_buf = src;
