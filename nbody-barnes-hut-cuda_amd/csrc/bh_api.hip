@@ -82,9 +82,9 @@ static void free_all(bh_ctx* c) {
   }
   void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sw_hist, c->sw_status,
-                  c->sw_ticket, c->sp_keys, c->sp_count, c->bbox_partial,
+                  c->sw_ticket, c->sp_keys, c->sp_count, c->bbox_partial, c->bounds_next, c->ibox_rows,
                   c->bounds, c->d8, c->ksamp, c->pa, c->pb, c->pn,
-                  c->cb, c->ttot, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
+                  c->cb, c->ttot, c->blk_done, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -172,12 +172,17 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && hipMemset(c->sw_hist, 0, 8 * 256 * sizeof(u32)) == hipSuccess;
   ok = ok && dalloc(&c->bbox_partial, (size_t)BH_BBOX_BLOCKS * 6) == hipSuccess;
   ok = ok && dalloc(&c->bounds, 8) == hipSuccess;
+  ok = ok && dalloc(&c->bounds_next, 8) == hipSuccess;
+  ok = ok && dalloc(&c->ibox_rows, (N / BH_INTEGRATE_TILE + 1) * 6) == hipSuccess;
   ok = ok && dalloc(&c->d8, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->ksamp, (size_t)2048 + 8) == hipSuccess;
   ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->cb, N + 4) == hipSuccess;
   ok = ok && dalloc(&c->ttot, 2 * (N / 1024 + 2)) == hipSuccess;
+  ok = ok && dalloc(&c->blk_done, 2 * BH_BLKDONE_STRIDE(N)) == hipSuccess;
+  ok = ok && hipMemset(c->blk_done, 0, 2 * BH_BLKDONE_STRIDE(N) * sizeof(u32)) == hipSuccess;
+  c->blk_done2 = c->blk_done ? c->blk_done + BH_BLKDONE_STRIDE(N) : nullptr;
   ok = ok && dalloc(&c->rec, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->frec, BH_FREC_POOL(c->rec_cap, N)) == hipSuccess;  // tree digests + body digests
   ok = ok && dalloc(&c->er_lo, (size_t)c->rec_cap) == hipSuccess;
@@ -262,6 +267,7 @@ int bh_upload(bh_ctx* c, const float* x, const float* y, const float* z, const f
     BH_HIP(c, hipMemcpyAsync(c->stage_buf + k * N, src[k], nb, hipMemcpyHostToDevice, c->stream));
   c->cur = 0;
   c->order_hint = false;  // caller order: nothing for the splitter sort to exploit
+  c->bounds_next_ok = false;
   BH_HIP(c, bhk_pack(c));
   BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));  // clears the sticky flags
   BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));
@@ -337,7 +343,8 @@ int bh_force(bh_ctx* c) {
 }
 int bh_integrate(bh_ctx* c) {
   BH_NEED(c, BH_ST_FORCE);
-  BH_HIP(c, bhk_integrate(c));
+  c->bounds_next_ok = false;
+  BH_HIP(c, bhk_integrate(c, false));
   c->stage = BH_ST_UPLOADED;  // positions changed: bbox..force must be redone
   return BH_OK;
 }
@@ -417,7 +424,14 @@ static int step_launch(bh_ctx* c) {
   hipEvent_t* ev = t ? c->evring + (size_t)(c->timed_steps % BH_TIMING_RING) * 8 : nullptr;
 #define BH_MARK(i) if (t) BH_HIP(c, hipEventRecord(ev[i], c->stream))
   BH_MARK(0);
-  BH_HIP(c, bhk_bbox(c));                      // ref:259
+  if (c->bounds_next_ok) {  // the previous step's integrate already folded the cube of these positions
+    float* t = c->bounds;
+    c->bounds = c->bounds_next;
+    c->bounds_next = t;
+    c->bounds_next_ok = false;
+  } else {
+    BH_HIP(c, bhk_bbox(c));                    // ref:259
+  }
   BH_MARK(1);
   BH_HIP(c, bhk_keys(c));                      // ref:260
   c->key_buf = 0;
@@ -437,7 +451,9 @@ static int step_launch(bh_ctx* c) {
   BH_MARK(5);
   BH_HIP(c, bhk_force(c, 0, c->n, false));     // ref:281
   BH_MARK(6);
-  BH_HIP(c, bhk_integrate(c));                 // ref:282
+  const bool fuse_bbox = !c->dd && c->p.step_graph != 1;
+  BH_HIP(c, bhk_integrate(c, fuse_bbox));      // ref:282 (+ ref:259 of the next step)
+  c->bounds_next_ok = fuse_bbox;
   BH_MARK(7);
 #undef BH_MARK
   if (t) c->timed_steps++;

@@ -975,6 +975,8 @@ void bh_dd_free(bh_ctx* c) {
   c->acc2 = nullptr;
   free(d);
   c->dd = nullptr;
+  c->bounds_next_ok = false;  // the domain-decomposed steps moved and exchanged bodies
+  c->order_hint = false;
 }
 
 extern "C" {
@@ -1016,6 +1018,8 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   bh_dd_state* d = (bh_dd_state*)calloc(1, sizeof(bh_dd_state));
   if (!d) return BH_ERR_OOM;
   c->dd = d;
+  c->bounds_next_ok = false;
+  c->order_hint = false;
   d->world = world;
   d->rank = rank;
   d->n_total = n_total;

@@ -689,40 +689,6 @@ __global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __re
   }
 }
 
-// ------------------------------------------------------------------ integrate
-// ref:227-249, source text, no contraction: v += a dt; clamp |v| to max_speed; p += v dt
-__global__ __launch_bounds__(256) void integrate_kernel(float4* __restrict__ posm,
-                                                        float4* __restrict__ velid,
-                                                        const float4* __restrict__ acc,
-                                                        const float4* __restrict__ acc2, int n, float DT,
-                                                        float MAX_SPEED) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = posm[i];
-  float4 v = velid[i];
-  float4 a = acc[i];
-  if (acc2) {  // two-pass force of the domain-decomposed step: own pass + remote pass
-    const float4 b = acc2[i];
-    a.x += b.x; a.y += b.y; a.z += b.z;
-  }
-  float vx = v.x + a.x * DT;
-  float vy = v.y + a.y * DT;
-  float vz = v.z + a.z * DT;
-  const float speedSq = vx * vx + vy * vy + vz * vz;
-  if (speedSq > MAX_SPEED * MAX_SPEED) {
-    const float scale = MAX_SPEED / sqrtf(speedSq);
-    vx *= scale;
-    vy *= scale;
-    vz *= scale;
-  }
-  v.x = vx; v.y = vy; v.z = vz;
-  p.x += vx * DT;
-  p.y += vy * DT;
-  p.z += vz * DT;
-  posm[i] = p;
-  velid[i] = v;
-}
-
 // ------------------------------------------------------------------ pack / unpack
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ s, int n,
                                                    float4* __restrict__ posm, float4* __restrict__ velid) {
@@ -894,13 +860,6 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   else
     force_fast_kernel<0, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
                                                        c->p.eps2, mode, c->info, root, budget, group);
-  return hipGetLastError();
-}
-
-hipError_t bhk_integrate(bh_ctx* c) {
-  const int n = c->n;
-  integrate_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2, n,
-                                                           c->p.dt, c->p.max_speed);
   return hipGetLastError();
 }
 

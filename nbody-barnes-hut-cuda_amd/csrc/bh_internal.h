@@ -109,7 +109,8 @@ struct bh_ctx {
   // onesweep sort (bh_sort_onesweep.hip)
   u32* sw_hist;    // [8][256] global digit totals of every pass
   u64* sw_status;  // [passes][ntiles][256] look-back granules {tag|state|count}
-  u32* sw_ticket;  // [0..7] tile tickets of the passes (cleared at the end of every sort), [8] sort calls so far
+  u32* sw_ticket;  // [0..7] tile tickets of the passes (cleared at the end of every sort), [8] sort calls so far,
+                   // [9] finished blocks of pairs_kernel, [10] of integrate_kernel (cleared by their last block)
   u32 sort_calls;
   int sort_tiles;
   // splitter sort (bh_sort_onesweep.hip, bhk_sort_split)
@@ -123,6 +124,9 @@ struct bh_ctx {
   // bbox
   float* bbox_partial;  // [BH_BBOX_BLOCKS][6]
   float* bounds;        // [8]: min xyz, min+size xyz, s0, pad
+  float* bounds_next;   // [8]: the cube of the positions the last integrate wrote (valid iff bounds_next_ok)
+  float* ibox_rows;     // [n / 256 + 1][6] per-block min / max of the integrate kernel
+  bool bounds_next_ok;  // set by a step's integrate, cleared by anything else that writes positions
 
   // tree build temporaries
   signed char* d8;  // [n+1] leading octal digits shared by keys j-1, j; d8[0] = d8[n] = -1
@@ -132,7 +136,9 @@ struct bh_ctx {
   int* pn;        // [n] its child count (0: j represents no emitted cell)
   int* cb;        // [n] offset of the cell's child block inside its 1024-pair tile (exclusive scan of the
                   // even-rounded pn within the tile)
-  int* ttot;      // [2 * (n / 1024 + 2)] child entries per pair tile, then (large n only) their exclusive prefix
+  u32* blk_done;  // [2][n / 32768 + 4] block counters of bh_last_block: pairs_kernel, then (blk_done2) integrate_kernel
+  u32* blk_done2;
+  int* ttot;      // [2 * (n / 1024 + 2)] child entries per pair tile, then their exclusive prefix (tile bases)
   bh_node* rec;   // [rec_cap] tree records (canonical: ABI download, strict/counting kernels)
   bh_frec* frec;  // [BH_FREC_POOL] digests for the fast force kernel (written by COM, pair layout): tree records,
                   // then BH_BODY_DIGEST slots (used only for the bodies of unsplit multi-body cells)
@@ -178,11 +184,50 @@ struct bh_ctx {
 #define BH_BLOCK0 2  // first child block
 #define BH_FORCE_BLOCK_DEFAULT 64  // one wave per workgroup: a CU slot frees as soon as its wave retires (-2 % at 1M)
 #define BH_BBOX_BLOCKS 1024
+#define BH_INTEGRATE_TILE 4096  // bodies per integrate block (1024 threads x 4)
+#define BH_BLKDONE_STRIDE(n) ((size_t)(n) / 32768 + 4)
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
 #ifndef BH_SORT_TILE
 #define BH_SORT_TILE 4096  // keys per sort tile
 #endif
 #define BH_SORT_ITEMS (BH_SORT_TILE / 256)  // per thread in the 256-thread kernels
+
+// "Last block finishes the job" hand-off without a release fence.  On a multi-XCD part __threadfence() writes
+// back the XCD's whole L2 (measured: 3907 blocks doing one each took integrate_kernel from 14 to 150 us).
+// Instead the per-block results are stored write-through at agent scope (bh_publish_*), the block waits until
+// those stores are acknowledged (bh_published: then they are visible device-wide), only then counts itself
+// done with a relaxed atomic; the block that sees the full count reads the results with agent-scope loads
+// (bh_collect_*), which bypass the non-coherent caches.
+#ifdef __HIPCC__
+__device__ __forceinline__ void bh_publish_i32(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void bh_publish_f32(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void bh_published() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int bh_collect_i32(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float bh_collect_f32(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One thread of block b (of nb) calls this after bh_published(); true for exactly one block, the last.
+// Two-level count — blocks in groups of 32, cnt[1 + group], then cnt[0] over the groups — because returning
+// atomics on ONE address serialise at ~10 ns each (3907 blocks: +40 us).  The counters are left at zero.
+__device__ __forceinline__ bool bh_last_block(u32* cnt, int b, int nb) {
+  const int g = b >> 5;
+  const int gsize = min(32, nb - (g << 5));
+  if (__hip_atomic_fetch_add(cnt + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (u32)(gsize - 1))
+    return false;
+  __hip_atomic_store(cnt + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int ngroups = (nb + 31) >> 5;
+  if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (u32)(ngroups - 1))
+    return false;
+  __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+#endif
 
 // ---- launchers (each enqueues on c->stream and returns hipGetLastError()) ----
 hipError_t bhk_pack(bh_ctx* c);                       // stage_buf SoA -> posm/velid
@@ -202,7 +247,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream,
                           float4* acc);  // fast kernel from pool record `root`
 hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows);  // measurement: per-wave event counters of the fast walk
-hipError_t bhk_integrate(bh_ctx* c);
+hipError_t bhk_integrate(bh_ctx* c, bool with_bbox);
 void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 
 // device-wide scans (bh_scan.hip)

@@ -33,7 +33,7 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ void block_minmax(float mn[3], float mx[3], float* lds /* [4][6] */) {
+__device__ __forceinline__ void block_minmax(float mn[3], float mx[3], float* lds /* [waves][6] */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -49,13 +49,27 @@ __device__ __forceinline__ void block_minmax(float mn[3], float mx[3], float* ld
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int q = 1; q < 4; q++)
+    const int nw = (int)(blockDim.x >> 6);
+    for (int q = 1; q < nw; q++)
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         mn[k] = fminf(mn[k], lds[q * 6 + k]);
         mx[k] = fmaxf(mx[k], lds[q * 6 + 3 + k]);
       }
   }
+}
+
+// the cube of ref:148-154 from the folded min / max
+__device__ __forceinline__ void write_cube(const float mn[3], const float mx[3], float* __restrict__ bounds) {
+  const float size = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));  // ref:148
+  bounds[0] = mn[0];
+  bounds[1] = mn[1];
+  bounds[2] = mn[2];
+  bounds[3] = mn[0] + size;  // ref:152-154: cube anchored at the min corner
+  bounds[4] = mn[1] + size;
+  bounds[5] = mn[2] + size;
+  bounds[6] = fmaxf(bounds[3] - bounds[0], 1.0f);  // root edge s0, ref:55
+  bounds[7] = 0.0f;
 }
 
 __global__ __launch_bounds__(256) void bbox_partial_kernel(const float4* __restrict__ posm, int n,
@@ -98,16 +112,96 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict
     bounds[0] = mn[0]; bounds[1] = mn[1]; bounds[2] = mn[2];
     bounds[3] = mx[0]; bounds[4] = mx[1]; bounds[5] = mx[2];
   } else if (threadIdx.x == 0) {
-    const float size = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));  // ref:148
-    bounds[0] = mn[0];
-    bounds[1] = mn[1];
-    bounds[2] = mn[2];
-    bounds[3] = mn[0] + size;  // ref:152-154: cube anchored at the min corner
-    bounds[4] = mn[1] + size;
-    bounds[5] = mn[2] + size;
-    bounds[6] = fmaxf(bounds[3] - bounds[0], 1.0f);  // root edge s0, ref:55
-    bounds[7] = 0.0f;
+    write_cube(mn, mx, bounds);
   }
+}
+
+// ------------------------------------------------------------------ integrate (+ the next step's bbox)
+// ref:227-249, source text, no contraction: v += a dt; clamp |v| to max_speed; p += v dt.
+// BBOX: the kernel also folds the min/max of the positions it writes — exactly the input of the next step's
+// bounding cube (ref:134-156) — into one row per block, and the block that finishes last folds the rows into
+// `bounds_next`: a step that follows a step needs no bbox kernels.  min/max are exact, so the cube is the
+// same bit for bit.
+template <bool BBOX>
+__global__ __launch_bounds__(1024) void integrate_kernel(float4* __restrict__ posm,
+                                                         float4* __restrict__ velid,
+                                                         const float4* __restrict__ acc,
+                                                         const float4* __restrict__ acc2, int n, float DT,
+                                                         float MAX_SPEED, float* __restrict__ rows,
+                                                         u32* __restrict__ done_count,
+                                                         float* __restrict__ bounds_next) {
+  float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
+  float mx[3] = {-1e10f, -1e10f, -1e10f};
+  constexpr int kPer = BH_INTEGRATE_TILE / 1024;
+  float4 p[kPer], v[kPer], a[kPer];
+#pragma unroll
+  for (int r = 0; r < kPer; r++) {
+    const int i = blockIdx.x * BH_INTEGRATE_TILE + r * 1024 + (int)threadIdx.x;
+    if (i < n) {
+      p[r] = posm[i];
+      v[r] = velid[i];
+      a[r] = acc[i];
+      if (acc2) {  // two-pass force of the domain-decomposed step: own pass + remote pass
+        const float4 b = acc2[i];
+        a[r].x += b.x; a[r].y += b.y; a[r].z += b.z;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kPer; r++) {
+    const int i = blockIdx.x * BH_INTEGRATE_TILE + r * 1024 + (int)threadIdx.x;
+    if (i < n) {
+      float vx = v[r].x + a[r].x * DT;
+      float vy = v[r].y + a[r].y * DT;
+      float vz = v[r].z + a[r].z * DT;
+      const float speedSq = vx * vx + vy * vy + vz * vz;
+      if (speedSq > MAX_SPEED * MAX_SPEED) {
+        const float scale = MAX_SPEED / sqrtf(speedSq);
+        vx *= scale;
+        vy *= scale;
+        vz *= scale;
+      }
+      v[r].x = vx; v[r].y = vy; v[r].z = vz;
+      p[r].x += vx * DT;
+      p[r].y += vy * DT;
+      p[r].z += vz * DT;
+      posm[i] = p[r];
+      velid[i] = v[r];
+      if (BBOX) {
+        mn[0] = fminf(mn[0], p[r].x); mn[1] = fminf(mn[1], p[r].y); mn[2] = fminf(mn[2], p[r].z);
+        mx[0] = fmaxf(mx[0], p[r].x); mx[1] = fmaxf(mx[1], p[r].y); mx[2] = fmaxf(mx[2], p[r].z);
+      }
+    }
+  }
+  if (!BBOX) return;
+  __shared__ float lds[16 * 6];
+  __shared__ int s_last;
+  block_minmax(mn, mx, lds);
+  if (threadIdx.x == 0) {
+    float* o = rows + (size_t)blockIdx.x * 6;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      bh_publish_f32(o + q, mn[q]);
+      bh_publish_f32(o + 3 + q, mx[q]);
+    }
+    bh_published();  // (bh_internal.h: last-block hand-off without a fence)
+    s_last = bh_last_block(done_count, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float fn[3] = {1e10f, 1e10f, 1e10f};
+  float fx[3] = {-1e10f, -1e10f, -1e10f};
+  for (int r = threadIdx.x; r < (int)gridDim.x; r += blockDim.x) {
+    const float* o = rows + (size_t)r * 6;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      fn[q] = fminf(fn[q], bh_collect_f32(o + q));
+      fx[q] = fmaxf(fx[q], bh_collect_f32(o + 3 + q));
+    }
+  }
+  __syncthreads();  // lds is reused
+  block_minmax(fn, fx, lds);
+  if (threadIdx.x == 0) write_cube(fn, fx, bounds_next);
 }
 
 // ------------------------------------------------------------------ keys
@@ -308,7 +402,9 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
                                                     int cap, const u64* __restrict__ ksamp, int ns, int ss,
                                                     int* __restrict__ pa, int* __restrict__ pb,
                                                     int* __restrict__ pn, int* __restrict__ cb,
-                                                    int* __restrict__ ttot, bh_devinfo* __restrict__ info) {
+                                                    int* __restrict__ ttot, int tp_off,
+                                                    u32* __restrict__ done_count,
+                                                    bh_devinfo* __restrict__ info) {
   __shared__ u64 s_samp[kSampMax];
   __shared__ __attribute__((aligned(16))) int pnl[kPairTile];  // child counts of the tile's pairs
   __shared__ u64 m[kPairLevels][kPairWords];
@@ -434,12 +530,12 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       if (j0 + 1 < n) cb[j0 + 1] = ex + v0;
       if (j0 + 2 < n) cb[j0 + 2] = ex + v0 + v1;
     }
-    if (threadIdx.x == 255) ttot[blockIdx.x] = ex + sum;
+    if (threadIdx.x == 255) bh_publish_i32(ttot + blockIdx.x, ex + sum);
   }
   // tree statistics: reduce in LDS, then ONE pair of global atomics per block (a global atomic per
   // thread put ~31K same-address atomics in a row: 90 of this kernel's 116 us at 1M bodies).
   // Integer sums / maxima: order-independent.
-  __shared__ int s_cells, s_maxl;
+  __shared__ int s_cells, s_maxl, s_last;
   if (threadIdx.x == 0) {
     s_cells = 0;
     s_maxl = 0;
@@ -450,13 +546,46 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
     atomicMax(&s_maxl, maxl);
   }
   __syncthreads();
-  if (threadIdx.x == 0 && s_cells) {
-    atomicAdd(&info->n_internal, s_cells);
-    atomicMax(&info->max_level, s_maxl);
+  if (threadIdx.x == 0) {
+    if (s_cells) {
+      atomicAdd(&info->n_internal, s_cells);
+      atomicMax(&info->max_level, s_maxl);
+    }
+  }
+  // The block that finishes LAST turns the per-tile totals into tile bases (exclusive scan, <= n/1024 values)
+  // for emit_kernel (bh_internal.h: last-block hand-off without a fence).  Thread 255 published this tile's
+  // total above; it waits for that store's acknowledgement, then counts the block done.
+  if (threadIdx.x == 255) {
+    bh_published();
+    s_last = bh_last_block(done_count, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last) {
+    const int ntiles = (int)gridDim.x;
+    int* tpre = ttot + tp_off;
+    int carry = 0;
+    for (int c0 = 0; c0 < ntiles; c0 += 256) {
+      const int i = c0 + (int)threadIdx.x;
+      const int v = (i < ntiles) ? bh_collect_i32(ttot + i) : 0;
+      int incl = v;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const int u = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += u;
+      }
+      const int wv = threadIdx.x >> 6;
+      __syncthreads();
+      if (lane == 63) s_ws[wv] = incl;
+      __syncthreads();
+      int ex = carry + incl - v;
+      for (int q = 0; q < wv; q++) ex += s_ws[q];
+      if (i < ntiles) tpre[i] = ex;
+      carry += s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
+    }
+    if (threadIdx.x == 0) tpre[ntiles] = carry;
   }
 }
 
-// classify the child cell [c0,c1) of a cell at level L and fill the topology fields of its record
 // entry offset of the child block of the cell whose representative pair is j
 #define BH_CB(j) (tpre[(j) >> 10] + cb[j])
 static_assert(kPairTile == 1024, "BH_CB shifts by 10");
@@ -563,10 +692,8 @@ __device__ __forceinline__ bh_node pad_entry() {
   return r;
 }
 
-// LDS_SCAN: the block turns the per-tile totals of pairs_kernel into tile bases itself (exclusive scan of
-// ntiles <= kEmitScanMax values in LDS); otherwise ttot[tp_off ..] holds the bases already (large n).
-constexpr int kEmitScanMax = 4096;
-template <bool LDS_SCAN>
+// ttot[tp_off ..] = tile bases (exclusive scan of the per-tile child-entry totals, written by the last block of
+// pairs_kernel); tpre[ntiles] = all entries
 __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
                                                    const signed char* __restrict__ d, int n, int B, int D,
                                                    int cap, const u64* __restrict__ ksamp, int ns, int ss,
@@ -581,36 +708,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   __shared__ u64 s_samp[kSampMax];
   __shared__ u64 m[kPairLevels][kPairWords];
   __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
-  extern __shared__ int s_tpre[];  // LDS_SCAN: [ntiles + 1] tile bases
-  const int* tpre = ttot + tp_off;
-  if (LDS_SCAN) {
-    __shared__ int s_ws[4];
-    for (int q = threadIdx.x; q < ntiles; q += 256) s_tpre[q] = ttot[q];
-    __syncthreads();
-    const int per = (ntiles + 255) >> 8;
-    const int q0 = threadIdx.x * per, q1 = min(q0 + per, ntiles);
-    int sum = 0;
-    for (int q = q0; q < q1; q++) sum += s_tpre[q];
-    int incl = sum;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-      const int u = __shfl_up(incl, dd, 64);
-      if (lane >= dd) incl += u;
-    }
-    if (lane == 63) s_ws[wv] = incl;
-    __syncthreads();
-    int run = incl - sum;
-    for (int q = 0; q < wv; q++) run += s_ws[q];
-    for (int q = q0; q < q1; q++) {
-      const int v = s_tpre[q];
-      s_tpre[q] = run;
-      run += v;
-    }
-    if (threadIdx.x == 255) s_tpre[ntiles] = run;
-    tpre = s_tpre;
-    // (the barrier inside build_window orders these writes before the first use)
-  }
+  const int* __restrict__ tpre = ttot + tp_off;
   const int t0 = blockIdx.x * kPairTile;
   const int base = t0 - kPairTile;
   build_window(d, n, base, m, dl);
@@ -821,6 +919,22 @@ hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int str
   return hipGetLastError();
 }
 
+// with_bbox: also produce the next step's bounding cube in c->bounds_next (see integrate_kernel)
+hipError_t bhk_integrate(bh_ctx* c, bool with_bbox) {
+  const int n = c->n;
+  const int blocks = (n + BH_INTEGRATE_TILE - 1) / BH_INTEGRATE_TILE;
+  if (with_bbox)
+    integrate_kernel<true><<<blocks, 1024, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2, n,
+                                                           c->p.dt, c->p.max_speed, c->ibox_rows,
+                                                           c->blk_done2,
+                                                           c->bounds_next);
+  else
+    integrate_kernel<false><<<blocks, 1024, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2,
+                                                            n, c->p.dt, c->p.max_speed, nullptr, nullptr,
+                                                            nullptr);
+  return hipGetLastError();
+}
+
 hipError_t bhk_keys(bh_ctx* c) {
   if (bhk_sort_split_eligible(c)) return bhk_keys_split(c);  // keys + splitters + bucket counts in one kernel
   if (c->keys_split) {  // bucket counts of keys that no sort consumed: void them
@@ -846,21 +960,13 @@ hipError_t bhk_build(bh_ctx* c) {
   const int ns = (n + (1 << ss) - 1) >> ss;
   lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info);
   const int ntiles = (n + kPairTile - 1) / kPairTile;
+  const int tp_off = n / 1024 + 2;
   pairs_kernel<<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
-                                              c->pn, c->cb, c->ttot, c->info);
-  // child-block offsets = tile base + offset in the tile (cb[], written by pairs_kernel)
-  if (ntiles <= kEmitScanMax) {
-    emit_kernel<true><<<ntiles, 256, (size_t)(ntiles + 1) * sizeof(int), c->stream>>>(
-        k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, ntiles, 0,
-        c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
-  } else {
-    const int tp_off = n / 1024 + 2;
-    const hipError_t e = bhk_scan_i32(c, c->ttot, c->ttot + tp_off, ntiles, nullptr);
-    if (e != hipSuccess) return e;
-    emit_kernel<false><<<ntiles, 256, 0, c->stream>>>(
-        k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off,
-        c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
-  }
+                                              c->pn, c->cb, c->ttot, tp_off, c->blk_done, c->info);
+  // child-block offsets = tile base (ttot[tp_off ..]) + offset in the tile (cb[]), both written by pairs_kernel
+  emit_kernel<<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
+                                             c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds, c->rec, c->er_lo,
+                                             c->er_hi, c->rec_cap, c->info);
   return hipGetLastError();
 }
 
