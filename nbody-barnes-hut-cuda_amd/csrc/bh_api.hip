@@ -149,6 +149,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   size_t scan_n = N + 1;
   if ((size_t)256 * c->sort_tiles > scan_n) scan_n = (size_t)256 * c->sort_tiles;
   c->scan_tmp_bytes = bhk_scan_tmp_bytes((int)scan_n);
+  c->scan_cnt_off = bhk_scan_cnt_offset((int)scan_n);
 
   bool ok = true;
   ok = ok && dalloc(&c->posm[0], N) == hipSuccess && dalloc(&c->posm[1], N) == hipSuccess;
@@ -192,6 +193,8 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && hipHostMalloc((void**)&c->host_flags, sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc(&c->scan_tmp, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipMalloc(&c->scan_tmp2, c->scan_tmp_bytes) == hipSuccess;
+  ok = ok && hipMemset(c->scan_tmp, 0, c->scan_tmp_bytes) == hipSuccess;
+  ok = ok && hipMemset(c->scan_tmp2, 0, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_pscan, hipEventDisableTiming) == hipSuccess;

@@ -1087,6 +1087,8 @@ int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const flo
     BH_HIP(c, hipMemcpyAsync(c->stage_buf + k * N, src[k], nb, hipMemcpyHostToDevice, c->stream));
   BH_HIP(c, hipMemcpyAsync(c->vals[0], ids, N * 4, hipMemcpyHostToDevice, c->stream));
   c->cur = 0;
+  c->order_hint = false;  // caller order
+  c->bounds_next_ok = false;
   dd_pack_ids_kernel<<<(n_loc + 255) / 256, 256, 0, c->stream>>>(c->stage_buf, (const int*)c->vals[0], n_loc,
                                                                   c->posm[0], c->velid[0]);
   BH_HIP(c, hipGetLastError());
@@ -1131,7 +1133,7 @@ int bh_dd_migrate_pack(bh_ctx* c, void* send_x2, int limit) {
   bh_dd_state* d = c->dd;
   if (limit < 1 || limit > d->mig_cap) return BH_ERR_BAD_ARG;
   const int n = c->n;
-  BH_HIP(c, bhk_keys(c));
+  BH_HIP(c, bhk_keys(c, false));  // classification only: no sort follows
   const int blocks = (n + 255) / 256 > 0 ? (n + 255) / 256 : 1;
   dd_classify_kernel<<<blocks, 256, 0, c->stream>>>(c->keys[0], n, d->skeys, d->world - 1, d->rank, d->flag);
   BH_HIP(c, hipGetLastError());

@@ -151,6 +151,7 @@ struct bh_ctx {
 
   // scan scratch
   void* scan_tmp;
+  size_t scan_cnt_off;  // byte offset of the bh_last_block counters inside scan_tmp / scan_tmp2
   size_t scan_tmp_bytes;
   // side stream: bh_step runs the COM prefix scan here, concurrently with the tree build
   hipStream_t stream2;
@@ -235,7 +236,7 @@ hipError_t bhk_unpack(bh_ctx* c, int what);           // 0: pos+vel -> stage_buf
 hipError_t bhk_bbox(bh_ctx* c);
 hipError_t bhk_bbox_raw(bh_ctx* c, float* out6);  // local min/max only
 hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int stride_floats);
-hipError_t bhk_keys(bh_ctx* c);
+hipError_t bhk_keys(bh_ctx* c, bool for_sort = true);
 hipError_t bhk_sort(bh_ctx* c);                       // radix sort + gather
 hipError_t bhk_sort_onesweep(bh_ctx* c);              // radix implementation (bh_sort_onesweep.hip)
 bool bhk_sort_split_eligible(const bh_ctx* c);        // splitter sort: keys + bucket counts, then partition + local sort
@@ -256,3 +257,4 @@ hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out /* n+1 */, int n
 hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n, bool side);
 hipError_t bhk_com_records(bh_ctx* c);  // second half of bhk_com: records from the prefix sums
 size_t bhk_scan_tmp_bytes(int n);
+size_t bhk_scan_cnt_offset(int n);

@@ -1,4 +1,5 @@
-// bh_scan.hip — device-wide exclusive prefix sums (reduce-then-scan, 3 launches).
+// bh_scan.hip — device-wide exclusive prefix sums (reduce-then-scan, 2 launches: the block of the reduce
+// kernel that finishes last scans the tile sums — bh_last_block, bh_internal.h).
 //
 // Used by the octree build (cell counts -> cell ids, child counts -> child-block offsets)
 // and by the centre-of-mass stage (fp64 prefix of (m, m*x, m*y, m*z) over the Morton-sorted
@@ -22,6 +23,8 @@ struct OpI32 {
   static __device__ __forceinline__ T add(T a, T b) { return a + b; }
   static __device__ __forceinline__ T shfl_up(T v, int d) { return __shfl_up(v, d, 64); }
   static __device__ __forceinline__ T shfl(T v, int l) { return __shfl(v, l, 64); }
+  static __device__ __forceinline__ void publish(T* p, T v) { bh_publish_i32(p, v); }
+  static __device__ __forceinline__ T collect(const T* p) { return bh_collect_i32(p); }
 };
 struct OpD4 {
   typedef bh_d4 T;
@@ -35,6 +38,20 @@ struct OpD4 {
   }
   static __device__ __forceinline__ T shfl(T v, int l) {
     return bh_d4{__shfl(v.m, l, 64), __shfl(v.x, l, 64), __shfl(v.y, l, 64), __shfl(v.z, l, 64)};
+  }
+  static __device__ __forceinline__ void publish(T* p, T v) {
+    double* q = reinterpret_cast<double*>(p);
+    __hip_atomic_store(q + 0, v.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 2, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 3, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  static __device__ __forceinline__ T collect(const T* p) {
+    const double* q = reinterpret_cast<const double*>(p);
+    return bh_d4{__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                 __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                 __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                 __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
   }
 };
 
@@ -92,12 +109,15 @@ __device__ __forceinline__ typename Op::T block_exclusive(typename Op::T v, type
   return Op::add(wprefix, excl);
 }
 
+// tile sums; the block that finishes last turns them into the exclusive tile prefixes in place
+// (total -> tile_sums[ntiles])
 template <typename Op, typename Load>
 __global__ __launch_bounds__(kThreads) void scan_reduce_kernel(Load load, int n_static,
                                                                const int* __restrict__ n_dev,
-                                                               typename Op::T* __restrict__ tile_sums) {
+                                                               typename Op::T* tile_sums, u32* __restrict__ done) {
   typedef typename Op::T T;
   __shared__ T lds[kThreads / 64];
+  __shared__ int s_last;
   const int n = n_dev ? *n_dev : n_static;
   const int i0 = blockIdx.x * kTile + threadIdx.x * kItems;
   T s = Op::zero();
@@ -106,23 +126,22 @@ __global__ __launch_bounds__(kThreads) void scan_reduce_kernel(Load load, int n_
     if (i0 + k < n) s = Op::add(s, load(i0 + k));
   T tot;
   (void)block_exclusive<Op, kThreads>(s, lds, &tot);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-
-// single block: exclusive scan of the tile sums in place; total -> tile_sums[ntiles]
-template <typename Op>
-__global__ __launch_bounds__(1024) void scan_tiles_kernel(typename Op::T* __restrict__ tile_sums,
-                                                          int ntiles) {
-  typedef typename Op::T T;
-  __shared__ T lds[1024 / 64];
+  if (threadIdx.x == 0) {
+    Op::publish(tile_sums + blockIdx.x, tot);
+    bh_published();
+    s_last = bh_last_block(done, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int ntiles = (int)gridDim.x;
   T carry = Op::zero();
-  for (int c0 = 0; c0 < ntiles; c0 += 1024) {
+  for (int c0 = 0; c0 < ntiles; c0 += kThreads) {
     const int i = c0 + (int)threadIdx.x;
-    T v = (i < ntiles) ? tile_sums[i] : Op::zero();
-    T tot;
-    T ex = block_exclusive<Op, 1024>(v, lds, &tot);
+    T v = (i < ntiles) ? Op::collect(tile_sums + i) : Op::zero();
+    T t2;
+    T ex = block_exclusive<Op, kThreads>(v, lds, &t2);
     if (i < ntiles) tile_sums[i] = Op::add(carry, ex);
-    carry = Op::add(carry, tot);
+    carry = Op::add(carry, t2);
   }
   if (threadIdx.x == 0) tile_sums[ntiles] = carry;
 }
@@ -156,35 +175,42 @@ __global__ __launch_bounds__(kThreads) void scan_apply_kernel(Load load, int n_s
 }
 
 template <typename Op, typename Load>
-hipError_t run_scan(hipStream_t stream, void* tmp, Load load, typename Op::T* out, int n,
+hipError_t run_scan(hipStream_t stream, void* tmp, size_t cnt_off, Load load, typename Op::T* out, int n,
                     const int* n_dev) {
   typedef typename Op::T T;
   const int ntiles = (n + kTile - 1) / kTile;
   T* sums = reinterpret_cast<T*>(tmp);
-  scan_reduce_kernel<Op, Load><<<ntiles, kThreads, 0, stream>>>(load, n, n_dev, sums);
-  scan_tiles_kernel<Op><<<1, 1024, 0, stream>>>(sums, ntiles);
+  u32* done = reinterpret_cast<u32*>(reinterpret_cast<char*>(tmp) + cnt_off);  // zero between scans
+  scan_reduce_kernel<Op, Load><<<ntiles, kThreads, 0, stream>>>(load, n, n_dev, sums, done);
   scan_apply_kernel<Op, Load><<<ntiles, kThreads, 0, stream>>>(load, n, n_dev, sums, ntiles, out);
   return hipGetLastError();
 }
 
 }  // namespace
 
-size_t bhk_scan_tmp_bytes(int n) {
+// scratch of one scan over up to n elements: [ntiles + 2] tile sums (largest element type), then the block
+// counters of bh_last_block (must be zero at creation; every scan leaves them zero)
+size_t bhk_scan_cnt_offset(int n) {
   const size_t ntiles = ((size_t)n + kTile - 1) / kTile;
   return (ntiles + 2) * sizeof(bh_d4);
 }
+size_t bhk_scan_tmp_bytes(int n) {
+  const size_t ntiles = ((size_t)n + kTile - 1) / kTile;
+  // int32 scans run over up to 3n + 8 elements (record pool) in the same scratch: 4x the groups
+  return bhk_scan_cnt_offset(n) + (ntiles / 8 + 8) * sizeof(u32);
+}
 
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out, int n, const int* n_dev) {
-  return run_scan<OpI32>(c->stream, c->scan_tmp, LoadI32{in}, out, n, n_dev);
+  return run_scan<OpI32>(c->stream, c->scan_tmp, c->scan_cnt_off, LoadI32{in}, out, n, n_dev);
 }
 
 hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out, int n) {
-  return run_scan<OpI32>(c->stream, c->scan_tmp, LoadI32Even{in}, out, n, nullptr);
+  return run_scan<OpI32>(c->stream, c->scan_tmp, c->scan_cnt_off, LoadI32Even{in}, out, n, nullptr);
 }
 
 // side = true: run on the context's side stream with its own scratch (bh_step overlaps this scan,
 // which needs only the sorted bodies, with the tree build, which needs only the sorted keys)
 hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out, int n, bool side) {
-  return run_scan<OpD4>(side ? c->stream2 : c->stream, side ? c->scan_tmp2 : c->scan_tmp, LoadPM{posm}, out,
-                        n, nullptr);
+  return run_scan<OpD4>(side ? c->stream2 : c->stream, side ? c->scan_tmp2 : c->scan_tmp, c->scan_cnt_off,
+                        LoadPM{posm}, out, n, nullptr);
 }

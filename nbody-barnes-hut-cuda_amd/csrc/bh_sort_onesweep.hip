@@ -760,8 +760,8 @@ static int split_buckets(int n) {
 bool bhk_sort_split_eligible(const bh_ctx* c) {
   const int v = c->p.sort_variant;
   if (v != 0 && v != 3) return false;
-  if (c->dd || c->p.step_graph == 1) return false;
-  if (c->n > 256 * 6144) return false;
+  if (c->p.step_graph == 1) return false;  // the call parity of the bucket counters is not a graph constant
+  if (c->n > 256 * 6144) return false;     // (domain-decomposed contexts: n is the current local body count)
   return v == 3 || c->order_hint;
 }
 

@@ -935,8 +935,9 @@ hipError_t bhk_integrate(bh_ctx* c, bool with_bbox) {
   return hipGetLastError();
 }
 
-hipError_t bhk_keys(bh_ctx* c) {
-  if (bhk_sort_split_eligible(c)) return bhk_keys_split(c);  // keys + splitters + bucket counts in one kernel
+// for_sort: a sort follows (keys + splitters + bucket counts in one kernel when the splitter sort applies)
+hipError_t bhk_keys(bh_ctx* c, bool for_sort) {
+  if (for_sort && bhk_sort_split_eligible(c)) return bhk_keys_split(c);
   if (c->keys_split) {  // bucket counts of keys that no sort consumed: void them
     const hipError_t e = hipMemsetAsync(c->sp_count + 256 * (c->sp_par & 1), 0, 256 * sizeof(u32), c->stream);
     if (e != hipSuccess) return e;
