@@ -340,6 +340,14 @@ __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int
 // word, a short word scan, and clz / ctz / popcount.  Only cells that reach beyond the window
 // (about one pair per thousand) are deferred to phase 2: sample-seeded 16-ary searches on the keys,
 // 8 lanes per cell (key_lower_bound above).
+#ifdef BH_TREE_TRACE
+// design-study instrumentation (tools/tree_trace.py): 100 MHz wall-clock stamps per block
+__device__ unsigned long long g_tree_trace[2][8192][8];
+#define TT_STAMP(kern, k) \
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_tree_trace[kern][blockIdx.x][k] = wall_clock64();
+#else
+#define TT_STAMP(kern, k)
+#endif
 constexpr int kPairTile = 1024;
 constexpr int kPairWin = 3 * kPairTile;
 constexpr int kPairWords = kPairWin / 64;  // 48
@@ -367,6 +375,101 @@ __device__ __forceinline__ int count_between(const u64* row, int p, int q) {  //
   return c;
 }
 
+// Level masks of one window word: lane I of (lo, hi) <- ballot(d <= I - 1), I = 0 .. 22.  v_cmp into fixed SGPR
+// pairs, then v_writelane_b32 with an inline-constant lane select; six compares are issued before the first
+// write-lane of a group because a write-lane must not read an SGPR that the VALU wrote in the previous few
+// cycles (the assembler does not see hazards inside inline asm; back to back the masks came out wrong).
+__device__ __forceinline__ void mask_levels(int dv, u32& lo, u32& hi) {
+  asm volatile(
+      "v_cmp_ge_i32 s[20:21], -1, %2\n\t"
+      "v_cmp_ge_i32 s[22:23], 0, %2\n\t"
+      "v_cmp_ge_i32 s[24:25], 1, %2\n\t"
+      "v_cmp_ge_i32 s[26:27], 2, %2\n\t"
+      "v_cmp_ge_i32 s[28:29], 3, %2\n\t"
+      "v_cmp_ge_i32 s[30:31], 4, %2\n\t"
+      "v_writelane_b32 %0, s20, 0\n\t"
+      "v_writelane_b32 %1, s21, 0\n\t"
+      "v_writelane_b32 %0, s22, 1\n\t"
+      "v_writelane_b32 %1, s23, 1\n\t"
+      "v_writelane_b32 %0, s24, 2\n\t"
+      "v_writelane_b32 %1, s25, 2\n\t"
+      "v_writelane_b32 %0, s26, 3\n\t"
+      "v_writelane_b32 %1, s27, 3\n\t"
+      "v_writelane_b32 %0, s28, 4\n\t"
+      "v_writelane_b32 %1, s29, 4\n\t"
+      "v_writelane_b32 %0, s30, 5\n\t"
+      "v_writelane_b32 %1, s31, 5\n\t"
+      : "+v"(lo), "+v"(hi)
+      : "v"(dv)
+      : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+  asm volatile(
+      "v_cmp_ge_i32 s[20:21], 5, %2\n\t"
+      "v_cmp_ge_i32 s[22:23], 6, %2\n\t"
+      "v_cmp_ge_i32 s[24:25], 7, %2\n\t"
+      "v_cmp_ge_i32 s[26:27], 8, %2\n\t"
+      "v_cmp_ge_i32 s[28:29], 9, %2\n\t"
+      "v_cmp_ge_i32 s[30:31], 10, %2\n\t"
+      "v_writelane_b32 %0, s20, 6\n\t"
+      "v_writelane_b32 %1, s21, 6\n\t"
+      "v_writelane_b32 %0, s22, 7\n\t"
+      "v_writelane_b32 %1, s23, 7\n\t"
+      "v_writelane_b32 %0, s24, 8\n\t"
+      "v_writelane_b32 %1, s25, 8\n\t"
+      "v_writelane_b32 %0, s26, 9\n\t"
+      "v_writelane_b32 %1, s27, 9\n\t"
+      "v_writelane_b32 %0, s28, 10\n\t"
+      "v_writelane_b32 %1, s29, 10\n\t"
+      "v_writelane_b32 %0, s30, 11\n\t"
+      "v_writelane_b32 %1, s31, 11\n\t"
+      : "+v"(lo), "+v"(hi)
+      : "v"(dv)
+      : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+  asm volatile(
+      "v_cmp_ge_i32 s[20:21], 11, %2\n\t"
+      "v_cmp_ge_i32 s[22:23], 12, %2\n\t"
+      "v_cmp_ge_i32 s[24:25], 13, %2\n\t"
+      "v_cmp_ge_i32 s[26:27], 14, %2\n\t"
+      "v_cmp_ge_i32 s[28:29], 15, %2\n\t"
+      "v_cmp_ge_i32 s[30:31], 16, %2\n\t"
+      "v_writelane_b32 %0, s20, 12\n\t"
+      "v_writelane_b32 %1, s21, 12\n\t"
+      "v_writelane_b32 %0, s22, 13\n\t"
+      "v_writelane_b32 %1, s23, 13\n\t"
+      "v_writelane_b32 %0, s24, 14\n\t"
+      "v_writelane_b32 %1, s25, 14\n\t"
+      "v_writelane_b32 %0, s26, 15\n\t"
+      "v_writelane_b32 %1, s27, 15\n\t"
+      "v_writelane_b32 %0, s28, 16\n\t"
+      "v_writelane_b32 %1, s29, 16\n\t"
+      "v_writelane_b32 %0, s30, 17\n\t"
+      "v_writelane_b32 %1, s31, 17\n\t"
+      : "+v"(lo), "+v"(hi)
+      : "v"(dv)
+      : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+  asm volatile(
+      "v_cmp_ge_i32 s[20:21], 17, %2\n\t"
+      "v_cmp_ge_i32 s[22:23], 18, %2\n\t"
+      "v_cmp_ge_i32 s[24:25], 19, %2\n\t"
+      "v_cmp_ge_i32 s[26:27], 20, %2\n\t"
+      "v_cmp_ge_i32 s[28:29], 21, %2\n\t"
+      "s_nop 0\n\t"
+      "v_writelane_b32 %0, s20, 18\n\t"
+      "v_writelane_b32 %1, s21, 18\n\t"
+      "v_writelane_b32 %0, s22, 19\n\t"
+      "v_writelane_b32 %1, s23, 19\n\t"
+      "v_writelane_b32 %0, s24, 20\n\t"
+      "v_writelane_b32 %1, s25, 20\n\t"
+      "v_writelane_b32 %0, s26, 21\n\t"
+      "v_writelane_b32 %1, s27, 21\n\t"
+      "v_writelane_b32 %0, s28, 22\n\t"
+      "v_writelane_b32 %1, s29, 22\n\t"
+      : "+v"(lo), "+v"(hi)
+      : "v"(dv)
+      : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+}
+
+static_assert(kPairLevels == 23, "mask_levels writes exactly 23 levels");
+
 // fill the LDS window: dl[s] = d[base + s] (-1 outside [0, n]) and the per-level masks
 __device__ __forceinline__ void build_window(const signed char* __restrict__ d, int n, int base,
                                              u64 (*m)[kPairWords], signed char* dl) {
@@ -386,13 +489,13 @@ __device__ __forceinline__ void build_window(const signed char* __restrict__ d, 
     }
   }
   __syncthreads();
+  // level v's ballot goes into lane v + 1 of a register pair (v_writelane), then ONE store per word by lanes
+  // 0..22 — the lane-0 store per level (exec save / move / store / restore) was most of the window build
   for (int w = wv; w < kPairWords; w += 4) {
     const int dv = dl[w * 64 + lane];
-#pragma unroll
-    for (int v = -1; v < kPairLevels - 1; v++) {
-      const u64 bb = __ballot(dv <= v);
-      if (lane == 0) m[v + 1][w] = bb;
-    }
+    u32 lo = 0u, hi = 0u;
+    mask_levels(dv, lo, hi);
+    if (lane < kPairLevels) m[lane][w] = ((u64)hi << 32) | (u64)lo;
   }
   __syncthreads();
 }
@@ -412,7 +515,9 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   const int t0 = blockIdx.x * kPairTile;
   const int base = t0 - kPairTile;  // global position of window slot 0
   const int lane = threadIdx.x & 63;
+  TT_STAMP(0, 0)
   build_window(d, n, base, m, dl);
+  TT_STAMP(0, 1)
 
   __shared__ int wide[kPairTile];  // window slots of the pairs whose cell leaves the window
   __shared__ int nwide;
@@ -461,6 +566,10 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
     }
   }
   __syncthreads();
+  TT_STAMP(0, 2)
+#ifdef BH_TREE_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_tree_trace[0][blockIdx.x][6] = (unsigned long long)nwide;
+#endif
   // phase 2: wide cells by key search, 8 lanes per pair (lane v = octant v), all pairs of the
   // block in flight together so the block pays one dependent-load chain, not one per round
   {
@@ -501,6 +610,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       }
     }
   }
+  TT_STAMP(0, 3)
   // Child-block offsets: one contiguous block per cell, in pair order, every block starting at an even entry
   // (an odd block is followed by a padding entry).  The tile scans its own counts here and publishes its total;
   // emit_kernel turns the <= n/1024 totals into tile bases itself (no separate scan pass over n values).
@@ -555,6 +665,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   // The block that finishes LAST turns the per-tile totals into tile bases (exclusive scan, <= n/1024 values)
   // for emit_kernel (bh_internal.h: last-block hand-off without a fence).  Thread 255 published this tile's
   // total above; it waits for that store's acknowledgement, then counts the block done.
+  TT_STAMP(0, 4)
   if (threadIdx.x == 255) {
     bh_published();
     s_last = bh_last_block(done_count, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
@@ -711,58 +822,142 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   const int* __restrict__ tpre = ttot + tp_off;
   const int t0 = blockIdx.x * kPairTile;
   const int base = t0 - kPairTile;
+  TT_STAMP(1, 0)
   build_window(d, n, base, m, dl);
+  TT_STAMP(1, 1)
   __shared__ int wide[kPairTile];
   __shared__ int nwide;
   if (threadIdx.x == 0) nwide = 0;
   __syncthreads();
   const float s0 = bounds[6];
-#pragma unroll 1
-  for (int r = 0; r < kPairTile / 256; r++) {
-    const int p = kPairTile + r * 256 + (int)threadIdx.x;
-    const int j = base + p;
-    if (j >= n) break;
-    if (j == 0) {  // root record (ref:65-81 initRootKernel)
-      const int E = BH_BLOCK0 + tpre[ntiles];
-      info->n_entries = E;
-      if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
-      rec[0] = make_child(k, B, D, cap, s0, pn, cb, tpre, 0, n, 0);
-      er_lo[0] = 0;
-      er_hi[0] = n;
-      rec[1] = pad_entry();  // child blocks start at even entries (BH_BLOCK0)
-      er_lo[1] = er_hi[1] = 0;
-      continue;
+  if (t0 == 0 && threadIdx.x == 0) {  // root record (ref:65-81 initRootKernel)
+    const int E = BH_BLOCK0 + tpre[ntiles];
+    info->n_entries = E;
+    if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
+    rec[0] = make_child(k, B, D, cap, s0, pn, cb, tpre, 0, n, 0);
+    er_lo[0] = 0;
+    er_hi[0] = n;
+    rec[1] = pad_entry();  // child blocks start at even entries (BH_BLOCK0)
+    er_lo[1] = er_hi[1] = 0;
+  }
+  // The thread's four pairs in four passes, so that the global loads of a pass are all in flight together
+  // (one round after the other paid two dependent load latencies per round: ~16 of this phase's 25 us).
+  constexpr int kR = kPairTile / 256;
+  int nc_[kR], e_[kR], a_[kR], b_[kR], jp_[kR], ord_[kR];
+#pragma unroll
+  for (int r = 0; r < kR; r++) {
+    const int j = t0 + r * 256 + (int)threadIdx.x;
+    nc_[r] = 0;
+    e_[r] = a_[r] = b_[r] = 0;
+    jp_[r] = -1;
+    ord_[r] = 0;
+    if (j > 0 && j < n) {
+      nc_[r] = pn[j];
+      e_[r] = BH_BLOCK0 + BH_CB(j);
+      a_[r] = pa[j];  // (defined only where nc > 0; unused otherwise)
+      b_[r] = pb[j];
     }
-    const int nc = pn[j];
+  }
+#pragma unroll
+  for (int r = 0; r < kR; r++) {
+    const int p = kPairTile + r * 256 + (int)threadIdx.x;
+    const int nc = nc_[r], e = e_[r], a = a_[r], b = b_[r];
     if (nc == 0) continue;
-    int e = BH_BLOCK0 + BH_CB(j);
-    if (e + nc > rec_cap) continue;  // cannot happen (records <= 2n); flagged by thread 0 if it did
-    const int a = pa[j], b = pb[j];
+    if (nc > 8 || e + nc > rec_cap) continue;  // cannot happen (records <= 2n); flagged by thread 0 if it did
     const int L = dl[p];
     const int qa = a - base, qb = b - base;
-    if (qa < 0 || qb >= kPairWin) {  // cell wider than the window: phase 2
+    // A cell of more than kPairTile bodies is "wide": its thread emits ALL its children in phase 2 (key
+    // searches).  The rule depends on the cell alone, so the threads of its children — possibly in other blocks
+    // — reach the same verdict.  A narrow cell lies inside this block's window: |a - j|, |b - j| <= kPairTile.
+    if (b - a > kPairTile) {
       wide[atomicAdd(&nwide, 1)] = p;
       continue;
     }
-    // children = runs between the positions with d == L in (qa, qb); p is the first of them
-    const u64* mle = m[L + 1];
-    int c0 = qa, c1 = p;
-    for (;;) {
-      rec[e] = make_child_win(m, base, B, D, cap, s0, pn, cb, tpre, c0, c1, L);
-      er_lo[e] = base + c0;
-      er_hi[e] = base + c1;
-      e++;
-      if (c1 >= qb) break;
-      c0 = c1;
-      const int nx = next_set(mle, c0);
-      c1 = (nx < 0 || nx > qb) ? qb : nx;
+    // (A) the cell's LEAF children: runs between the positions with d == L in (qa, qb), p being the first.
+    // A child that is itself an emitted cell is skipped here — (B) below: that cell's own thread writes it,
+    // from its own child count and block offset.  (Resolving every internal child's branching level and
+    // representative pair from the parent — a level-by-level mask search per child, the wave waiting for its
+    // slowest lane — was most of this kernel's time.)
+    {
+      const u64* mle = m[L + 1];
+      int c0 = qa, c1 = p;
+#pragma unroll 1
+      for (int q = 0; q < nc; q++) {
+        const int cnt = c1 - c0;
+        bool leaf = true;
+        bh_node r;
+        r.x = r.y = r.z = r.m = 0.0f;
+        r.first = base + c0;
+        r.count = cnt;
+        if (cnt == 1) {
+          r.kind = BH_KIND_BODY;
+          r.s = -1.0f;  // negative edge: accepted by every theta >= 0
+        } else if (cnt <= cap) {
+          r.kind = BH_KIND_MULTI;
+          r.s = ldexpf(s0, -(L + 1));
+        } else {
+          // branches above the depth cap?  (a position with d < D strictly inside the child)
+          const int nd = (D >= 1) ? next_set(m[D], c0) : -1;
+          leaf = !(nd >= 0 && nd < c1);
+          r.kind = BH_KIND_MULTI;  // never branches above the depth cap: unsplit multi-body cell at level D
+          r.s = ldexpf(s0, -D);
+        }
+        if (leaf) {
+          rec[e + q] = r;
+          er_lo[e + q] = base + c0;
+          er_hi[e + q] = base + c1;
+        }
+        c0 = c1;
+        if (c1 < qb) {
+          const int nx = next_set(mle, c0);
+          c1 = (nx < 0 || nx > qb) ? qb : nx;
+        }
+      }
+      if (nc & 1) {  // a block of an odd number of children is followed by one padding entry
+        rec[e + nc] = pad_entry();
+        er_lo[e + nc] = er_hi[e + nc] = 0;
+      }
     }
-    if (nc & 1) {  // a block of an odd number of children is followed by one padding entry
-      rec[e] = pad_entry();
-      er_lo[e] = er_hi[e] = 0;
+    // (B) this cell's own record goes into its parent's child block.  Parent = the smallest branching cell
+    // around [a, b): level Lp = max(d[a], d[b]); it starts at the nearest position <= a with d < Lp, ends at
+    // the nearest >= b with d < Lp; its children are delimited by its positions with d == Lp, so this cell's
+    // ordinal is the number of those in (start, a], and the parent's representative pair is the first of them.
+    if (a == 0 && b == n) continue;  // the root cell's record is entry 0
+    {
+      const int da = dl[qa], db = dl[qb];
+      const int Lp = max(da, db);
+      const u64* mlt = m[Lp];       // d <  Lp
+      const u64* mleq = m[Lp + 1];  // d <= Lp
+      const int ps = (da < Lp) ? qa : prev_set(mlt, qa);
+      const int pe = (db < Lp) ? qb : next_set(mlt, qb);
+      if (ps < 0 || pe < 0 || pe - ps > kPairTile) continue;  // wide parent: it emits this record itself
+      ord_[r] = (qa == ps) ? 0 : 1 + count_between(mleq, ps, qa);
+      jp_[r] = base + next_set(mleq, ps);  // the parent's representative pair
+    }
+  }
+  int ep_[kR];
+#pragma unroll
+  for (int r = 0; r < kR; r++) ep_[r] = (jp_[r] >= 0) ? BH_BLOCK0 + BH_CB(jp_[r]) + ord_[r] : rec_cap;
+#pragma unroll
+  for (int r = 0; r < kR; r++) {
+    if (ep_[r] < rec_cap) {
+      const int p = kPairTile + r * 256 + (int)threadIdx.x;
+      bh_node rr;
+      rr.x = rr.y = rr.z = rr.m = 0.0f;
+      rr.s = ldexpf(s0, -(int)dl[p]);
+      rr.first = e_[r];
+      rr.count = nc_[r];
+      rr.kind = BH_KIND_INTERNAL;
+      rec[ep_[r]] = rr;
+      er_lo[ep_[r]] = a_[r];
+      er_hi[ep_[r]] = b_[r];
     }
   }
   __syncthreads();
+  TT_STAMP(1, 2)
+#ifdef BH_TREE_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_tree_trace[1][blockIdx.x][6] = (unsigned long long)nwide;
+#endif
   // phase 2: wide cells, 8 lanes per cell, lane v emits the child in octant v (if non-empty)
   {
     const int lane = threadIdx.x & 63, sub = threadIdx.x & 7;
@@ -802,6 +997,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       }
     }
   }
+  TT_STAMP(1, 3)
 }
 
 // ------------------------------------------------------------------ COM
@@ -951,6 +1147,12 @@ hipError_t bhk_keys(bh_ctx* c, bool for_sort) {
     keys_kernel<21><<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, c->keys[0]);
   return hipGetLastError();
 }
+
+#ifdef BH_TREE_TRACE
+extern "C" int bh_debug_tree_trace(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tree_trace), sizeof(g_tree_trace));
+}
+#endif
 
 hipError_t bhk_build(bh_ctx* c) {
   const int n = c->n;
