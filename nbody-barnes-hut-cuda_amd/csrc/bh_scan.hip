@@ -135,12 +135,24 @@ __global__ __launch_bounds__(kThreads) void scan_reduce_kernel(Load load, int n_
   if (!s_last) return;
   const int ntiles = (int)gridDim.x;
   T carry = Op::zero();
-  for (int c0 = 0; c0 < ntiles; c0 += kThreads) {
-    const int i = c0 + (int)threadIdx.x;
-    T v = (i < ntiles) ? Op::collect(tile_sums + i) : Op::zero();
+  // a serial tail of the kernel: four tile sums per thread, loaded together (one agent-scope round trip per
+  // 1024 tiles), summed in registers, one block scan
+  constexpr int kPer = 4;
+  for (int c0 = 0; c0 < ntiles; c0 += kThreads * kPer) {
+    const int i0 = c0 + (int)threadIdx.x * kPer;
+    T v[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; q++) v[q] = (i0 + q < ntiles) ? Op::collect(tile_sums + i0 + q) : Op::zero();
+    T sum = Op::zero();
+#pragma unroll
+    for (int q = 0; q < kPer; q++) sum = Op::add(sum, v[q]);
     T t2;
-    T ex = block_exclusive<Op, kThreads>(v, lds, &t2);
-    if (i < ntiles) tile_sums[i] = Op::add(carry, ex);
+    T run = Op::add(carry, block_exclusive<Op, kThreads>(sum, lds, &t2));
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+      if (i0 + q < ntiles) tile_sums[i0 + q] = run;
+      run = Op::add(run, v[q]);
+    }
     carry = Op::add(carry, t2);
   }
   if (threadIdx.x == 0) tile_sums[ntiles] = carry;

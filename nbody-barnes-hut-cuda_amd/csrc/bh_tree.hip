@@ -570,34 +570,32 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
 #ifdef BH_TREE_TRACE
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_tree_trace[0][blockIdx.x][6] = (unsigned long long)nwide;
 #endif
-  // phase 2: wide cells by key search, 8 lanes per pair (lane v = octant v), all pairs of the
-  // block in flight together so the block pays one dependent-load chain, not one per round
+  // phase 2: wide cells by key search, 16 lanes per pair: lane v = 0..8 finds the first key whose (L+1)-digit
+  // prefix is >= pj*8 + v — v = 0 is the cell's start a, v = 8 its end b, 1..7 the octant boundaries — so all
+  // nine searches of a pair (and all pairs of the block) run concurrently: one dependent-load chain instead of
+  // three (start, then end, then octants: 17-27 us of the slowest blocks' 48).
   {
-    const int sub = threadIdx.x & 7;
+    const int sub = threadIdx.x & 15;
     const int nw = nwide;
     if (nw > 0) {  // block-uniform: stage the key samples for the bisection seeds
       for (int s = threadIdx.x; s < ns; s += 256) s_samp[s] = ksamp[s];
     }
     __syncthreads();
-    for (int idx = threadIdx.x >> 3; idx < nw; idx += 32) {
+    for (int idx = threadIdx.x >> 4; idx < nw; idx += 16) {
       const int p = wide[idx];
       const int j = base + p;
       const int L = dl[p];
       const int sh = 3 * (B - L), dsh = 3 * (B - 1 - L);
       const u64 pj = key_prefix(k[j], sh);
-      const int a = key_lower_bound(k, n, s_samp, ns, ss, sh, pj);
-      int nc = 0, b = 0;
-      if (((k[j - 1] >> dsh) & 7ull) == ((k[a] >> dsh) & 7ull)) {  // j is the first child boundary
-        b = key_lower_bound(k, n, s_samp, ns, ss, sh, pj + 1ull);
-        if (b - a > cap) {
-          // lower bound of digit >= sub inside the cell = first key with (L+1)-digit prefix >= pj*8+sub
-          const int l = (sub == 0) ? a : key_lower_bound(k, n, s_samp, ns, ss, dsh, (pj << 3) | (u64)sub);
-          int nxt = __shfl_down(l, 1, 8);
-          if (sub == 7) nxt = b;
-          const u64 bal = __ballot(nxt > l);
-          nc = __popcll((bal >> (lane & ~7)) & 0xffull);
-        }
-      }
+      const u64 kjm = k[j - 1];
+      const int l = (sub <= 8) ? key_lower_bound(k, n, s_samp, ns, ss, dsh, (pj << 3) + (u64)sub) : 0;
+      const int a = __shfl(l, 0, 16), b = __shfl(l, 8, 16);
+      const int nxt = __shfl_down(l, 1, 16);
+      const u64 bal = __ballot(sub < 8 && nxt > l);
+      int nc = 0;
+      // j is the cell's FIRST child boundary iff key j-1 lies in the cell's first non-empty octant
+      if (((kjm >> dsh) & 7ull) == ((k[a] >> dsh) & 7ull) && b - a > cap)
+        nc = __popcll((bal >> (lane & ~15)) & 0xffull);
       if (sub == 0) {
         pn[j] = nc;
         pnl[p - kPairTile] = nc;
@@ -675,10 +673,17 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
     const int ntiles = (int)gridDim.x;
     int* tpre = ttot + tp_off;
     int carry = 0;
-    for (int c0 = 0; c0 < ntiles; c0 += 256) {
-      const int i = c0 + (int)threadIdx.x;
-      const int v = (i < ntiles) ? bh_collect_i32(ttot + i) : 0;
-      int incl = v;
+    // this is a serial tail of the kernel: eight totals per thread, loaded together (one agent-scope round trip
+    // per 2048 tiles), summed in registers, one block scan
+    for (int c0 = 0; c0 < ntiles; c0 += 256 * 8) {
+      const int i0 = c0 + (int)threadIdx.x * 8;
+      int v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = (i0 + q < ntiles) ? bh_collect_i32(ttot + i0 + q) : 0;
+      int sum = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) sum += v[q];
+      int incl = sum;
 #pragma unroll
       for (int dd = 1; dd < 64; dd <<= 1) {
         const int u = __shfl_up(incl, dd, 64);
@@ -688,9 +693,13 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       __syncthreads();
       if (lane == 63) s_ws[wv] = incl;
       __syncthreads();
-      int ex = carry + incl - v;
-      for (int q = 0; q < wv; q++) ex += s_ws[q];
-      if (i < ntiles) tpre[i] = ex;
+      int run = carry + incl - sum;
+      for (int q = 0; q < wv; q++) run += s_ws[q];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (i0 + q < ntiles) tpre[i0 + q] = run;
+        run += v[q];
+      }
       carry += s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
     }
     if (threadIdx.x == 0) tpre[ntiles] = carry;
