@@ -377,6 +377,67 @@ def test_steps_end_to_end(pkg, orc, n, steps):
     o.close()
 
 
+def _state(e):
+    return np.stack(e.download(), 1).tobytes(), e.download_order().tobytes()
+
+
+def test_step_shortcuts_survive_uploads_and_stage_calls(pkg):
+    """bh_step takes two shortcuts from the previous step — the bounding cube folded by its integrate kernel and
+    the splitter sort that relies on the stored key order — and both must be dropped whenever something else
+    wrote the bodies.  Every mixed sequence below must end bit-identical to the same physics on a context that
+    never takes a shortcut (radix sort pinned, one stage call at a time)."""
+    n = 50000
+    ic1 = pkg.plummer(n, seed=1)
+    ic2 = special_ics("outlier", n, np.random.default_rng(2))
+
+    def stages(e, k):
+        for _ in range(k):
+            e.bbox(); e.morton(); e.sort(); e.build(); e.com(); e.force(); e.integrate()
+
+    ref = _engine(pkg, ic1, sort_variant=2)
+    stages(ref, 3)
+    ref.upload(*ic2)
+    stages(ref, 4)
+    want = _state(ref)
+    ref.close()
+
+    # (a) steps, upload in the middle (different cube, caller order), steps
+    e = _engine(pkg, ic1)
+    e.step(3)
+    e.upload(*ic2)
+    e.step(4)
+    assert _state(e) == want
+    assert e.stats().status_flags == 0
+    e.close()
+    # (b) steps and single-stage calls interleaved; morton twice before a sort; a bbox the step does not need
+    e = _engine(pkg, ic1)
+    e.step(1)
+    stages(e, 1)
+    e.bbox(); e.morton(); e.bbox(); e.morton(); e.sort(); e.build(); e.com(); e.force(); e.integrate()
+    e.upload(*ic2)
+    stages(e, 1)
+    e.step(2)
+    e.bbox()
+    e.step(1)
+    assert _state(e) == want
+    assert e.stats().status_flags == 0
+    e.close()
+
+
+def test_step_cube_from_integrate_is_the_bbox_cube(pkg, orc):
+    """the cube a step takes from the previous step's integrate kernel == bh_bbox of the same positions"""
+    ic = pkg.plummer(70001, seed=9)
+    e = _engine(pkg, ic)
+    for _ in range(3):
+        e.step(1)
+        x, y, z = e.download()[:3]
+        want = orc.bbox(x, y, z)
+        e.step(1)                      # uses the folded cube; the tree it leaves was built inside it
+        used = e.download_bounds()
+        assert np.array_equal(used, want)
+    e.close()
+
+
 def test_stage_order_errors(pkg):
     ic = pkg.plummer(100, seed=1)
     e = pkg.Engine(100)
