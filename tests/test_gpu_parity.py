@@ -424,6 +424,25 @@ def test_step_shortcuts_survive_uploads_and_stage_calls(pkg):
     e.close()
 
 
+def test_step_graph_replay_matches_plain_launches(pkg):
+    """bh_params.step_graph = 1: bh_step captured once per body-array parity and replayed as a HIP graph (radix
+    sort and explicit bbox kernels: every kernel argument of a step is then constant) == plain launches, bit for
+    bit, over 7 steps and across an upload"""
+    n = 30000
+    ic1 = pkg.plummer(n, seed=4)
+    ic2 = pkg.plummer(n, seed=5)
+    out = []
+    for g in (0, 1):
+        e = _engine(pkg, ic1, step_graph=g)
+        e.step(4)
+        e.upload(*ic2)
+        e.step(3)
+        out.append(_state(e))
+        assert e.stats().status_flags == 0
+        e.close()
+    assert out[0] == out[1]
+
+
 def test_step_cube_from_integrate_is_the_bbox_cube(pkg, orc):
     """the cube a step takes from the previous step's integrate kernel == bh_bbox of the same positions"""
     ic = pkg.plummer(70001, seed=9)
