@@ -349,7 +349,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{n_total // world:,} bodies per GPU ({n_total:,} total), Plummer sphere a=400 seed {args.seed}, "
-                            f"theta={args.theta}, G=0.5 eps2=50 dt=0.02, fp32, leaf_cap=1, 63-bit keys "
+                            f"theta={args.theta}, G=0.5 eps2=50 dt=0.02, fp32, leaf_cap=1, 63-bit keys in Hilbert order "
                             "(BASELINE.json configs[2]; x8 = configs[3])",
                 "n_total": n_total,
                 "parallelism": "1 GPU" if not multi else (

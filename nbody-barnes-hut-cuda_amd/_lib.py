@@ -20,7 +20,8 @@ class BhParams(C.Structure):
         ("leaf_cap", C.c_int32), ("max_depth", C.c_int32), ("key_bits", C.c_int32),
         ("strict_fp", C.c_int32), ("force_variant", C.c_int32), ("xcd_mode", C.c_int32),
         ("sort_variant", C.c_int32), ("literal_force", C.c_int32), ("force_block", C.c_int32),
-        ("step_graph", C.c_int32), ("force_group", C.c_int32),
+        ("step_graph", C.c_int32), ("force_group", C.c_int32), ("key_curve", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -50,6 +50,7 @@ int bh_default_params(bh_params* p) {
   p->max_depth = 21;
   p->key_bits = 63;
   p->strict_fp = 0;
+  p->key_curve = 1;  // Hilbert order
   return BH_OK;
 }
 
@@ -111,8 +112,10 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   if (n < 1 || n > (1 << 30) / 2) return BH_ERR_BAD_ARG;
   if (p.key_bits != 63 && p.key_bits != 30) return BH_ERR_BAD_ARG;
   if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0 ||
-      p.force_variant < 0 || p.force_variant > 1 || p.sort_variant < 0 || p.sort_variant > 3)
+      p.force_variant < 0 || p.force_variant > 1 || p.sort_variant < 0 || p.sort_variant > 3 ||
+      p.key_curve < 0 || p.key_curve > 1)
     return BH_ERR_BAD_ARG;
+  if (p.key_bits == 30) p.key_curve = 0;  // the reference-literal 30-bit code is a Morton code
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BH_ERR_NO_DEVICE;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void dd_x1_tail_kernel(float* __restrict__ sen
 // keys of all samples under the new cube, bitonic sort, equal-count quantiles -> splitter keys
 __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict__ g, int world, int xf,
                                                         int samp_cap, const float* __restrict__ bounds,
-                                                        u64* __restrict__ skeys) {
+                                                        int curve, u64* __restrict__ skeys) {
   __shared__ u64 k[kSampTotal];
   __shared__ int nvalid;
   const int tid = threadIdx.x;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
     if (r < world) {
       const float4 p = reinterpret_cast<const float4*>(g + (size_t)r * xf + 8)[t];
       if (p.w > 0.5f) {
-        key = morton_key<kB>(p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
+        key = body_key<kB>(curve, p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
         mine++;
       }
     }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void dd_nloc_init_kernel(const float4* __restri
 // body count after this round (block-reduced: a global atomic per thread serialises)
 __global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __restrict__ g, int world,
                                                              int limit, size_t f4,
-                                                             const float* __restrict__ bounds,
+                                                             const float* __restrict__ bounds, int curve,
                                                              const u64* __restrict__ skeys, int me,
                                                              int* __restrict__ flag2, int* __restrict__ nloc) {
   __shared__ u64 sk[64];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __res
     int f = 0;
     if (k < ne) {
       const float4 p = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
-      const u64 key = morton_key<kB>(p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
+      const u64 key = body_key<kB>(curve, p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
       const int o = owner_of(key, sk, nsplit);
       atomicAdd(&cnt[o], 1);
       f = (o == me && q != me) ? 1 : 0;
@@ -344,8 +344,9 @@ __global__ __launch_bounds__(256) void dd_spine_kernel(const bh_node* __restrict
 __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
     const int* __restrict__ piece_tmp, const int* ddi, int* ddi_w, const bh_node* __restrict__ rec,
     const int* __restrict__ er_lo, const int* __restrict__ er_hi, const u64* __restrict__ keys,
-    const bh_d4* __restrict__ P, const float4* __restrict__ posm, const float* __restrict__ bounds, int me,
-    int n_loc, bh_dd_piece* __restrict__ out, int* __restrict__ piece_idx, bh_devinfo* __restrict__ info) {
+    const bh_d4* __restrict__ P, const float4* __restrict__ posm, const float* __restrict__ bounds, int curve,
+    int me, int n_loc, bh_dd_piece* __restrict__ out, int* __restrict__ piece_idx,
+    bh_devinfo* __restrict__ info) {
   __shared__ int lo[BH_DD_PIECE_CAP], idx[BH_DD_PIECE_CAP];
   const int found = ddi[0];
   const int np = min(found, BH_DD_PIECE_CAP);
@@ -390,9 +391,13 @@ __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
     d.sm = p1.m - p0.m; d.sx = p1.x - p0.x; d.sy = p1.y - p0.y; d.sz = p1.z - p0.z;
     // box of the compressed cell: the Lb leading digits its bodies share
     const int Lb = common_digits(keys[a], keys[b - 1], kB);
-    const int sh = 3 * (kB - Lb);
-    const u64 kp = (sh >= 63) ? 0ull : ((keys[a] >> sh) << sh);
-    const u32 ix = compact_bits21(kp >> 2), iy = compact_bits21(kp >> 1), iz = compact_bits21(kp);
+    // cell coordinates of any body of the cell (the key de-interleaved, and for the Hilbert order run back
+    // through the curve), low 21 - Lb bits cleared = the cell's minimum corner
+    const u64 ka = keys[a];
+    u32 ix = compact_bits21(ka >> 2), iy = compact_bits21(ka >> 1), iz = compact_bits21(ka);
+    if (curve == 1) hilbert_transpose_to_axes(ix, iy, iz);
+    const u32 keep = (Lb <= 0) ? 0u : ~((1u << (kB - Lb)) - 1u);
+    ix &= keep; iy &= keep; iz &= keep;
     d.bx = bounds[0] + (float)ix / 2097152.0f * size;
     d.by = bounds[1] + (float)iy / 2097152.0f * size;
     d.bz = bounds[2] + (float)iz / 2097152.0f * size;
@@ -1120,7 +1125,7 @@ int bh_dd_cube_apply(bh_ctx* c, const void* gathered_x1) {
   const int xf = x1_floats(d->world);
   BH_HIP(c, bhk_bounds_from_rows(c, (const float*)gathered_x1, d->world, xf));
   dd_split_kernel<<<1, 1024, 0, c->stream>>>((const float*)gathered_x1, d->world, xf, d->samp_cap, c->bounds,
-                                             d->skeys);
+                                             c->p.key_curve, d->skeys);
   BH_HIP(c, hipGetLastError());
   c->stage = BH_ST_UPLOADED | BH_ST_BBOX;
   c->ever |= BH_ST_BBOX;
@@ -1156,8 +1161,9 @@ int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_lo
   const int slots = d->world * limit;
   const int n_cap = (c->rec_cap - 8) / 3;
   dd_nloc_init_kernel<<<1, 64, 0, c->stream>>>(g, d->world, f4, d->nloc);
-  dd_absorb_flag_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, c->bounds, d->skeys,
-                                                                    d->rank, d->flag, d->nloc);
+  dd_absorb_flag_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, c->bounds,
+                                                                    c->p.key_curve, d->skeys, d->rank, d->flag,
+                                                                    d->nloc);
   BH_HIP(c, hipGetLastError());
   BH_HIP(c, bhk_scan_i32(c, d->flag, d->fpos, slots, nullptr));
   dd_absorb_copy_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, d->rank, d->flag,
@@ -1193,8 +1199,8 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
                                                                    c->n, d->piece_tmp, d->ddi);
   dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, d->ddi, c->rec, c->er_lo, c->er_hi,
                                                            c->keys[c->key_buf], c->P, c->posm[c->cur], c->bounds,
-                                                           d->rank, c->n, (bh_dd_piece*)send_x3, d->piece_idx,
-                                                           c->info);
+                                                           c->p.key_curve, d->rank, c->n, (bh_dd_piece*)send_x3,
+                                                           d->piece_idx, c->info);
   BH_HIP(c, hipGetLastError());
   c->stage |= BH_ST_MORTON | BH_ST_SORT | BH_ST_BUILD | BH_ST_COM;
   c->ever |= BH_ST_MORTON | BH_ST_SORT | BH_ST_BUILD | BH_ST_COM;

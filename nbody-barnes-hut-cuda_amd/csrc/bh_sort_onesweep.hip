@@ -429,7 +429,8 @@ constexpr int kKsThreads = 1024;  // x 4 keys: 4 waves per SIMD hide the LDS rou
 template <int B>
 __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __restrict__ posm,
                                                                const float* __restrict__ bounds, int n, int nb,
-                                                               float nb_over_n, u64* __restrict__ keys,
+                                                               int curve, float nb_over_n,
+                                                               u64* __restrict__ keys,
                                                                u64* __restrict__ splitters,
                                                                u32* __restrict__ bcount) {
   __shared__ u64 raw[256];
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
     k[r] = 0ull;
     if (i < n) {
       const float4 q = posm[i];
-      k[r] = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
+      k[r] = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
       keys[i] = k[r];
     }
   }
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
   u64 sk = ~0ull;
   if (tid < nb - 1) {
     const float4 q = posm[(int)(((u64)(tid + 1) * (u64)n) / (u64)nb)];
-    sk = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
+    sk = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
   }
   if (tid < 256) {
     raw[tid] = sk;
@@ -775,10 +776,10 @@ hipError_t bhk_keys_split(bh_ctx* c) {
   const int nb = split_buckets(n);
   if (c->B == 10)
     keys_split_kernel<10><<<c->sort_tiles, kKsThreads, 0, c->stream>>>(
-        c->posm[c->cur], c->bounds, n, nb, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+        c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
   else
     keys_split_kernel<21><<<c->sort_tiles, kKsThreads, 0, c->stream>>>(
-        c->posm[c->cur], c->bounds, n, nb, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+        c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
   c->keys_split = true;
   return hipGetLastError();
 }

@@ -207,14 +207,14 @@ __global__ __launch_bounds__(1024) void integrate_kernel(float4* __restrict__ po
 // ------------------------------------------------------------------ keys
 template <int B>
 __global__ __launch_bounds__(256) void keys_kernel(const float4* __restrict__ posm,
-                                                   const float* __restrict__ bounds, int n,
+                                                   const float* __restrict__ bounds, int n, int curve,
                                                    u64* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
   const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
   const float4 q = posm[i];
-  const u64 k = morton_key<B>(q.x, q.y, q.z, minX, minY, minZ, size);
+  const u64 k = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
   keys[i] = k;
 }
 
@@ -1151,9 +1151,9 @@ hipError_t bhk_keys(bh_ctx* c, bool for_sort) {
   const int n = c->n;
   const int blocks = (n + 255) / 256;
   if (c->B == 10)
-    keys_kernel<10><<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, c->keys[0]);
+    keys_kernel<10><<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, 0, c->keys[0]);
   else
-    keys_kernel<21><<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, c->keys[0]);
+    keys_kernel<21><<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->bounds, n, c->p.key_curve, c->keys[0]);
   return hipGetLastError();
 }
 

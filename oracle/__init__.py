@@ -23,7 +23,7 @@ NODE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("m", "f4"), ("s",
 class Params(C.Structure):
     _fields_ = [("G", C.c_float), ("theta", C.c_float), ("dt", C.c_float), ("eps2", C.c_float),
                 ("max_speed", C.c_float), ("leaf_cap", C.c_int32), ("max_depth", C.c_int32),
-                ("key_bits", C.c_int32), ("compress", C.c_int32)]
+                ("key_bits", C.c_int32), ("compress", C.c_int32), ("key_curve", C.c_int32)]
 
 
 def build(force=False):
@@ -50,7 +50,10 @@ def lib():
         L.bho_default_params.argtypes = [C.POINTER(Params)]
         L.bho_bbox.argtypes = [_F, _F, _F, C.c_int, _F]
         L.bho_morton30.argtypes = [_F, _F, _F, _F, C.c_int, _U32, _I32]
-        L.bho_keys.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, _U64]
+        L.bho_keys.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _U64]
+        L.bho_hilbert_index.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.bho_hilbert_index.restype = C.c_uint64
+        L.bho_hilbert_cell.argtypes = [C.c_uint64, C.POINTER(C.c_uint32)]
         L.bho_sort.argtypes = [_U64, C.c_int, _U64, _I32]
         L.bho_root_edge.argtypes = [_F]
         L.bho_root_edge.restype = C.c_float
@@ -119,11 +122,23 @@ def morton30(x, y, z, bounds):
     return codes, idx
 
 
-def keys(x, y, z, bounds, key_bits=63):
+def keys(x, y, z, bounds, key_bits=63, key_curve=0):
     x, y, z, bounds = _f(x), _f(y), _f(z), _f(bounds)
     k = np.empty(len(x), np.uint64)
-    lib().bho_keys(_fp(x), _fp(y), _fp(z), _fp(bounds), len(x), int(key_bits), k.ctypes.data_as(_U64))
+    lib().bho_keys(_fp(x), _fp(y), _fp(z), _fp(bounds), len(x), int(key_bits), int(key_curve),
+                   k.ctypes.data_as(_U64))
     return k
+
+
+def hilbert_index(x, y, z):
+    """cell (x, y, z) of the 2^21-per-axis grid -> its number along the Hilbert curve"""
+    return int(lib().bho_hilbert_index(int(x), int(y), int(z)))
+
+
+def hilbert_cell(index):
+    out = (C.c_uint32 * 3)()
+    lib().bho_hilbert_cell(int(index), out)
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def sort(k):

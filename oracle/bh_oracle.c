@@ -33,6 +33,7 @@ void bho_default_params(bho_params* p) {
   p->max_depth = 21;
   p->key_bits = 63;
   p->compress = 1;
+  p->key_curve = 0;
 }
 
 int bho_max_threads(void) { return omp_get_max_threads(); }
@@ -98,12 +99,73 @@ static uint64_t spread3(uint32_t q, int bits) {
   return r;
 }
 
+/* Hilbert numbering of the 2^21-per-axis cell grid (bh_params.key_curve = 1; NOT in the reference, which uses the
+   Morton / Z order — the cells and therefore the octree are the same, only their order along the key axis
+   changes).  J. Skilling, "Programming the Hilbert curve", AIP Conf. Proc. 707 (2004), restated in its original
+   array form with explicit loops over the dimensions (the GPU has the three axes unrolled in registers):
+   AxesToTranspose turns cell coordinates into the "transposed" index, whose bit-interleave — X[0] supplying the
+   most significant bit of each triple — is the position along the curve. */
+#define HB 21
+static void axes_to_transpose(uint32_t X[3]) {
+  const uint32_t M = 1u << (HB - 1);
+  for (uint32_t Q = M; Q > 1; Q >>= 1) { /* inverse undo of the excess work */
+    const uint32_t P = Q - 1;
+    for (int i = 0; i < 3; i++) {
+      if (X[i] & Q) {
+        X[0] ^= P; /* invert the low bits of X[0] */
+      } else {     /* exchange the low bits of X[0] and X[i] */
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  for (int i = 1; i < 3; i++) X[i] ^= X[i - 1]; /* Gray encode */
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  for (int i = 0; i < 3; i++) X[i] ^= t;
+}
+static void transpose_to_axes(uint32_t X[3]) {
+  const uint32_t N = 2u << (HB - 1);
+  uint32_t t = X[2] >> 1; /* Gray decode by H ^ (H / 2) */
+  for (int i = 2; i > 0; i--) X[i] ^= X[i - 1];
+  X[0] ^= t;
+  for (uint32_t Q = 2; Q != N; Q <<= 1) { /* undo the excess work */
+    const uint32_t P = Q - 1;
+    for (int i = 2; i >= 0; i--) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t u = (X[0] ^ X[i]) & P;
+        X[0] ^= u;
+        X[i] ^= u;
+      }
+    }
+  }
+}
+uint64_t bho_hilbert_index(uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t X[3] = {x, y, z};
+  axes_to_transpose(X);
+  return (spread3(X[0], HB) << 2) | (spread3(X[1], HB) << 1) | spread3(X[2], HB);
+}
+void bho_hilbert_cell(uint64_t index, uint32_t xyz[3]) {
+  uint32_t X[3] = {0, 0, 0};
+  for (int j = 0; j < HB; j++) {
+    X[0] |= (uint32_t)((index >> (3 * j + 2)) & 1u) << j;
+    X[1] |= (uint32_t)((index >> (3 * j + 1)) & 1u) << j;
+    X[2] |= (uint32_t)((index >> (3 * j)) & 1u) << j;
+  }
+  transpose_to_axes(X);
+  xyz[0] = X[0]; xyz[1] = X[1]; xyz[2] = X[2];
+}
+
 /* key_bits 30: the reference quantisation (x1023, ref:56-58) -> identical to bho_morton30.
    key_bits 63: same normalisation, 21 bits/axis, scale 2^21 with an explicit clamp, so a
    cell of the key grid is exactly a cell of the repeated midpoint halving (ref:96-99,114-119).
    x is the most significant bit of each octal digit (ref:61). */
 static void keys_strided(const float* x, const float* y, const float* z, int stride,
-                         const float bounds[6], int n, int key_bits, uint64_t* keys) {
+                         const float bounds[6], int n, int key_bits, int key_curve, uint64_t* keys) {
   const int b = key_bits / 3;
   const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
   const float size = fmaxf(bounds[3] - bounds[0], 1.0f);
@@ -118,13 +180,14 @@ static void keys_strided(const float* x, const float* y, const float* z, int str
     if (xx > qmax) xx = qmax;
     if (yy > qmax) yy = qmax;
     if (zz > qmax) zz = qmax;
-    keys[i] = (spread3(xx, b) << 2) | (spread3(yy, b) << 1) | spread3(zz, b);
+    keys[i] = (key_curve == 1 && b == HB) ? bho_hilbert_index(xx, yy, zz)
+                                          : (spread3(xx, b) << 2) | (spread3(yy, b) << 1) | spread3(zz, b);
   }
 }
 
 void bho_keys(const float* x, const float* y, const float* z, const float bounds[6], int n,
-              int key_bits, uint64_t* keys) {
-  keys_strided(x, y, z, 1, bounds, n, key_bits, keys);
+              int key_bits, int key_curve, uint64_t* keys) {
+  keys_strided(x, y, z, 1, bounds, n, key_bits, key_curve, keys);
 }
 
 /* ------------------------------------------------------------------ sort */
@@ -678,7 +741,7 @@ void bho_step(bho_state* s, int order, int nthreads) {
   double t0 = omp_get_wtime(), t1;
   bbox_strided(s->xyzm, s->xyzm + 1, s->xyzm + 2, 4, n, s->bounds); /* ref:259 */
   t1 = omp_get_wtime(); s->t[0] = t1 - t0; t0 = t1;
-  keys_strided(s->xyzm, s->xyzm + 1, s->xyzm + 2, 4, s->bounds, n, s->p.key_bits, s->keys); /* ref:260 */
+  keys_strided(s->xyzm, s->xyzm + 1, s->xyzm + 2, 4, s->bounds, n, s->p.key_bits, s->p.key_curve, s->keys); /* ref:260 */
   t1 = omp_get_wtime(); s->t[1] = t1 - t0; t0 = t1;
   bho_sort(s->keys, n, s->skeys, s->perm); /* ref:262-264 */
 #pragma omp parallel for schedule(static)

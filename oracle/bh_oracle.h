@@ -28,6 +28,8 @@ typedef struct bho_params {
   float G, theta, dt, eps2, max_speed; /* ref:14-18 */
   int32_t leaf_cap, max_depth, key_bits;
   int32_t compress; /* 1: path-compressed octree (the engine's tree); 0: literal chain cells */
+  int32_t key_curve; /* numbering of the key grid's cells: 0 = Morton (the reference's, ref:42-63; default),
+                        1 = Hilbert (include/bh.h bh_params.key_curve; 63-bit keys only) */
 } bho_params;
 
 #define BHO_KIND_BODY 0
@@ -54,8 +56,12 @@ void bho_default_params(bho_params* p);
 void bho_bbox(const float* x, const float* y, const float* z, int n, float bounds[6]);              /* ref:134-156 */
 void bho_morton30(const float* x, const float* y, const float* z, const float bounds[6], int n,
                   uint32_t* codes, int32_t* indices);                                                /* ref:42-63, literal */
+/* key_curve as in bho_params */
 void bho_keys(const float* x, const float* y, const float* z, const float bounds[6], int n,
-              int key_bits, uint64_t* keys);
+              int key_bits, int key_curve, uint64_t* keys);
+/* 21-bit cell coordinates <-> Hilbert cell number (test hooks for the curve's defining properties) */
+uint64_t bho_hilbert_index(uint32_t x, uint32_t y, uint32_t z);
+void bho_hilbert_cell(uint64_t index, uint32_t xyz[3]);
 void bho_sort(const uint64_t* keys, int n, uint64_t* sorted_keys, int32_t* perm);                    /* ref:262-264: stable */
 float bho_root_edge(const float bounds[6]);                                                          /* ref:55 fmaxf(b[3]-b[0],1) */
 /* returns number of entries, or -1 if capacity is too small */

@@ -34,7 +34,7 @@ class OracleEngine:
 
     def tree_stages(self):
         b = O.bbox(self.xyzm[:, 0], self.xyzm[:, 1], self.xyzm[:, 2])
-        k = O.keys(self.xyzm[:, 0], self.xyzm[:, 1], self.xyzm[:, 2], b, self.p.key_bits)
+        k = O.keys(self.xyzm[:, 0], self.xyzm[:, 1], self.xyzm[:, 2], b, self.p.key_bits, self.p.key_curve)
         sk, perm = O.sort(k)
         self.xyzm = np.ascontiguousarray(self.xyzm[perm])
         self.vel = np.ascontiguousarray(self.vel[perm])

@@ -6,7 +6,7 @@ def oracle_pipeline(O, ic, p):
     """Oracle stages on caller-order arrays -> dict of every intermediate."""
     x, y, z, vx, vy, vz, m = ic
     b = O.bbox(x, y, z)
-    k = O.keys(x, y, z, b, p.key_bits)
+    k = O.keys(x, y, z, b, p.key_bits, p.key_curve)
     sk, perm = O.sort(k)
     xyzm = np.stack([x, y, z, m], 1)[perm].astype(np.float32)
     vel = np.stack([vx, vy, vz], 1)[perm].astype(np.float32)
@@ -16,10 +16,16 @@ def oracle_pipeline(O, ic, p):
                 er_hi=hi, n_internal=ni, max_level=ml)
 
 
+def key_curve_of(gp):
+    """the curve an engine with these bh_params orders its keys by (30-bit keys are always Morton)"""
+    return 0 if gp.key_bits == 30 else gp.key_curve
+
+
 def oparams(O, gp):
     """oracle params from an engine's bh_params"""
     return O.params(G=gp.G, theta=gp.theta, dt=gp.dt, eps2=gp.eps2, max_speed=gp.max_speed,
-                    leaf_cap=gp.leaf_cap, max_depth=gp.max_depth, key_bits=gp.key_bits)
+                    leaf_cap=gp.leaf_cap, max_depth=gp.max_depth, key_bits=gp.key_bits,
+                    key_curve=key_curve_of(gp))
 
 
 def special_ics(name, n, rng):

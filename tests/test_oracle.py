@@ -301,3 +301,51 @@ def test_golden_fixtures(pkg, orc):
     assert np.array_equal(nx, g["xyzm_after"]) and np.array_equal(nv, g["vel_after"])
     meta = json.load(open(os.path.join(GOLD, "plummer4096_seed42.json")))
     assert meta["n_internal"] == o["n_internal"] and meta["n_entries"] == len(o["rec"])
+
+
+def test_hilbert_numbering_is_a_hilbert_curve(orc):
+    """the oracle's Hilbert numbering of the 2^21-per-axis cell grid (key_curve = 1) has the curve's defining
+    properties: a bijection (index -> cell -> index), consecutive indices are face neighbours (exactly one
+    coordinate changes, by one cell), and every 3L-bit index prefix is one aligned cube of the level-L octree —
+    the property the tree build relies on"""
+    rng = np.random.default_rng(5)
+    top = 1 << 63
+    starts = [0, top - 4100, 1 << 30, (1 << 60) - 2050, 0x1249249249249249 - 2000] + \
+             [int(v) for v in rng.integers(0, top - 5000, 12)]
+    for s0 in starts:
+        prev = orc.hilbert_cell(s0)
+        assert orc.hilbert_index(*prev) == s0
+        for i in range(s0 + 1, s0 + 4097):
+            c = orc.hilbert_cell(i)
+            assert orc.hilbert_index(*c) == i
+            d = [abs(c[a] - prev[a]) for a in range(3)]
+            assert sorted(d) == [0, 0, 1], (i, prev, c)
+            prev = c
+    for L in (1, 2, 5, 13, 20):
+        sh = 3 * (21 - L)
+        for pfx in [int(v) for v in rng.integers(0, 1 << (3 * L), 6)]:
+            lo, hi = pfx << sh, ((pfx + 1) << sh) - 1
+            probes = [lo, hi] + [int(v) for v in rng.integers(lo, hi + 1, 20)]
+            cells = np.array([orc.hilbert_cell(q) for q in probes], dtype=np.int64)
+            assert np.all((cells >> (21 - L)) == (cells[0] >> (21 - L)))   # one cube of edge 2^(21-L)
+
+
+def test_hilbert_keys_sort_bodies_into_the_same_cells(pkg, orc):
+    """key_curve changes the ORDER of the cells, not the cells: per octree level the multiset of cell populations
+    is the same under Morton and Hilbert keys, and so is the canonical tree's size"""
+    x, y, z, *_ = pkg.plummer(20000, seed=3)
+    b = orc.bbox(x, y, z)
+    km = orc.keys(x, y, z, b, 63, 0)
+    kh = orc.keys(x, y, z, b, 63, 1)
+    for L in (1, 3, 6, 10, 15, 21):
+        sh = np.uint64(3 * (21 - L))
+        cm = np.sort(np.unique(km >> sh, return_counts=True)[1])
+        ch = np.sort(np.unique(kh >> sh, return_counts=True)[1])
+        assert np.array_equal(cm, ch), L
+    trees = []
+    for kc, k in ((0, km), (1, kh)):
+        sk, perm = orc.sort(k)
+        p = orc.params(key_curve=kc)
+        rec, lo, hi, ni, ml = orc.build_tree(sk, p, orc.root_edge(b))
+        trees.append((len(rec), ni, ml))
+    assert trees[0] == trees[1]
