@@ -812,6 +812,27 @@ __device__ __forceinline__ bh_node pad_entry() {
   return r;
 }
 
+// Where, in its parent's child block, does the child [qa, qb) (window slots) go?  Parent = the smallest branching
+// cell around it: level Lp = max(d[qa], d[qb]); it starts at the nearest position <= qa with d < Lp and ends at the
+// nearest >= qb with d < Lp; its children are delimited by its positions with d == Lp, so the child's ordinal is
+// the number of those in (start, qa], and the parent's representative pair (*slot) is the first of them.
+// False: there is no parent (the child is the whole system) or the parent is wide (> kPairTile bodies, which
+// includes every parent that leaves the window) and emits the record itself.
+__device__ __forceinline__ bool parent_slot(u64 (*m)[kPairWords], const signed char* dl, int qa, int qb, int* slot,
+                                            int* ord) {
+  const int da = dl[qa], db = dl[qb];
+  const int Lp = max(da, db);
+  if (Lp < 0) return false;
+  const u64* mlt = m[Lp];       // d <  Lp
+  const u64* mleq = m[Lp + 1];  // d <= Lp
+  const int ps = (da < Lp) ? qa : prev_set(mlt, qa);
+  const int pe = (db < Lp) ? qb : next_set(mlt, qb);
+  if (ps < 0 || pe < 0 || pe - ps > kPairTile) return false;
+  *ord = (qa == ps) ? 0 : 1 + count_between(mleq, ps, qa);
+  *slot = next_set(mleq, ps);
+  return true;
+}
+
 // ttot[tp_off ..] = tile bases (exclusive scan of the per-tile child-entry totals, written by the last block of
 // pairs_kernel); tpre[ntiles] = all entries
 __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
@@ -849,17 +870,26 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     rec[1] = pad_entry();  // child blocks start at even entries (BH_BLOCK0)
     er_lo[1] = er_hi[1] = 0;
   }
-  // The thread's four pairs in four passes, so that the global loads of a pass are all in flight together
-  // (one round after the other paid two dependent load latencies per round: ~16 of this phase's 25 us).
+  // Every record is written by a thread that knows it without searching: an emitted cell's thread (its
+  // representative pair) writes the cell's OWN record into its parent's child block, and with leaf_cap = 1 the
+  // thread of body j writes the leaf that starts at j (the body, or the group of bodies sharing all max_depth
+  // digits with it).  Where the record goes follows from the d[] window alone (parent_slot).  (Round 2 began
+  // with each parent resolving its <= 8 children one after the other — a level-by-level mask search per internal
+  // child and a divergent loop, the wave waiting for its slowest lane: 29 of this kernel's 41 us per block.)
+  // The thread's four pairs go through the passes together, so that the global loads of a pass are all in flight
+  // at once.  Cells of more than kPairTile bodies are "wide": their thread emits ALL their children in phase 2
+  // (key searches); the rule depends on the cell alone, so the threads of its children — possibly in other blocks
+  // — reach the same verdict.  A narrow cell lies inside this block's window: |a - j|, |b - j| <= kPairTile.
   constexpr int kR = kPairTile / 256;
   int nc_[kR], e_[kR], a_[kR], b_[kR], jp_[kR], ord_[kR];
+  int jl_[kR], ordl_[kR], cntl_[kR];  // the leaf starting at body j: parent's pair, ordinal, bodies
 #pragma unroll
   for (int r = 0; r < kR; r++) {
     const int j = t0 + r * 256 + (int)threadIdx.x;
     nc_[r] = 0;
     e_[r] = a_[r] = b_[r] = 0;
-    jp_[r] = -1;
-    ord_[r] = 0;
+    jp_[r] = jl_[r] = -1;
+    ord_[r] = ordl_[r] = cntl_[r] = 0;
     if (j > 0 && j < n) {
       nc_[r] = pn[j];
       e_[r] = BH_BLOCK0 + BH_CB(j);
@@ -870,24 +900,39 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
 #pragma unroll
   for (int r = 0; r < kR; r++) {
     const int p = kPairTile + r * 256 + (int)threadIdx.x;
+    const int j = base + p;
+    // ---- the leaf that starts at body j (leaf_cap = 1)
+    if (cap == 1 && j < n) {
+      const int da = dl[p];
+      if (da < D) {  // else: j shares all D digits with j-1 and sits inside the leaf that started earlier
+        int qe = p + 1;
+        if (dl[qe] >= D) qe = next_set(m[D], p);  // unsplit cell at the depth cap: up to the next d < D
+        if (qe >= 0) {
+          int slot, ord;
+          if (parent_slot(m, dl, p, qe, &slot, &ord)) {
+            jl_[r] = base + slot;
+            ordl_[r] = ord;
+            cntl_[r] = qe - p;
+          }
+        }
+      }
+    }
     const int nc = nc_[r], e = e_[r], a = a_[r], b = b_[r];
     if (nc == 0) continue;
     if (nc > 8 || e + nc > rec_cap) continue;  // cannot happen (records <= 2n); flagged by thread 0 if it did
     const int L = dl[p];
     const int qa = a - base, qb = b - base;
-    // A cell of more than kPairTile bodies is "wide": its thread emits ALL its children in phase 2 (key
-    // searches).  The rule depends on the cell alone, so the threads of its children — possibly in other blocks
-    // — reach the same verdict.  A narrow cell lies inside this block's window: |a - j|, |b - j| <= kPairTile.
     if (b - a > kPairTile) {
       wide[atomicAdd(&nwide, 1)] = p;
       continue;
     }
-    // (A) the cell's LEAF children: runs between the positions with d == L in (qa, qb), p being the first.
-    // A child that is itself an emitted cell is skipped here — (B) below: that cell's own thread writes it,
-    // from its own child count and block offset.  (Resolving every internal child's branching level and
-    // representative pair from the parent — a level-by-level mask search per child, the wave waiting for its
-    // slowest lane — was most of this kernel's time.)
-    {
+    if (nc & 1) {  // a block of an odd number of children is followed by one padding entry
+      rec[e + nc] = pad_entry();
+      er_lo[e + nc] = er_hi[e + nc] = 0;
+    }
+    // ---- leaf_cap > 1: the parent writes its leaf children (runs between the positions with d == L in (qa, qb),
+    // p being the first); internal children still write themselves
+    if (cap != 1) {
       const u64* mle = m[L + 1];
       int c0 = qa, c1 = p;
 #pragma unroll 1
@@ -922,35 +967,27 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
           c1 = (nx < 0 || nx > qb) ? qb : nx;
         }
       }
-      if (nc & 1) {  // a block of an odd number of children is followed by one padding entry
-        rec[e + nc] = pad_entry();
-        er_lo[e + nc] = er_hi[e + nc] = 0;
-      }
     }
-    // (B) this cell's own record goes into its parent's child block.  Parent = the smallest branching cell
-    // around [a, b): level Lp = max(d[a], d[b]); it starts at the nearest position <= a with d < Lp, ends at
-    // the nearest >= b with d < Lp; its children are delimited by its positions with d == Lp, so this cell's
-    // ordinal is the number of those in (start, a], and the parent's representative pair is the first of them.
+    // ---- this cell's own record goes into its parent's child block
     if (a == 0 && b == n) continue;  // the root cell's record is entry 0
     {
-      const int da = dl[qa], db = dl[qb];
-      const int Lp = max(da, db);
-      const u64* mlt = m[Lp];       // d <  Lp
-      const u64* mleq = m[Lp + 1];  // d <= Lp
-      const int ps = (da < Lp) ? qa : prev_set(mlt, qa);
-      const int pe = (db < Lp) ? qb : next_set(mlt, qb);
-      if (ps < 0 || pe < 0 || pe - ps > kPairTile) continue;  // wide parent: it emits this record itself
-      ord_[r] = (qa == ps) ? 0 : 1 + count_between(mleq, ps, qa);
-      jp_[r] = base + next_set(mleq, ps);  // the parent's representative pair
+      int slot, ord;
+      if (parent_slot(m, dl, qa, qb, &slot, &ord)) {
+        jp_[r] = base + slot;
+        ord_[r] = ord;
+      }
     }
   }
-  int ep_[kR];
-#pragma unroll
-  for (int r = 0; r < kR; r++) ep_[r] = (jp_[r] >= 0) ? BH_BLOCK0 + BH_CB(jp_[r]) + ord_[r] : rec_cap;
+  int ep_[kR], el_[kR];
 #pragma unroll
   for (int r = 0; r < kR; r++) {
+    ep_[r] = (jp_[r] >= 0) ? BH_BLOCK0 + BH_CB(jp_[r]) + ord_[r] : rec_cap;
+    el_[r] = (jl_[r] >= 0) ? BH_BLOCK0 + BH_CB(jl_[r]) + ordl_[r] : rec_cap;
+  }
+#pragma unroll
+  for (int r = 0; r < kR; r++) {
+    const int p = kPairTile + r * 256 + (int)threadIdx.x;
     if (ep_[r] < rec_cap) {
-      const int p = kPairTile + r * 256 + (int)threadIdx.x;
       bh_node rr;
       rr.x = rr.y = rr.z = rr.m = 0.0f;
       rr.s = ldexpf(s0, -(int)dl[p]);
@@ -960,6 +997,22 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       rec[ep_[r]] = rr;
       er_lo[ep_[r]] = a_[r];
       er_hi[ep_[r]] = b_[r];
+    }
+    if (el_[r] < rec_cap) {
+      bh_node rr;
+      rr.x = rr.y = rr.z = rr.m = 0.0f;
+      rr.first = base + p;
+      rr.count = cntl_[r];
+      if (cntl_[r] == 1) {
+        rr.kind = BH_KIND_BODY;
+        rr.s = -1.0f;  // negative edge: accepted by every theta >= 0
+      } else {
+        rr.kind = BH_KIND_MULTI;  // never branches above the depth cap: unsplit multi-body cell at level D
+        rr.s = ldexpf(s0, -D);
+      }
+      rec[el_[r]] = rr;
+      er_lo[el_[r]] = base + p;
+      er_hi[el_[r]] = base + p + cntl_[r];
     }
   }
   __syncthreads();
