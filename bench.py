@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--xcd-mode", type=int, default=0, help="tuning: block->chunk placement (bh_params.xcd_mode)")
+    ap.add_argument("--xcd-mode", type=int, default=3, help="tuning: block->chunk placement (bh_params.xcd_mode, 3 = automatic)")
     ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
     ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
     ap.add_argument("--graph", action="store_true",

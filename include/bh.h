@@ -62,8 +62,10 @@ typedef struct bh_params {
   int32_t force_variant; /* fast force kernel: 0 = hand-scheduled gfx950 walk (default), 1 = the same walk
                             as scheduled by the compiler (A/B and fallback)                */
   int32_t xcd_mode;      /* fast force kernels, block -> body-chunk placement (speed only):
-                            0 = one contiguous eighth of the Morton order per XCD, 1 = identity,
-                            2 = runs of 16 chunks per XCD dealt round-robin                       */
+                            0 = one contiguous eighth of the body order per XCD, 1 = identity,
+                            2 = runs of 64 chunks per XCD dealt round-robin,
+                            3 = automatic (default): 2 when the launch has more waves than the GPU holds
+                                at once, else 0                                                  */
   int32_t sort_variant;  /* 0 = automatic (default): splitter sort (one partition pass + per-bucket LDS
                             sort) when the bodies are still in an earlier step's key order and fit,
                             else 2;  1 = histogram + scan + scatter kernels per radix pass (no

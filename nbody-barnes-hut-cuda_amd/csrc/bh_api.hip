@@ -51,6 +51,7 @@ int bh_default_params(bh_params* p) {
   p->key_bits = 63;
   p->strict_fp = 0;
   p->key_curve = 1;  // Hilbert order
+  p->xcd_mode = 3;   // automatic
   return BH_OK;
 }
 
@@ -113,7 +114,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   if (p.key_bits != 63 && p.key_bits != 30) return BH_ERR_BAD_ARG;
   if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0 ||
       p.force_variant < 0 || p.force_variant > 1 || p.sort_variant < 0 || p.sort_variant > 3 ||
-      p.key_curve < 0 || p.key_curve > 1)
+      p.key_curve < 0 || p.key_curve > 1 || p.xcd_mode < 0 || p.xcd_mode > 3)
     return BH_ERR_BAD_ARG;
   if (p.key_bits == 30) p.key_curve = 0;  // the reference-literal 30-bit code is a Morton code
 
@@ -130,6 +131,12 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   c->D = p.max_depth < c->B ? p.max_depth : c->B;
   c->cap = p.leaf_cap;
   c->device = device;
+  c->num_cus = 256;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      c->num_cus = cus;
+  }
   if (hipSetDevice(device) != hipSuccess) {
     delete c;
     return BH_ERR_NO_DEVICE;

@@ -57,7 +57,14 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // mode 2: runs of kXcdRun consecutive chunks per XCD, runs dealt round-robin (locality of a run,
 // balance of round-robin; the launcher rounds the grid up to a multiple of 8*kXcdRun and surplus
 // chunks fall out at the `valid` test).  Placement is a speed matter only, never correctness.
-constexpr int kXcdRun = 16;
+// Measured with Hilbert-ordered bodies (force ms, mode 0 / 1 / 2): 65,536: 0.224 / 0.242 / 0.227; 500,000:
+// 0.705 / 0.777 / 0.734; 700,000: 0.961 / - / 0.941; 1M: 1.288 / 1.269 / 1.239; 1M theta 0.3: 3.99 / 3.83 / 3.75;
+// 2M: 2.52 / - / 2.43; 8M: 9.86 / - / 9.60 — contiguous eighths win while the whole launch is resident at once,
+// interleaved runs win once it is not (a dense eighth then finishes late): bh_params.xcd_mode 3 picks by that.
+#ifndef BH_XCD_RUN
+#define BH_XCD_RUN 64  // 16..64 measure alike at 1M bodies, 256 is 6 % slower, 2 is 2 % slower
+#endif
+constexpr int kXcdRun = BH_XCD_RUN;
 __device__ __forceinline__ int block_chunk(int mode) {
   const int nb = gridDim.x, b = blockIdx.x;
   if (mode == 1) return b;
@@ -786,6 +793,15 @@ static int force_group(const bh_ctx* c, int bodies) {
   return bodies <= 64 * 1024 + 32 * 1024 ? 32 : 64;
 }
 
+// bh_params.xcd_mode 3 (default): interleaved runs when the launch has more waves than the GPU holds at once
+// (8 waves per SIMD: 54 VGPRs), contiguous eighths otherwise
+static int resolve_xcd_mode(const bh_ctx* c, int bodies, int group) {
+  const int mode = c->p.xcd_mode;
+  if (mode != 3) return mode;
+  const long long waves = ((long long)bodies + group - 1) / group;
+  return waves > (long long)c->num_cus * 32 ? 2 : 0;
+}
+
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
   if (hi <= lo) return hipSuccess;
   const int blocks = (hi - lo + 255) / 256;
@@ -805,7 +821,6 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
     if (c->p.strict_fp)
       force_kernel<true, false><<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, th, e2, nullptr, nullptr, nullptr, c->info);
     else {
-      const int mode = c->p.xcd_mode;
       // the frec pool = tree digests + one digest slot per body (bh_internal.h)
       if ((long long)BH_FREC_POOL(c->rec_cap, c->n) >= (1ll << 27)) {
         // the fast kernel addresses records with 32-bit byte offsets (pool < 4 GiB, ~44M bodies):
@@ -816,6 +831,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       int tpb = c->p.force_block;  // 64, 128 or 256 threads per workgroup (0 = default)
       if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
       const int group = force_group(c, hi - lo);
+      const int mode = resolve_xcd_mode(c, hi - lo, group);
       int g2 = ((hi - lo + group - 1) / group * 64 + tpb - 1) / tpb;
       if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
       static const bool debug_budget = getenv("BH_FORCE_BUDGET") != nullptr;  // bring-up aid: bounded walk
@@ -836,7 +852,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
 hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [ceil(n/64)][8], device */) {
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
-  const int mode = c->p.xcd_mode == 2 ? 0 : c->p.xcd_mode;
+  const int mode = (c->p.xcd_mode == 1) ? 1 : 0;  // one row per wave in launch order: no grid padding here
   const int g2 = (c->n + tpb - 1) / tpb;
   force_walk_stats_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->n, c->p.eps2, mode, rows);
   return hipGetLastError();
@@ -848,9 +864,10 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   if (hi <= lo) return hipSuccess;
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
-  const int mode = c->p.xcd_mode == 2 ? 0 : c->p.xcd_mode;
   const int group = force_group(c, hi - lo);
-  const int g2 = ((hi - lo + group - 1) / group * 64 + tpb - 1) / tpb;
+  const int mode = resolve_xcd_mode(c, hi - lo, group);
+  int g2 = ((hi - lo + group - 1) / group * 64 + tpb - 1) / tpb;
+  if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
   // a wave pops one child block per opened cell: no wave of a well-formed pool can pop more blocks than
   // the pool has records, so this bound never fires on valid data and always ends a walk over a cycle
   const int budget = kTraversalBudget;

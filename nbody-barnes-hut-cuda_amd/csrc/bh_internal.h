@@ -82,6 +82,7 @@ struct bh_devinfo {
 
 struct bh_ctx {
   int n;
+  int num_cus;  // compute units of the device (force-kernel placement heuristics)
   bh_params p;
   int B, D, cap;  // bits per axis, effective max depth, leaf cap
   int device;
