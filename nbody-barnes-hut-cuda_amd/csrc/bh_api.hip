@@ -265,6 +265,7 @@ int bh_set_timing(bh_ctx* c, int on) {
     for (int i = 0; i < BH_TIMING_RING * 8; i++) BH_HIP(c, hipEventCreate(&c->evring[i]));
   }
   c->timing = on != 0;
+  c->timing_mode = (on == 2) ? 2 : 1;
   c->timed_steps = 0;
   return BH_OK;
 }
@@ -435,7 +436,10 @@ int bh_force_count(bh_ctx* c) {
 static int step_launch(bh_ctx* c) {
   const bool t = c->timing;
   hipEvent_t* ev = t ? c->evring + (size_t)(c->timed_steps % BH_TIMING_RING) * 8 : nullptr;
-#define BH_MARK(i) if (t) BH_HIP(c, hipEventRecord(ev[i], c->stream))
+  // mode 2 records only the pair around the force launch: an event record costs the stream ~7-16 us between
+  // two dependent kernels, eight of them ~60 us per 1M-body step (seen as gaps in the rocprofv3 kernel trace)
+  const bool all = t && c->timing_mode != 2;
+#define BH_MARK(i) if (all || (t && ((i) == 5 || (i) == 6))) BH_HIP(c, hipEventRecord(ev[i], c->stream))
   BH_MARK(0);
   if (c->bounds_next_ok) {  // the previous step's integrate already folded the cube of these positions
     float* t = c->bounds;
@@ -665,7 +669,10 @@ int bh_get_stats(bh_ctx* c, bh_stats* st) {
   st->max_level = hi.max_level;
   st->status_flags = hi.flags;
   st->steps = c->steps;
-  if (c->timing && c->timed_steps > 0) {
+  if (c->timing && c->timing_mode == 2 && c->timed_steps > 0) {
+    hipEvent_t* ev = c->evring + (size_t)((c->timed_steps - 1) % BH_TIMING_RING) * 8;
+    BH_HIP(c, hipEventElapsedTime(&st->ms_force, ev[5], ev[6]));
+  } else if (c->timing && c->timed_steps > 0) {
     hipEvent_t* ev = c->evring + (size_t)((c->timed_steps - 1) % BH_TIMING_RING) * 8;
     float* ms[7] = {&st->ms_bbox, &st->ms_morton, &st->ms_sort, &st->ms_build,
                     &st->ms_com, &st->ms_force, &st->ms_integrate};
@@ -692,7 +699,10 @@ int bh_timing_history(bh_ctx* c, float* ms_force, float* ms_step, int capacity, 
     const long step = c->timed_steps - take + i;
     hipEvent_t* ev = c->evring + (size_t)(step % BH_TIMING_RING) * 8;
     if (ms_force) BH_HIP(c, hipEventElapsedTime(&ms_force[i], ev[5], ev[6]));
-    if (ms_step) BH_HIP(c, hipEventElapsedTime(&ms_step[i], ev[0], ev[7]));
+    if (ms_step) {
+      if (c->timing_mode == 2) ms_step[i] = 0.0f;  // not recorded in this mode
+      else BH_HIP(c, hipEventElapsedTime(&ms_step[i], ev[0], ev[7]));
+    }
   }
   *count = (int)take;
   return BH_OK;

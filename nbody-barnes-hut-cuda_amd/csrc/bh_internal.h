@@ -174,6 +174,7 @@ struct bh_ctx {
 
   // timing
   bool timing;
+  int timing_mode;  // 1: event after every stage; 2: only the pair around the force launch
   hipEvent_t* evring;  // [BH_TIMING_RING][8], created by the first bh_set_timing(1)
   long timed_steps;    // steps recorded into the ring since timing was switched on
 };

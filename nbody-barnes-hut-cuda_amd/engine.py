@@ -162,7 +162,8 @@ class Engine:
         self._ck(lib.bh_sync(self._h), "bh_sync")
 
     def set_timing(self, on=True):
-        self._ck(lib.bh_set_timing(self._h, 1 if on else 0), "bh_set_timing")
+        """True / 1: events after every stage of a step; 2: only around the force launch (cheap); False: off"""
+        self._ck(lib.bh_set_timing(self._h, 2 if on == 2 else (1 if on else 0)), "bh_set_timing")
 
     # -- data out
     def download(self):
