@@ -256,8 +256,6 @@ def main():
     # ~60 us per step)
     eng.set_timing(2 if (not multi and not args.graph) else 0)
 
-    if dist_mode == "domain" and rank == 0:
-        stepper.set_profile(True)   # per-phase event pairs on rank 0's stream (a few microseconds per step)
     barrier()
     t0 = time.perf_counter()
     if not multi:
@@ -283,6 +281,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # per-phase device times of the domain-decomposed step: 5 further steps on every rank (the exchanges are
+    # collective), events on rank 0's stream only — NOT in the timed region: each event record costs the stream
+    # several microseconds and the slowest rank sets the job's time
+    if dist_mode == "domain":
+        stepper.set_profile(rank == 0)
+        try:
+            stepper.step(5)
+        except bhdist.DomainLeft as ex:
+            print(f"[bench rank {rank}] profiling steps left the domain scheme: {ex!r}", file=sys.stderr, flush=True)
+        barrier()
 
     out = None
     if rank == 0:
