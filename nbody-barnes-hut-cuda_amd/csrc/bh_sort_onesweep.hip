@@ -1,22 +1,28 @@
-// bh_sort_onesweep.hip — stable LSD radix sort, ONE kernel per 8-bit pass (default sort path).
+// bh_sort_onesweep.hip — the step's stable sort by key, two implementations with identical results:
 //
-// Replaces thrust::sort_by_key (ref nbody_v5_bench.cu:262-264).  Same contract as bh_sort.hip
-// (stable ascending by key, value = slot index), a third of the launches and two thirds of the
-// traffic: keys and values are read once and written once per pass.
+//  * splitter sort (bhk_sort_split, further down): every sort whose input is still in an earlier sort's key
+//    order — keys + splitters + bucket counts in one kernel, ONE stable partition pass, one workgroup per bucket
+//    sorting it in LDS and gathering the bodies (3 kernels);
+//  * LSD radix sort, ONE kernel per 8-bit pass (bhk_sort_onesweep): the first sort after an upload, n > 1.5M,
+//    bh_params.sort_variant 2.
+//
+// Both replace thrust::sort_by_key (ref nbody_v5_bench.cu:262-264); same contract as bh_sort.hip (stable
+// ascending by key, value = slot index).  The radix pass:
 //   * one up-front kernel builds the global digit histograms of ALL passes (global digit totals do
 //     not depend on the order of the keys);
-//   * each pass kernel ranks its 4096-key tile exactly like sort_scatter_kernel (wave64 match-any
-//     with 8 ballots, wave-private LDS counters combined in wave order -> stable), then resolves
-//     the tile's per-digit prefix by DECOUPLED LOOK-BACK instead of a separate histogram + scan:
+//   * each pass kernel counts its 4096-key tile's digits, publishes them, ranks the tile (wave64 match-any,
+//     wave-private LDS counters combined in wave order -> stable) and resolves the tile's per-digit prefix by a
+//     TWO-LEVEL DECOUPLED LOOK-BACK instead of a separate histogram + scan:
 //       - tiles take a ticket (atomicAdd) when they start, so a tile's predecessors are already
 //         running: look-back only ever waits on resident workgroups (no dispatch-order assumption);
 //       - per (tile, digit) ONE 8-byte granule {tag:30 | state:2 | count:32} written and polled with
 //         relaxed agent-scope atomics (the data-tagged single-granule hand-off of
 //         cdna_hip_programming.md Guideline 16: flag and value travel in one word, so no
-//         fence ordering between them is needed).  state 1 = this tile's count, 2 = inclusive
-//         prefix.  The tag is the sort-call number, so the table is never cleared and a stale
-//         entry from an earlier call reads as "not ready";
-//       - thread d walks back over digit d's granules (256 independent chains per block);
+//         fence ordering between them is needed).  state 1 = this tile's count, 3 = sum over the tile's group
+//         of 16 up to and including it, 2 = inclusive prefix.  The tag is the sort-call number, so the table is
+//         never cleared and a stale entry from an earlier call reads as "not ready";
+//       - thread d handles digit d (256 independent chains per block): own group first, then the last tile of
+//         every earlier group (details at the kernel);
 //       - every spin is bounded; on timeout the kernel sets BH_FLAG_SORT_TIMEOUT and goes on
 //         (wrong order, loudly reported) instead of hanging the device.
 #include "bh_internal.h"
