@@ -453,12 +453,13 @@ static int step_launch(bh_ctx* c) {
   BH_HIP(c, bhk_keys(c));                      // ref:260
   c->key_buf = 0;
   BH_MARK(2);
-  BH_HIP(c, bhk_sort(c));                      // ref:262-264
+  BH_HIP(c, bhk_sort(c, true));                // ref:262-264 (the body gather may be left pending)
   BH_MARK(3);
   // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan
   // on the side stream while the main stream builds the tree (both are small, latency-bound grids)
   BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
   BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
+  BH_HIP(c, bhk_gather_bodies(c, c->stream2));  // splitter sort: the bodies follow the keys here, beside the build
   BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, true));
   BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
   BH_HIP(c, bhk_build(c));                     // ref:266-275

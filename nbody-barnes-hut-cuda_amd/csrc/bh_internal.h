@@ -118,6 +118,7 @@ struct bh_ctx {
   u64* sp_keys;     // [256] sorted splitters, padded with ~0
   u32* sp_count;    // [2][256] bucket sizes, double-buffered by call parity (the sort clears the other half)
   int sp_par;
+  bool gather_pending;  // bhk_sort_split left the body gather to bhk_gather_bodies
   bool keys_split;  // keys[0] and sp_count[sp_par] come from keys_split_kernel and no sort has consumed them
   bool order_hint;  // the bodies are stored in the key order of an earlier sort (set by every sort, cleared by
                     // uploads): what makes evenly spaced bodies good splitters
@@ -239,11 +240,12 @@ hipError_t bhk_bbox(bh_ctx* c);
 hipError_t bhk_bbox_raw(bh_ctx* c, float* out6);  // local min/max only
 hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int stride_floats);
 hipError_t bhk_keys(bh_ctx* c, bool for_sort = true);
-hipError_t bhk_sort(bh_ctx* c);                       // radix sort + gather
+hipError_t bhk_sort(bh_ctx* c, bool defer_gather = false);  // sort + gather (deferred: see bhk_sort_split)
 hipError_t bhk_sort_onesweep(bh_ctx* c);              // radix implementation (bh_sort_onesweep.hip)
 bool bhk_sort_split_eligible(const bh_ctx* c);        // splitter sort: keys + bucket counts, then partition + local sort
 hipError_t bhk_keys_split(bh_ctx* c);
-hipError_t bhk_sort_split(bh_ctx* c);
+hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather);
+hipError_t bhk_gather_bodies(bh_ctx* c, hipStream_t stream);  // no-op unless a gather is pending
 hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);

@@ -392,6 +392,18 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
 #undef OS_DIGIT
 }
 
+__global__ __launch_bounds__(256) void gather_only_kernel(const u32* __restrict__ perm,
+                                                          const float4* __restrict__ posm_in,
+                                                          const float4* __restrict__ velid_in,
+                                                          float4* __restrict__ posm_out,
+                                                          float4* __restrict__ velid_out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 j = perm[i];
+  posm_out[i] = posm_in[j];
+  velid_out[i] = velid_in[j];
+}
+
 __global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ perm,
                                                       const float4* __restrict__ posm_in,
                                                       const float4* __restrict__ velid_in,
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
     u64* kout, u32* vout,    // sorted keys / permutation
     const u32* __restrict__ bcount, u32* __restrict__ bcount_next,
     const float4* __restrict__ posm_in, const float4* __restrict__ velid_in, float4* __restrict__ posm_out,
-    float4* __restrict__ velid_out, u32* __restrict__ sw_ticket) {
+    float4* __restrict__ velid_out, u32* __restrict__ sw_ticket, int gather) {
   __shared__ u64 skey[kLsCap];
   __shared__ u32 sval[kLsCap];
   __shared__ u32 wcnt[kLsWaves][256];
@@ -662,8 +674,10 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
           const u32 v = val[r];
           kout[start + idx] = key[r];
           vout[start + idx] = v;
-          posm_out[start + idx] = posm_in[v];
-          velid_out[start + idx] = velid_in[v];
+          if (gather) {  // else: bhk_gather_bodies, beside the tree build (bh_step)
+            posm_out[start + idx] = posm_in[v];
+            velid_out[start + idx] = velid_in[v];
+          }
         }
       }
     }
@@ -741,8 +755,10 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
     const u32 v = sv[i];
     kout[start + i] = sk[i];
     vout[start + i] = v;
-    posm_out[start + i] = posm_in[v];
-    velid_out[start + i] = velid_in[v];
+    if (gather) {
+      posm_out[start + i] = posm_in[v];
+      velid_out[start + i] = velid_in[v];
+    }
   }
 }
 
@@ -790,7 +806,9 @@ hipError_t bhk_keys_split(bh_ctx* c) {
   return hipGetLastError();
 }
 
-hipError_t bhk_sort_split(bh_ctx* c) {
+// defer_gather: leave the physical body gather to bhk_gather_bodies (c->gather_pending); the tree build needs
+// only the sorted keys, so bh_step runs the gather on its second stream in front of the COM prefix scan
+hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather) {
   const int n = c->n;
   const int par = c->sp_par & 1;
   u32* bc = c->sp_count + 256 * par;
@@ -800,11 +818,22 @@ hipError_t bhk_sort_split(bh_ctx* c) {
       c->info, c->sp_keys, (float)split_buckets(n) / (float)n);
   local_sort_kernel<<<split_buckets(n), kLsThreads, 0, c->stream>>>(
       c->keys[1], c->vals[1], c->keys[0], c->vals[0], bc, c->sp_count + 256 * (par ^ 1), c->posm[c->cur],
-      c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket);
+      c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket, defer_gather ? 0 : 1);
+  c->gather_pending = defer_gather;
   c->key_buf = 0;
   c->cur ^= 1;
   c->sp_par ^= 1;
   c->keys_split = false;
+  return hipGetLastError();
+}
+
+// the deferred body gather of bhk_sort_split: posm/velid[cur] <- [cur ^ 1] through the sorted permutation
+hipError_t bhk_gather_bodies(bh_ctx* c, hipStream_t stream) {
+  if (!c->gather_pending) return hipSuccess;
+  const int n = c->n;
+  gather_only_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c->vals[0], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1],
+                                                          c->posm[c->cur], c->velid[c->cur], n);
+  c->gather_pending = false;
   return hipGetLastError();
 }
 
