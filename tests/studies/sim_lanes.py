@@ -1,13 +1,14 @@
 """design study driver for tools/sim_lanes.c (CPU only): lane occupancy of the shared traversal."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+# lives under tests/ because it feeds the ORACLE's tree to the simulation (oracle/ is test infrastructure only)
 import bhpkg, oracle as O
 from helpers import oracle_pipeline
 so = os.path.join(ROOT, "tools", "bin", "libsim_lanes.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", os.path.join(ROOT, "tools", "sim_lanes.c"), "-o", so, "-lm"])
+subprocess.check_call(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", os.path.join(ROOT, "tests", "studies", "sim_lanes.c"), "-o", so, "-lm"])
 L = C.CDLL(so)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 theta = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
