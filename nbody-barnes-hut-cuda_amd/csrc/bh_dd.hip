@@ -1193,9 +1193,17 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
   bh_dd_state* d = c->dd;
   BH_HIP(c, bhk_keys(c));
   c->key_buf = 0;
-  BH_HIP(c, bhk_sort(c));
+  BH_HIP(c, bhk_sort(c, true));
+  // as in bh_step: the body gather (if the splitter sort left it pending) and the fp64 COM prefix scan need only
+  // the sorted order, the build only the sorted keys — second stream beside the build
+  BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
+  BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
+  BH_HIP(c, bhk_gather_bodies(c, c->stream2));
+  BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, true));
+  BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
   BH_HIP(c, bhk_build(c));
-  BH_HIP(c, bhk_com(c));
+  BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
+  BH_HIP(c, bhk_com_records(c));
   dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->er_lo, c->er_hi, c->info, c->rec_cap,
                                                                    c->n, d->piece_tmp, d->ddi);
   dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, d->ddi, c->rec, c->er_lo, c->er_hi,
