@@ -787,10 +787,13 @@ __global__ __launch_bounds__(256) void unpack_u32x3_kernel(const u32* __restrict
 
 }  // namespace
 
-// bodies per wave of the fast walk: 32 when 64 would leave most SIMDs with at most one wave (1024 SIMDs)
+// bodies per wave of the fast walk: fewer than 64 (upper lanes idle) when 64 would leave the 1024 SIMDs with one
+// or two waves each — smaller groups walk smaller unions of records and more waves hide each other's scalar-load
+// latency.  Measured force ms (16 / 32 / 64 bodies per wave): 16,384 bodies 0.153 / 0.170 / 0.191; 32,768:
+// 0.185 / 0.187 / 0.216; 65,536: 0.286 / 0.223 / 0.233; 98,304: 0.391 / 0.274 / 0.268; 131,072: 0.514 / 0.337 / 0.276
 static int force_group(const bh_ctx* c, int bodies) {
-  if (c->p.force_group == 32 || c->p.force_group == 64) return c->p.force_group;
-  return bodies <= 64 * 1024 + 32 * 1024 ? 32 : 64;
+  if (c->p.force_group == 16 || c->p.force_group == 32 || c->p.force_group == 64) return c->p.force_group;
+  return bodies <= 24 * 1024 ? 16 : (bodies <= 80 * 1024 ? 32 : 64);
 }
 
 // bh_params.xcd_mode 3 (default): interleaved runs when the launch has more waves than the GPU holds at once

@@ -7,7 +7,7 @@ pkg = bhpkg.load()
 for n in [int(a) for a in sys.argv[1:]] or [65536, 98304, 131072, 196608, 262144, 524288]:
     ic = pkg.plummer(n, seed=42)
     row = []
-    for g in (32, 64):
+    for g in (16, 32, 64):
         e = pkg.Engine(n, force_group=g)
         e.upload(*ic)
         e.set_timing(True)
