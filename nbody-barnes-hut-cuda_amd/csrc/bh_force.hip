@@ -844,9 +844,12 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       else if (c->p.force_variant == 1)
         force_fast_kernel<1, false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
                                                                mode, c->info, 0, 0, group);
-      else
-        force_fast_kernel<0, false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
-                                                               mode, c->info, 0, 0, group);
+      else {
+        // design-study knob (tools/occupancy_ab.sh): dynamic LDS bytes per workgroup cap the waves per CU
+        static const int lds_pad = getenv("BH_FORCE_LDS") ? atoi(getenv("BH_FORCE_LDS")) : 0;
+        force_fast_kernel<0, false><<<g2, tpb, (size_t)lds_pad, c->stream>>>((const float*)c->frec, posm, c->acc, lo,
+                                                                             hi, G, e2, mode, c->info, 0, 0, group);
+      }
     }
   }
   return hipGetLastError();
