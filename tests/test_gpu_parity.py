@@ -131,6 +131,39 @@ def test_splitter_sort_in_steps(pkg, orc):
     assert np.array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("n", [256 * 6144, 256 * 6144 + 1])
+def test_splitter_sort_size_limit(pkg, n):
+    """256 buckets x 6144 bodies is the largest context the automatic choice gives to the splitter sort; one body
+    more and every step uses the radix sort.  Either way == a context pinned to the radix sort, bit for bit."""
+    ic = pkg.plummer(n, seed=8)
+    out = []
+    for sv in (0, 2):
+        e = _engine(pkg, ic, sort_variant=sv)
+        e.step(3)
+        out.append((e.download_order().tobytes(), e.download_keys().tobytes()))
+        assert e.stats().status_flags == 0
+        e.close()
+    assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("n", [5000, 200000])
+def test_force_placement_and_group_size_do_not_change_results(pkg, n):
+    """bh_params.xcd_mode (workgroup -> body-chunk placement) and force_group (bodies per wave) are speed knobs:
+    accelerations are bit-identical for every setting"""
+    ic = pkg.plummer(n, seed=6)
+    ref = None
+    for kw in (dict(), dict(xcd_mode=0), dict(xcd_mode=1), dict(xcd_mode=2), dict(force_group=16),
+               dict(force_group=32), dict(force_group=64), dict(force_block=256, xcd_mode=2)):
+        e = _engine(pkg, ic, **kw)
+        e.tree_stages(); e.force()
+        a = np.stack(e.download_acc(), 1).tobytes()
+        assert e.stats().status_flags == 0
+        e.close()
+        if ref is None:
+            ref = a
+        assert a == ref, kw
+
+
 def _check_tree(pkg, orc, ic, **kw):
     e = _engine(pkg, ic, **kw)
     e.tree_stages()
