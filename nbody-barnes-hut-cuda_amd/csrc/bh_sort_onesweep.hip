@@ -476,19 +476,26 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
     const float4 q = posm[(int)(((u64)(tid + 1) * (u64)n) / (u64)nb)];
     sk = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
   }
+  __shared__ u32 rnk[256];
   if (tid < 256) {
     raw[tid] = sk;
     cnt[tid] = 0;
+    rnk[tid] = 0;
   }
   __syncthreads();
-  if (tid < 256) {
-    int rank = 0;
-    for (int c = 0; c < 256; c++) {
+  {  // rank sort of the <= 255 splitters, four threads per splitter (64 comparisons each: this serial loop is
+     // most of the kernel at small n, where the grid is a handful of blocks)
+    const int t = tid & 255, q = tid >> 8;
+    const u64 mine = raw[t];
+    int part = 0;
+    for (int c = 64 * q; c < 64 * q + 64; c++) {
       const u64 o = raw[c];
-      rank += (o < sk || (o == sk && c < tid)) ? 1 : 0;
+      part += (o < mine || (o == mine && c < t)) ? 1 : 0;
     }
-    sp[rank] = sk;
+    if (part) atomicAdd(&rnk[t], (u32)part);
   }
+  __syncthreads();
+  if (tid < 256) sp[rnk[tid]] = sk;
   __syncthreads();
   if (blockIdx.x == 0 && tid < 256) splitters[tid] = sp[tid];
 #pragma unroll
