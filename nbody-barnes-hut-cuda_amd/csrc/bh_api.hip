@@ -190,7 +190,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->cb, N + 4) == hipSuccess;
-  ok = ok && dalloc(&c->ttot, 2 * (N / 1024 + 2)) == hipSuccess;
+  ok = ok && dalloc(&c->ttot, 2 * (N / 256 + 2)) == hipSuccess;
   ok = ok && dalloc(&c->blk_done, 2 * BH_BLKDONE_STRIDE(N)) == hipSuccess;
   ok = ok && hipMemset(c->blk_done, 0, 2 * BH_BLKDONE_STRIDE(N) * sizeof(u32)) == hipSuccess;
   c->blk_done2 = c->blk_done ? c->blk_done + BH_BLKDONE_STRIDE(N) : nullptr;

@@ -138,9 +138,10 @@ struct bh_ctx {
   int* pn;        // [n] its child count (0: j represents no emitted cell)
   int* cb;        // [n] offset of the cell's child block inside its 1024-pair tile (exclusive scan of the
                   // even-rounded pn within the tile)
-  u32* blk_done;  // [2][n / 32768 + 4] block counters of bh_last_block: pairs_kernel, then (blk_done2) integrate_kernel
+  u32* blk_done;  // [2][n / 8192 + 4] block counters of bh_last_block: pairs_kernel, then (blk_done2) integrate_kernel
   u32* blk_done2;
-  int* ttot;      // [2 * (n / 1024 + 2)] child entries per pair tile, then their exclusive prefix (tile bases)
+  int* ttot;      // [2 * (n / 256 + 2)] child entries per pair tile (1024 or 256 pairs), then their exclusive
+                  // prefix (tile bases)
   bh_node* rec;   // [rec_cap] tree records (canonical: ABI download, strict/counting kernels)
   bh_frec* frec;  // [BH_FREC_POOL] digests for the fast force kernel (written by COM, pair layout): tree records,
                   // then BH_BODY_DIGEST slots (used only for the bodies of unsplit multi-body cells)
@@ -189,7 +190,9 @@ struct bh_ctx {
 #define BH_FORCE_BLOCK_DEFAULT 64  // one wave per workgroup: a CU slot frees as soon as its wave retires (-2 % at 1M)
 #define BH_BBOX_BLOCKS 1024
 #define BH_INTEGRATE_TILE 4096  // bodies per integrate block (1024 threads x 4)
-#define BH_BLKDONE_STRIDE(n) ((size_t)(n) / 32768 + 4)
+#define BH_PAIR_SMALL_N 163840  // bodies up to which the tree build uses 256-pair tiles (A/B per step: 16,384 -15 us,
+                                // 65,536 -14 us, 125,000 -8 us, 262,144 +5 us)
+#define BH_BLKDONE_STRIDE(n) ((size_t)(n) / 8192 + 4)  // one counter per 32 tiles of >= 256 pairs
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
 #ifndef BH_SORT_TILE
 #define BH_SORT_TILE 4096  // keys per sort tile

@@ -348,8 +348,9 @@ __device__ unsigned long long g_tree_trace[2][8192][8];
 #else
 #define TT_STAMP(kern, k)
 #endif
-constexpr int kPairTile = 1024;
-constexpr int kPairWin = 3 * kPairTile;
+constexpr int kPairTile = 1024;            // pairs per block (template parameter TILE: 1024, or 256 for small n)
+constexpr int kHalo = 1024;                // window positions either side of the tile = the largest "narrow" cell
+constexpr int kPairWin = 3 * kPairTile;    // LDS window slots (TILE 256 uses the first 256 + 2 * kHalo of them)
 constexpr int kPairWords = kPairWin / 64;  // 48
 constexpr int kPairLevels = 23;            // v = -1 .. 21
 
@@ -470,15 +471,21 @@ __device__ __forceinline__ void mask_levels(int dv, u32& lo, u32& hi) {
 
 static_assert(kPairLevels == 23, "mask_levels writes exactly 23 levels");
 
-// fill the LDS window: dl[s] = d[base + s] (-1 outside [0, n]) and the per-level masks
+// fill the LDS window: dl[s] = d[base + s] (-1 outside [0, n]) and the per-level masks.  TILE < kPairTile: only the
+// first TILE + 2 kHalo slots belong to the window; the rest reads as d = 127 (no mask bit: a search that runs into
+// it finds nothing, exactly like one that runs off the full window)
+template <int TILE>
 __device__ __forceinline__ void build_window(const signed char* __restrict__ d, int n, int base,
                                              u64 (*m)[kPairWords], signed char* dl) {
+  constexpr int kUsed = TILE + 2 * kHalo;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // one 16-byte load per thread (192 threads cover the window); a byte-per-thread loop compiles
   // to 12 serialized global round trips per block and dominated this kernel
   for (int s = threadIdx.x * 16; s < kPairWin; s += 256 * 16) {
     const int g0 = base + s;
-    if (g0 >= 0 && g0 + 15 <= n) {
+    if (s >= kUsed) {
+      *reinterpret_cast<uint4*>(dl + s) = make_uint4(0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu);
+    } else if (g0 >= 0 && g0 + 15 <= n) {
       *reinterpret_cast<uint4*>(dl + s) = *reinterpret_cast<const uint4*>(d + g0);
     } else {
 #pragma unroll
@@ -492,14 +499,17 @@ __device__ __forceinline__ void build_window(const signed char* __restrict__ d, 
   // level v's ballot goes into lane v + 1 of a register pair (v_writelane), then ONE store per word by lanes
   // 0..22 — the lane-0 store per level (exec save / move / store / restore) was most of the window build
   for (int w = wv; w < kPairWords; w += 4) {
-    const int dv = dl[w * 64 + lane];
     u32 lo = 0u, hi = 0u;
-    mask_levels(dv, lo, hi);
+    if (w * 64 < kUsed) {  // wave-uniform
+      const int dv = dl[w * 64 + lane];
+      mask_levels(dv, lo, hi);
+    }
     if (lane < kPairLevels) m[lane][w] = ((u64)hi << 32) | (u64)lo;
   }
   __syncthreads();
 }
 
+template <int TILE>
 __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
                                                     const signed char* __restrict__ d, int n, int B, int D,
                                                     int cap, const u64* __restrict__ ksamp, int ns, int ss,
@@ -509,26 +519,26 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
                                                     u32* __restrict__ done_count,
                                                     bh_devinfo* __restrict__ info) {
   __shared__ u64 s_samp[kSampMax];
-  __shared__ __attribute__((aligned(16))) int pnl[kPairTile];  // child counts of the tile's pairs
+  __shared__ __attribute__((aligned(16))) int pnl[TILE];  // child counts of the tile's pairs
   __shared__ u64 m[kPairLevels][kPairWords];
   __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
-  const int t0 = blockIdx.x * kPairTile;
-  const int base = t0 - kPairTile;  // global position of window slot 0
+  const int t0 = blockIdx.x * TILE;
+  const int base = t0 - kHalo;  // global position of window slot 0
   const int lane = threadIdx.x & 63;
   TT_STAMP(0, 0)
-  build_window(d, n, base, m, dl);
+  build_window<TILE>(d, n, base, m, dl);
   TT_STAMP(0, 1)
 
-  __shared__ int wide[kPairTile];  // window slots of the pairs whose cell leaves the window
+  __shared__ int wide[TILE];  // window slots of the pairs whose cell leaves the window
   __shared__ int nwide;
   if (threadIdx.x == 0) nwide = 0;
-  for (int q = threadIdx.x; q < kPairTile; q += 256) pnl[q] = 0;
+  for (int q = threadIdx.x; q < TILE; q += 256) pnl[q] = 0;
   __syncthreads();
 
   int cells = 0, maxl = 0;
 #pragma unroll 1
-  for (int r = 0; r < kPairTile / 256; r++) {
-    const int p = kPairTile + r * 256 + (int)threadIdx.x;  // window slot
+  for (int r = 0; r < TILE / 256; r++) {
+    const int p = kHalo + r * 256 + (int)threadIdx.x;  // window slot
     const int j = base + p;
     if (j >= n) break;
     int nc = 0;
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       wide[atomicAdd(&nwide, 1)] = p;  // list order is irrelevant: results are keyed by j
     } else {
       pn[j] = nc;
-      pnl[p - kPairTile] = nc;
+      pnl[p - kHalo] = nc;
     }
   }
   __syncthreads();
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
         nc = __popcll((bal >> (lane & ~15)) & 0xffull);
       if (sub == 0) {
         pn[j] = nc;
-        pnl[p - kPairTile] = nc;
+        pnl[p - kHalo] = nc;
         if (nc) {
           pa[j] = a;
           pb[j] = b;
@@ -615,10 +625,15 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   __shared__ int s_ws[4];
   __syncthreads();
   {
-    const int q0 = threadIdx.x * 4;
-    const int4 c4 = *reinterpret_cast<const int4*>(pnl + q0);
-    const int v0 = (c4.x + 1) & ~1, v1 = (c4.y + 1) & ~1, v2 = (c4.z + 1) & ~1, v3 = (c4.w + 1) & ~1;
-    const int sum = v0 + v1 + v2 + v3;
+    constexpr int kPer = TILE / 256;  // consecutive pairs per thread: 4 or 1
+    const int q0 = threadIdx.x * kPer;
+    int v[kPer];
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+      v[q] = (pnl[q0 + q] + 1) & ~1;
+      sum += v[q];
+    }
     int incl = sum;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
@@ -631,12 +646,11 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
     int ex = incl - sum;
     for (int q = 0; q < wv; q++) ex += s_ws[q];
     const int j0 = t0 + q0;
-    if (j0 + 3 < n) {
-      *reinterpret_cast<int4*>(cb + j0) = make_int4(ex, ex + v0, ex + v0 + v1, ex + v0 + v1 + v2);
-    } else {
-      if (j0 < n) cb[j0] = ex;
-      if (j0 + 1 < n) cb[j0 + 1] = ex + v0;
-      if (j0 + 2 < n) cb[j0 + 2] = ex + v0 + v1;
+    int run = ex;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+      if (j0 + q < n) cb[j0 + q] = run;
+      run += v[q];
     }
     if (threadIdx.x == 255) bh_publish_i32(ttot + blockIdx.x, ex + sum);
   }
@@ -707,12 +721,11 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
 }
 
 // entry offset of the child block of the cell whose representative pair is j
-#define BH_CB(j) (tpre[(j) >> 10] + cb[j])
-static_assert(kPairTile == 1024, "BH_CB shifts by 10");
+#define BH_CB(j) (tpre[(j) >> tshift] + cb[j])  // tshift = log2(TILE) of the build
 
 __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, int D, int cap, float s0,
                                               const int* __restrict__ pn, const int* __restrict__ cb,
-                                              const int* tpre,
+                                              const int* tpre, int tshift,
                                               int c0, int c1, int child_level, int n = 0,
                                               const u64* samp = nullptr, int ns = 0, int ss = 0) {
   bh_node r;
@@ -762,48 +775,6 @@ __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, 
   return r;
 }
 
-// topology fields of the record of child [c0,c1) (window slots) of a cell at level L, resolved
-// with the window masks: the child's branching level Lb is the smallest v > L whose mask has a bit
-// strictly inside the child, and that first bit is the child's representative pair
-__device__ __forceinline__ bh_node make_child_win(u64 (*m)[kPairWords], int base, int B, int D, int cap,
-                                                  float s0, const int* __restrict__ pn,
-                                                  const int* __restrict__ cb, const int* tpre, int c0, int c1,
-                                                  int L) {
-  bh_node r;
-  r.x = r.y = r.z = r.m = 0.0f;
-  const int cnt = c1 - c0;
-  r.first = base + c0;
-  r.count = cnt;
-  if (cnt == 1) {
-    r.kind = BH_KIND_BODY;
-    r.s = -1.0f;  // negative edge: accepted by every theta >= 0
-    return r;
-  }
-  r.kind = BH_KIND_MULTI;
-  if (cnt <= cap) {
-    r.s = ldexpf(s0, -(L + 1));
-    return r;
-  }
-  int Lb = B, jr = -1;
-  for (int v = L + 1; v < B; v++) {
-    const int s = next_set(m[v + 1], c0);
-    if (s >= 0 && s < c1) {
-      Lb = v;
-      jr = s;
-      break;
-    }
-  }
-  if (Lb >= D) {  // never branches above the depth cap: unsplit multi-body cell at level D
-    r.s = ldexpf(s0, -D);
-    return r;
-  }
-  r.kind = BH_KIND_INTERNAL;
-  r.first = BH_BLOCK0 + BH_CB(base + jr);
-  r.count = pn[base + jr];
-  r.s = ldexpf(s0, -Lb);
-  return r;
-}
-
 __device__ __forceinline__ bh_node pad_entry() {
   bh_node r;
   r.x = r.y = r.z = r.m = r.s = 0.0f;
@@ -816,7 +787,7 @@ __device__ __forceinline__ bh_node pad_entry() {
 // cell around it: level Lp = max(d[qa], d[qb]); it starts at the nearest position <= qa with d < Lp and ends at the
 // nearest >= qb with d < Lp; its children are delimited by its positions with d == Lp, so the child's ordinal is
 // the number of those in (start, qa], and the parent's representative pair (*slot) is the first of them.
-// False: there is no parent (the child is the whole system) or the parent is wide (> kPairTile bodies, which
+// False: there is no parent (the child is the whole system) or the parent is wide (> kHalo bodies, which
 // includes every parent that leaves the window) and emits the record itself.
 __device__ __forceinline__ bool parent_slot(u64 (*m)[kPairWords], const signed char* dl, int qa, int qb, int* slot,
                                             int* ord) {
@@ -827,7 +798,7 @@ __device__ __forceinline__ bool parent_slot(u64 (*m)[kPairWords], const signed c
   const u64* mleq = m[Lp + 1];  // d <= Lp
   const int ps = (da < Lp) ? qa : prev_set(mlt, qa);
   const int pe = (db < Lp) ? qb : next_set(mlt, qb);
-  if (ps < 0 || pe < 0 || pe - ps > kPairTile) return false;
+  if (ps < 0 || pe < 0 || pe - ps > kHalo) return false;
   *ord = (qa == ps) ? 0 : 1 + count_between(mleq, ps, qa);
   *slot = next_set(mleq, ps);
   return true;
@@ -835,6 +806,7 @@ __device__ __forceinline__ bool parent_slot(u64 (*m)[kPairWords], const signed c
 
 // ttot[tp_off ..] = tile bases (exclusive scan of the per-tile child-entry totals, written by the last block of
 // pairs_kernel); tpre[ntiles] = all entries
+template <int TILE>
 __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
                                                    const signed char* __restrict__ d, int n, int B, int D,
                                                    int cap, const u64* __restrict__ ksamp, int ns, int ss,
@@ -850,12 +822,14 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   __shared__ u64 m[kPairLevels][kPairWords];
   __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
   const int* __restrict__ tpre = ttot + tp_off;
-  const int t0 = blockIdx.x * kPairTile;
-  const int base = t0 - kPairTile;
+  constexpr int tshift = (TILE == 1024) ? 10 : 8;
+  static_assert(TILE == 1024 || TILE == 256, "tile shift");
+  const int t0 = blockIdx.x * TILE;
+  const int base = t0 - kHalo;
   TT_STAMP(1, 0)
-  build_window(d, n, base, m, dl);
+  build_window<TILE>(d, n, base, m, dl);
   TT_STAMP(1, 1)
-  __shared__ int wide[kPairTile];
+  __shared__ int wide[TILE];
   __shared__ int nwide;
   if (threadIdx.x == 0) nwide = 0;
   __syncthreads();
@@ -864,7 +838,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     const int E = BH_BLOCK0 + tpre[ntiles];
     info->n_entries = E;
     if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
-    rec[0] = make_child(k, B, D, cap, s0, pn, cb, tpre, 0, n, 0);
+    rec[0] = make_child(k, B, D, cap, s0, pn, cb, tpre, tshift, 0, n, 0);
     er_lo[0] = 0;
     er_hi[0] = n;
     rec[1] = pad_entry();  // child blocks start at even entries (BH_BLOCK0)
@@ -877,10 +851,10 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   // with each parent resolving its <= 8 children one after the other — a level-by-level mask search per internal
   // child and a divergent loop, the wave waiting for its slowest lane: 29 of this kernel's 41 us per block.)
   // The thread's four pairs go through the passes together, so that the global loads of a pass are all in flight
-  // at once.  Cells of more than kPairTile bodies are "wide": their thread emits ALL their children in phase 2
+  // at once.  Cells of more than kHalo bodies are "wide": their thread emits ALL their children in phase 2
   // (key searches); the rule depends on the cell alone, so the threads of its children — possibly in other blocks
-  // — reach the same verdict.  A narrow cell lies inside this block's window: |a - j|, |b - j| <= kPairTile.
-  constexpr int kR = kPairTile / 256;
+  // — reach the same verdict.  A narrow cell lies inside this block's window: |a - j|, |b - j| <= kHalo.
+  constexpr int kR = TILE / 256;
   int nc_[kR], e_[kR], a_[kR], b_[kR], jp_[kR], ord_[kR];
   int jl_[kR], ordl_[kR], cntl_[kR];  // the leaf starting at body j: parent's pair, ordinal, bodies
 #pragma unroll
@@ -899,7 +873,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   }
 #pragma unroll
   for (int r = 0; r < kR; r++) {
-    const int p = kPairTile + r * 256 + (int)threadIdx.x;
+    const int p = kHalo + r * 256 + (int)threadIdx.x;
     const int j = base + p;
     // ---- the leaf that starts at body j (leaf_cap = 1)
     if (cap == 1 && j < n) {
@@ -922,7 +896,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     if (nc > 8 || e + nc > rec_cap) continue;  // cannot happen (records <= 2n); flagged by thread 0 if it did
     const int L = dl[p];
     const int qa = a - base, qb = b - base;
-    if (b - a > kPairTile) {
+    if (b - a > kHalo) {
       wide[atomicAdd(&nwide, 1)] = p;
       continue;
     }
@@ -986,7 +960,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   }
 #pragma unroll
   for (int r = 0; r < kR; r++) {
-    const int p = kPairTile + r * 256 + (int)threadIdx.x;
+    const int p = kHalo + r * 256 + (int)threadIdx.x;
     if (ep_[r] < rec_cap) {
       bh_node rr;
       rr.x = rr.y = rr.z = rr.m = 0.0f;
@@ -1044,7 +1018,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       if (nonempty) {
         const int e = BH_BLOCK0 + BH_CB(j) + __popcll(grp & ((1ull << sub) - 1ull));
         if (e < rec_cap) {
-          rec[e] = make_child(k, B, D, cap, s0, pn, cb, tpre, l, nxt, L + 1, n, s_samp, ns, ss);
+          rec[e] = make_child(k, B, D, cap, s0, pn, cb, tpre, tshift, l, nxt, L + 1, n, s_samp, ns, ss);
           er_lo[e] = l;
           er_hi[e] = nxt;
         }
@@ -1224,14 +1198,26 @@ hipError_t bhk_build(bh_ctx* c) {
   while (((n + (1 << ss) - 1) >> ss) > kSampMax) ss++;
   const int ns = (n + (1 << ss) - 1) >> ss;
   lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info);
-  const int ntiles = (n + kPairTile - 1) / kPairTile;
-  const int tp_off = n / 1024 + 2;
-  pairs_kernel<<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
-                                              c->pn, c->cb, c->ttot, tp_off, c->blk_done, c->info);
+  // 1024 pairs per block; 256 up to 163,840 bodies, where n / 1024 blocks leave most of the 256 CUs idle and a
+  // block's four rounds are pure latency (65,536 bodies: pairs 22 -> 13 us, emit 28 -> 15 us); the halo stays 1024
+  const int tile = (n <= BH_PAIR_SMALL_N) ? 256 : kPairTile;
+  const int ntiles = (n + tile - 1) / tile;
+  const int tp_off = n / tile + 2;
   // child-block offsets = tile base (ttot[tp_off ..]) + offset in the tile (cb[]), both written by pairs_kernel
-  emit_kernel<<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
-                                             c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds, c->rec, c->er_lo,
-                                             c->er_hi, c->rec_cap, c->info);
+  if (tile == 256) {
+    pairs_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
+                                                     c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done, c->info);
+    emit_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
+                                                    c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds, c->rec,
+                                                    c->er_lo, c->er_hi, c->rec_cap, c->info);
+  } else {
+    pairs_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
+                                                           c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
+                                                           c->info);
+    emit_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
+                                                          c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds,
+                                                          c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
+  }
   return hipGetLastError();
 }
 
