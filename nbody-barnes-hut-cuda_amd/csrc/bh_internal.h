@@ -185,7 +185,8 @@ struct bh_ctx {
 // number of children is followed by one padding entry), so a block never straddles more 64-byte lines than
 // it has to: the force kernel's scalar loads are bound by the number of cache-line requests.
 // Entries <= root + bodies + cells + one pad per cell <= 3n.
-#define BH_REC_CAP(n) (3 * (n) + 8)
+// EVEN: BH_BODY_DIGEST blocks start at rec_cap + 2 lo and a child block must start at an even record (64-byte pair)
+#define BH_REC_CAP(n) ((3 * (n) + 8 + 1) & ~1)
 #define BH_BLOCK0 2  // first child block
 #define BH_FORCE_BLOCK_DEFAULT 64  // one wave per workgroup: a CU slot frees as soon as its wave retires (-2 % at 1M)
 #define BH_BBOX_BLOCKS 1024

@@ -136,6 +136,36 @@ def _check(ic, world, steps, tol_pos=5e-2, tol_med=1e-4):
     return e
 
 
+def test_dd_eight_ranks_vs_the_oracle_itself():
+    """the domain-decomposed step against the CPU ORACLE (not against a single HIP context): 8 ranks in-process,
+    65,536 Plummer bodies (BASELINE configs[0] size), K = 5 whole steps vs oracle.Oracle.step from identical
+    inputs.  Same distribution form as tests/test_gpu_fullsize.py; the stitched tree accepts the same cells, the
+    fp32 summation order differs (top tree first, LET segments interleaved).  Stated tolerance after 5 steps:
+        |dx| median <= 3.1e-5, p99.99 <= 2e-4, max <= 5e-4;  |dv| median <= 1e-6, p99.99 <= 4e-5, max <= 2e-4;
+        first-step... last-step accelerations: relative median <= 4e-6"""
+    import oracle as O
+    pkg = bhpkg.load()
+    n, K, world = 65536, 5, 8
+    ic = pkg.plummer(n, seed=42)
+    out = run_ranks(world, ic, K)
+    p, v, a = merge(out, n)
+    o = O.Oracle(n, O.params(key_curve=pkg.default_params().key_curve))
+    o.upload(*ic)
+    o.step(K, order=O.ORDER_BATCHED)
+    w = np.stack(o.download(), 1).astype(np.float64)
+    oa = np.stack(o.download_acc(), 1)
+    o.close()
+    dx = np.abs(p.astype(np.float64) - w[:, :3]).max(axis=1)
+    dv = np.abs(v.astype(np.float64) - w[:, 3:]).max(axis=1)
+    e = rel(a, oa)
+    print(f"DD x8 vs oracle, n={n} K={K}: |dx| p50 {np.median(dx):.3e} p99.99 {np.percentile(dx, 99.99):.3e} max {dx.max():.3e}; "
+          f"|dv| p50 {np.median(dv):.3e} p99.99 {np.percentile(dv, 99.99):.3e} max {dv.max():.3e}; "
+          f"acc rel p50 {np.median(e):.3e} max {e.max():.3e}")
+    assert np.median(dx) <= 3.1e-5 and np.percentile(dx, 99.99) <= 2e-4 and dx.max() <= 5e-4
+    assert np.median(dv) <= 1e-6 and np.percentile(dv, 99.99) <= 4e-5 and dv.max() <= 2e-4
+    assert np.median(e) <= 4e-6
+
+
 def test_dd_disc_initial_conditions():
     """the reference's thin rotating disc (ref:297-307): strongly anisotropic domains"""
     pkg = bhpkg.load()
@@ -238,8 +268,11 @@ def test_dd_abi_argument_and_order_checks():
             e.dd_upload(*pkg.plummer(60000, seed=1), np.arange(60000, dtype=np.int32))  # above the capacity
 
 
-def test_dd_malformed_let_record_is_closed_and_reported():
-    """hang/fault safety of the first unattended multi-GPU run: a gathered LET record whose child block
+@pytest.mark.parametrize("how", ["pointer", "nan_threshold"])
+def test_dd_malformed_let_record_is_closed_and_reported(how):
+    """(how = nan_threshold: the record's opening threshold is NaN as well — the walk's `d2 > thr2` is then never
+    true, so the record is ALWAYS opened; the validation must not mistake it for a closed one.)
+    hang/fault safety of the first unattended multi-GPU run: a gathered LET record whose child block
     points outside its own segment is closed by the validation pass of bh_dd_top (never opened), the sticky
     flag BH_FLAG_DD_LET_INVALID is raised, bh_sync returns BH_ERR_DEVICE_FLAG, and the next step's
     bh_dd_migrate_apply refuses to go on.  (The corrupted pointer stays inside the pool, so even a missing
@@ -271,6 +304,8 @@ def test_dd_malformed_let_record_is_closed_and_reported():
                 cand = torch.nonzero((thr[300:] >= 0) & (seg[300:, 12] > 0))  # an openable record of the block area
                 if len(cand) > 0:   # (a segment sent closed because it did not fit carries no blocks: wait for the retry)
                     seg[300 + int(cand[0]), 10] = 2                       # child block -> the local tree's first block
+                    if how == "nan_threshold":
+                        seg.view(torch.float32)[300 + int(cand[0]), 8] = float("nan")
                     CorruptingComm.hits += 1
             g.barrier.wait()
 

@@ -285,6 +285,32 @@ def test_force_fast_edge_cases(pkg, orc, name, variant):
     e.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n", [777, 5001, 5002])
+@pytest.mark.parametrize("kw", [dict(leaf_cap=4), dict(leaf_cap=8), dict(max_depth=3), dict(leaf_cap=3, max_depth=5)])
+def test_force_fast_unsplit_cells_odd_and_even_n(pkg, orc, kw, n, variant):
+    """unsplit multi-body cells (leaf_cap > 1 / depth cap): their bodies' digests form child blocks in the second
+    region of the digest pool, which must start at EVEN records whatever the parity of n (round 2 had
+    rec_cap = 3n + 8: odd for odd n, every such block then straddled two 64-byte pairs and its bodies exerted
+    no force).  Both fast walks vs the oracle; a body with all its neighbours missing would be off by O(1)."""
+    ic = pkg.plummer(n, seed=9)
+    e = _engine(pkg, ic, force_variant=variant, **kw)
+    e.tree_stages(); e.force()
+    ga = np.stack(e.download_acc(), 1)
+    rec = e.download_tree()
+    assert (rec["kind"] == orc.KIND_MULTI).sum() > 0   # the case under test is present
+    p = oparams(orc, e.params)
+    o = oracle_pipeline(orc, ic, p)
+    oacc, *_ = orc.force(o["rec"], o["xyzm"], p, orc.ORDER_PREORDER)
+    oa = np.zeros((n, 3), np.float32)
+    oa[o["perm"]] = oacc[:, :3]
+    rel = np.linalg.norm(ga - oa, axis=1) / np.linalg.norm(oa, axis=1)
+    assert np.median(rel) <= 2e-6 and rel.max() <= 5e-4, (np.median(rel), rel.max())
+    st = e.stats()
+    assert st.status_flags == 0
+    e.close()
+
+
 @pytest.mark.parametrize("theta", [0.0, 0.2, 0.5, 1.0])
 def test_force_block_sizes_agree(pkg, orc, theta):
     """the wave is the unit of work: 64-, 128- and 256-thread workgroups give identical results"""
