@@ -95,7 +95,8 @@ typedef struct bh_params {
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:
  * entry 0 is the root; the children of an internal entry are the `count`
- * consecutive entries starting at `first` (ascending octant digit, empty
+ * consecutive entries starting at `first` (ascending key digit — the octant digit
+ * x<<2|y<<1|z with Morton keys, the Hilbert digit with key_curve = 1 — empty
  * octants omitted); `first` is always even (BH_KIND_PAD entries fill the gaps).
  * Replaces `struct OctreeNode` (ref:20-28, 76 B). */
 #define BH_KIND_BODY 0     /* exactly one body: (x,y,z,m) is the body, s = 0, first = sorted body index */

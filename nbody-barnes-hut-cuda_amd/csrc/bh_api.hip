@@ -489,16 +489,20 @@ static void drop_graphs(bh_ctx* c) {
     }
 }
 
-// The reference's step is one function with one synchronisation (ref:255-283); here it is ~27 kernels on two
+// The reference's step is one function with one synchronisation (ref:255-283); here it is 12 kernels on two
 // streams whose arguments never change from step to step except for the ping-pong parity of the body arrays
 // (the sort gathers cur -> cur^1): one HIP graph per parity, captured the first time that parity is stepped
 // and replayed afterwards.  Not used while per-stage timing is on (event records between the stages), in
-// domain-decomposed mode (body count changes) or with BH_NO_GRAPH set.  OPT-IN (bh_params.step_graph = 1):
+// domain-decomposed mode (body count changes) (design-study builds, -DBH_STUDY, also honour BH_NO_GRAPH).  OPT-IN (bh_params.step_graph = 1):
 // on ROCm 7.2 the replay measured SLOWER than the plain launches (1.93 vs 1.85 ms at 1M bodies, 0.66 vs 0.57 ms
 // at 65,536: graph kernel nodes are dispatched with more packet overhead than back-to-back stream launches).
 int bh_step(bh_ctx* c) {
   BH_NEED(c, BH_ST_UPLOADED);
+#ifdef BH_STUDY
   static const bool env_off = getenv("BH_NO_GRAPH") != nullptr;
+#else
+  constexpr bool env_off = false;
+#endif
   if (c->timing || c->dd || c->p.step_graph != 1 || env_off || c->graph_failed) return step_launch(c);
   const int par = c->cur;
   if (!c->gexec[par]) {

@@ -1,4 +1,4 @@
-// bh_force.hip — wave-cooperative Barnes-Hut tree traversal (the hot kernel) + integrate.
+// bh_force.hip — wave-cooperative Barnes-Hut tree traversal (the hot kernel), pack / unpack kernels.
 //
 // Reference: computeForceKernel nbody_v5_bench.cu:191-225 (one thread per body, private
 // int stack[64] in scratch, AoS 76-byte nodes, bodies in random order inside a warp) and
@@ -9,30 +9,30 @@
 //   any other cell is opened and its children are visited.
 //
 // MI355X design
-//   * one wave64 owns 64 Morton-consecutive bodies (one per lane) and walks ONE shared
-//     traversal: the record being tested is wave-uniform, so it is fetched once per wave
-//     with scalar loads (s_load_dwordx8 into SGPRs, via the constant address space) instead
-//     of 64 times, and feeds the VALU as SGPR operands;
-//   * every lane applies the reference's per-body MAC exactly; a lane that accepted an
-//     ancestor is simply masked off below it.  `__ballot(active && !accept)` is the set of
-//     lanes that still need a cell opened; if it is non-empty the (child block, lane mask)
-//     pair is pushed on the wave's stack.  Per-lane results therefore equal the per-body
-//     recurrence of the CPU oracle (same interactions, deterministic order);
-//   * the wave's stack lives in registers ACROSS LANES: entry j is held by lane j&63 of
-//     VGPR set j>>6 (v_writelane / v_readlane) — no scratch, no LDS, no memory latency on
-//     push/pop.  3 sets = 192 entries >= the 7*21+1 bound for 63-bit keys;
-//   * children of a cell are one contiguous block of 32-byte records, so an opened cell costs
-//     a few back-to-back scalar loads and up to 8 independent MAC evaluations (ILP);
-//   * blockIdx is remapped so that each XCD walks a contiguous slab of the Morton order and
-//     its private L2 keeps that slab's part of the tree.
+//   * one wave64 owns 64 key-consecutive bodies (Hilbert order by default; one per lane) and walks ONE shared
+//     traversal: the record being tested is wave-uniform, so it is fetched once per wave with scalar loads
+//     (s_load_dwordx16 = one 64-byte digest pair, via the constant address space) instead of 64 times, and
+//     feeds the VALU as SGPR operands;
+//   * every lane applies the reference's per-body MAC exactly; a lane that accepted an ancestor is simply
+//     masked off below it.  The set of lanes that still need a cell opened is the (EXEC-restricted) result of
+//     the compare; if it is non-empty the (child block, lane mask) pair is pushed on the wave's stack.  Per-lane
+//     results therefore equal the per-body recurrence of the CPU oracle (same interactions, fixed order);
+//   * the wave's stack lives in registers ACROSS LANES: entry j is held by lane j of four VGPRs
+//     (v_writelane / v_readlane) — no scratch, no LDS, no memory latency on push/pop.  64 entries cover every
+//     tree seen in practice; a wave that needs more redoes its walk with the generic loop's 192 entries
+//     (>= the 7*21+1 bound for 63-bit keys);
+//   * children of a cell are one contiguous, 64-byte-aligned block of digest pairs, so an opened cell costs
+//     two or four back-to-back scalar loads and up to 4 packed pair evaluations;
+//   * blockIdx is remapped (block_chunk) so that the waves of an XCD share parts of the tree in its private L2.
+// force_kernel<STRICT, COUNT> below is the plain per-record loop on the canonical 32-byte records (bit-exact
+// reference arithmetic, V/O/P counters); force_fast_kernel is the benchmarked one.  integrate lives in bh_tree.hip.
 #include <stdlib.h>
 
 #include "bh_internal.h"
 
 namespace {
 
-// Wave-uniform reads go through the constant address space so the backend selects scalar
-// loads (s_load_dwordx4/x8 into SGPRs); the eight dwords of a record are merged into one.
+// Wave-uniform reads go through the constant address space so the backend selects scalar loads
 typedef __attribute__((address_space(4))) const float cfloat_t;
 
 __device__ __forceinline__ bh_node load_rec(cfloat_t* base, int e) {
@@ -420,12 +420,10 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_M3(DZ, Z) "v_pk_add_f32 " DZ ", " Z ", v[18:19] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
 #define BH_M4(DX) "v_pk_fma_f32 v[38:39], " DX ", " DX ", v[20:21]\n"
 #define BH_M5(DY) "v_pk_fma_f32 v[38:39], " DY ", " DY ", v[38:39]\n"
-#define BH_M7(MA, T0) "v_cmp_lt_f32_e64 " MA ", " T0 ", v38\n"
-#define BH_M8(MB, T1) "v_cmp_lt_f32_e64 " MB ", " T1 ", v39\n"
+#define BH_M7(MA, T0) "v_cmp_ge_f32_e64 " MA ", " T0 ", v38\n"
+#define BH_M8(MB, T1) "v_cmp_ge_f32_e64 " MB ", " T1 ", v39\n"
 #define BH_M9(R0, R1) "v_rsq_f32 " R0 ", v38\n v_rsq_f32 " R1 ", v39\n"
-#define BH_CHK(q, MA, MB)                                                                                \
-  "s_andn2_b64 s[26:27], exec, " MA "\n s_cbranch_scc1 L_pushA" #q "_%=\n"                                \
-  "s_andn2_b64 s[26:27], exec, " MB "\n s_cbranch_scc1 L_pushB" #q "_%=\n"
+#define BH_CHK(q, MA, MB) "s_or_b64 s[26:27], " MA ", " MB "\n s_cbranch_scc1 L_push" #q "_%=\n"
 #define BH_MAC_(q, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1)                                       \
   BH_M1(DX, X) BH_M2(DY, Y) BH_M3(DZ, Z) BH_M4(DX) BH_M5(DY) BH_M5(DZ) BH_M7(MA, T0) BH_M8(MB, T1)        \
   BH_M9(R0, R1) BH_CHK(q, MA, MB)
@@ -438,7 +436,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_F2(R) "v_pk_mul_f32 " R ", " R ", " R "\n"
 #define BH_F3(R) "v_pk_mul_f32 v[40:41], v[40:41], " R "\n"
 #define BH_FA(D, A) "v_pk_fma_f32 " A ", v[40:41], " D ", " A "\n"
-#define BH_FM(MA, MB) "v_cndmask_b32_e64 v40, 0, v40, " MA "\n v_cndmask_b32_e64 v41, 0, v41, " MB "\n"
+#define BH_FM(MA, MB) "v_cndmask_b32_e64 v40, v40, 0, " MA "\n v_cndmask_b32_e64 v41, v41, 0, " MB "\n"
 #define BH_SEG_(LBL, MASK, qm, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1) \
   LBL ":\n"                                                                                               \
   BH_M1(DX, X) BH_F1(GM, FR) BH_M2(DY, Y) BH_F2(FR) BH_M3(DZ, Z) BH_F3(FR) BH_M4(DX) MASK(FMA, FMB)       \
@@ -454,7 +452,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   LBL ":\n" BH_F1(GM, FR) BH_F2(FR) BH_F3(FR) MASK(FMA, FMB) BH_FA(FDX, "v[42:43]") BH_FA(FDY, "v[44:45]") \
   BH_FA(FDZ, "v[46:47]")
 #define BH_LAST(...) BH_X(BH_LAST_, __VA_ARGS__)
-#define BH_PUSH1(FIRST, META)                                                                            \
+#define BH_PUSH1(FIRST, META, MLO, MHI)                                                                         \
   "s_mov_b32 m0, s30\n"                                                                                   \
   "s_add_u32 s30, s30, 1\n"                                                                               \
   ".if %c[stats] == 0\n"                                                                                  \
@@ -463,22 +461,25 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   ".endif\n"                                                                                              \
   "v_writelane_b32 v48, " FIRST ", m0\n"                                                                  \
   "v_writelane_b32 v49, " META ", m0\n"                                                                   \
-  "v_writelane_b32 v50, s26, m0\n"                                                                        \
-  "v_writelane_b32 v51, s27, m0\n"
-// a pair with at least one opened record: push, then continue in the masked variant of its force half
-#define BH_ARMS_(q, MB, F0, M0, F1, M1)                                                                  \
-  "L_pushA" #q "_%=:\n" BH_PUSH1(F0, M0)                                                                  \
-  "s_andn2_b64 s[26:27], exec, " MB "\n"                                                                  \
-  "s_cbranch_scc0 L_segm" #q "_%=\n"                                                                      \
-  "L_pushB" #q "_%=:\n" BH_PUSH1(F1, M1)                                                                  \
+  "v_writelane_b32 v50, " MLO ", m0\n"                                                                   \
+  "v_writelane_b32 v51, " MHI ", m0\n"
+// a pair with at least one opened record: push the opened one(s), then continue in the masked variant of its
+// force half.  MA / MB are the pair's OPEN masks (v_cmp_nlt under EXEC = the block's lane mask).
+#define BH_ARMS_(q, MA, MALO, MAHI, MB, MBLO, MBHI, F0, M0, F1, M1)                                       \
+  "L_push" #q "_%=:\n"                                                                                    \
+  "s_cmp_eq_u64 " MA ", 0\n"                                                                              \
+  "s_cbranch_scc1 L_pushB" #q "_%=\n" BH_PUSH1(F0, M0, MALO, MAHI)                                         \
+  "s_cmp_eq_u64 " MB ", 0\n"                                                                              \
+  "s_cbranch_scc1 L_segm" #q "_%=\n"                                                                      \
+  "L_pushB" #q "_%=:\n" BH_PUSH1(F1, M1, MBLO, MBHI)                                                      \
   "s_branch L_segm" #q "_%=\n"
 // pair p of the window: x s[36+16p:37+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11, meta +12/+13
 #define BH_P0 "s[36:37]", "s[38:39]", "s[40:41]", "s44", "s45"
 #define BH_P1 "s[52:53]", "s[54:55]", "s[56:57]", "s60", "s61"
 #define BH_P2 "s[68:69]", "s[70:71]", "s[72:73]", "s76", "s77"
 #define BH_P3 "s[84:85]", "s[86:87]", "s[88:89]", "s92", "s93"
-#define BH_PRO_ALL BH_PRO(0, BH_S0, BH_P0) BH_PRO(1, BH_S1, BH_P1) BH_PRO(2, BH_S0, BH_P2)               \
-  "L_pro3_%=:\n" BH_MAC(3, BH_S1, BH_P3)
+#define BH_PRO_SMALL BH_PRO(0, BH_S0, BH_P0) BH_PRO(1, BH_S1, BH_P1)
+#define BH_PRO_BIG BH_PRO(2, BH_S0, BH_P2) "L_pro3_%=:\n" BH_MAC(3, BH_S1, BH_P3)
 #define BH_SEG_ALL                                                                                       \
   BH_SEG(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEG(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)             \
   BH_SEG(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0) BH_LAST("L_seg0_%=", BH_NOMASK, BH_S0, "s[42:43]")
@@ -486,20 +487,24 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   BH_SEGM(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEGM(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)           \
   BH_SEGM(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0)                                                          \
   "L_segm0_%=:\n" BH_STAT_MASKED BH_LAST("L_segmx0_%=", BH_FM, BH_S0, "s[42:43]") BH_POP_TAIL
+#define BH_MK0 "s[18:19]", "s18", "s19", "s[14:15]", "s14", "s15"  // open masks of set 0 (even pairs)
+#define BH_MK1 "s[12:13]", "s12", "s13", "s[10:11]", "s10", "s11"  // set 1 (odd pairs)
+#define BH_ARMS(...) BH_X(BH_ARMS_, __VA_ARGS__)
 #define BH_ARMS_ALL                                                                                      \
-  BH_ARMS_(3, "s[10:11]", "s94", "s96", "s95", "s97") BH_ARMS_(2, "s[14:15]", "s78", "s80", "s79", "s81") \
-  BH_ARMS_(1, "s[10:11]", "s62", "s64", "s63", "s65") BH_ARMS_(0, "s[14:15]", "s46", "s48", "s47", "s49")
+  BH_ARMS(3, BH_MK1, "s94", "s96", "s95", "s97") BH_ARMS(2, BH_MK0, "s78", "s80", "s79", "s81")          \
+  BH_ARMS(1, BH_MK1, "s62", "s64", "s63", "s65") BH_ARMS(0, BH_MK0, "s46", "s48", "s47", "s49")
 // end of a block: pop the next one (the test of L_pop folded into the loop-back branch)
 #define BH_POP_TAIL "s_sub_u32 s30, s30, 1\n s_cbranch_scc0 L_popb_%=\n s_branch L_done_%=\n"
-// a block of <= 4 children is two cache lines (always fetching four measured +1 %)
-#define BH_SMALL_TEST "s_cmp_gt_u32 s33, 4\n s_cbranch_scc0 L_small_%=\n"
-// jump table in the lanes of v52: lane c = entry offset (from L_pro0) of a block of c children; lanes >= 8
-// keep the 4-pair entry (such a block also trips the "> 8 children" redo); read with one v_readlane
-#define BH_TBL(c, L) "s_mov_b32 s33, " L "-L_pro0_%=\n v_writelane_b32 v52, s33, " #c "\n"
-#define BH_TBL_ALL                                                                                       \
-  "s_mov_b32 s33, L_pro3_%=-L_pro0_%=\n v_mov_b32 v52, s33\n"                                             \
-  BH_TBL(0, "L_end_%=") BH_TBL(1, "L_pro0_%=") BH_TBL(2, "L_pro0_%=") BH_TBL(3, "L_pro1_%=")               \
-  BH_TBL(4, "L_pro1_%=") BH_TBL(5, "L_pro2_%=") BH_TBL(6, "L_pro2_%=")
+// Dispatch on the child count c (s33) by a two-level branch tree — no jump table, no computed jump:
+//   c <= 4: two cache lines are fetched (always fetching four measured +1 %), entry PRO1 (c = 3, 4) or PRO0;
+//   c >= 5: four lines, entry PRO3 (c >= 7; c > 8 also trips the "more than 8 children" redo) or PRO2.
+// The second compare sits between the EXEC write and the wait for the loads.  A block of 0 children is never
+// built, and no record of such a block can be opened: the open test `thr2 >= d2` is false for a null record
+// (thr2 = -1) whatever d2 is, NaN included.
+#define BH_DISPATCH_SMALL                                                                                \
+  "s_mov_b64 exec, s[34:35]\n s_cmp_gt_u32 s33, 2\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro1_%=\n"
+#define BH_DISPATCH_BIG                                                                                  \
+  "s_mov_b64 exec, s[34:35]\n s_cmp_gt_u32 s33, 6\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro3_%=\n"
 
 // Returns false if the 64-entry cross-lane stack overflowed or a block with more than 8 children was met
 // (unsplit cell of > 8 bodies); ax..az are then invalid and the caller redoes the wave.
@@ -529,11 +534,6 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "v_mov_b32 v21, %[eps2]\n"
       "v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
       "v_mov_b32 v48, 0\n v_mov_b32 v49, 0\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n"
-      "s_getpc_b64 s[22:23]\n"
-      "L_here_%=:\n"
-      "s_add_u32 s22, s22, L_pro0_%=-L_here_%=\n"
-      "s_addc_u32 s23, s23, 0\n"
-      BH_TBL_ALL
       "s_mov_b32 s30, 0\n"
       "s_mov_b32 s31, 0\n"
       "s_mov_b32 s16, 0\n"
@@ -546,8 +546,8 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_sub_u32 s30, s30, 1\n"
       "s_cbranch_scc1 L_done_%=\n"
       "L_popb_%=:\n"
-      "v_readlane_b32 s33, v49, s30\n"  // the count first: it is the lane select of the table read below,
-      "v_readlane_b32 s32, v48, s30\n"  // which must come >= 4 instructions after the VALU write of it
+      "v_readlane_b32 s33, v49, s30\n"
+      "v_readlane_b32 s32, v48, s30\n"
       "v_readlane_b32 s34, v50, s30\n"
       "v_readlane_b32 s35, v51, s30\n"
       "s_lshl_b32 s32, s32, 5\n"
@@ -558,10 +558,6 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       ".endif\n"
       "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"
       "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"
-      BH_SMALL_TEST
-      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
-      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
-      "L_small_%=:\n"
       ".if %c[stats]\n"
       "s_add_u32 s17, s17, 1\n"   // blocks popped
       "s_add_u32 s24, s33, 1\n"
@@ -569,15 +565,16 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_min_u32 s24, s24, 4\n"
       "s_add_u32 s16, s16, s24\n"  // pairs evaluated
       ".endif\n"
-      "v_readlane_b32 s33, v52, s33\n"
-      "s_mov_b64 exec, s[34:35]\n"
-      "s_add_u32 s24, s22, s33\n"
-      "s_addc_u32 s25, s23, 0\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      "s_setpc_b64 s[24:25]\n"
-      BH_PRO_ALL
+      "s_cmp_gt_u32 s33, 4\n"
+      "s_cbranch_scc1 L_big_%=\n"
+      BH_DISPATCH_SMALL
+      BH_PRO_SMALL
+      "L_big_%=:\n"
+      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
+      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
+      BH_DISPATCH_BIG
+      BH_PRO_BIG
       BH_SEG_ALL
-      "L_end_%=:\n"  // also the entry of a block of 0 children (never built; every table offset is >= 0)
       BH_POP_TAIL
       BH_SEGM_ALL
       BH_ARMS_ALL
@@ -602,7 +599,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
         "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v16", "v17",
         "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",
         "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
-        "v50", "v51", "v52");
+        "v50", "v51");
   if (STATS) {
     const u64 t1 = __builtin_amdgcn_s_memtime();
     const u64 r1 = __builtin_amdgcn_s_memrealtime();
@@ -826,8 +823,9 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
     else {
       // the frec pool = tree digests + one digest slot per body (bh_internal.h)
       if ((long long)BH_FREC_POOL(c->rec_cap, c->n) >= (1ll << 27)) {
-        // the fast kernel addresses records with 32-bit byte offsets (pool < 4 GiB, ~44M bodies):
-        // beyond that the generic kernel does the same arithmetic on the canonical records
+        // the fast kernel addresses records with 32-bit byte offsets: pool = 5n + 16 records of 32 B < 4 GiB,
+        // i.e. up to ~26.8M bodies per context; beyond that the generic kernel does the same arithmetic on the
+        // canonical records (INTEGRATION.md notes the threshold)
         force_kernel<false, false><<<blocks, 256, 0, c->stream>>>(rec, posm, c->acc, lo, hi, G, th, e2, nullptr, nullptr, nullptr, c->info);
         return hipGetLastError();
       }
@@ -837,7 +835,13 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       const int mode = resolve_xcd_mode(c, hi - lo, group);
       int g2 = ((hi - lo + group - 1) / group * 64 + tpb - 1) / tpb;
       if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
-      static const bool debug_budget = getenv("BH_FORCE_BUDGET") != nullptr;  // bring-up aid: bounded walk
+#ifdef BH_STUDY  // design-study builds only (tools/mkvariant.sh study -DBH_STUDY): bounded walk / occupancy cap
+      static const bool debug_budget = getenv("BH_FORCE_BUDGET") != nullptr;
+      static const int lds_pad = getenv("BH_FORCE_LDS") ? atoi(getenv("BH_FORCE_LDS")) : 0;
+#else
+      constexpr bool debug_budget = false;
+      constexpr int lds_pad = 0;
+#endif
       if (debug_budget)
         force_fast_kernel<0, true><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
                                                               mode, c->info, 0, kTraversalBudget, group);
@@ -845,8 +849,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
         force_fast_kernel<1, false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
                                                                mode, c->info, 0, 0, group);
       else {
-        // design-study knob (tools/occupancy_ab.sh): dynamic LDS bytes per workgroup cap the waves per CU
-        static const int lds_pad = getenv("BH_FORCE_LDS") ? atoi(getenv("BH_FORCE_LDS")) : 0;
+        // lds_pad (BH_STUDY builds, tools/occupancy_ab.sh): dynamic LDS bytes per workgroup cap the waves per CU
         force_fast_kernel<0, false><<<g2, tpb, (size_t)lds_pad, c->stream>>>((const float*)c->frec, posm, c->acc, lo,
                                                                              hi, G, e2, mode, c->info, 0, 0, group);
       }

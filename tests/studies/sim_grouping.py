@@ -75,3 +75,39 @@ report("fixed 32 (2 pairs/instr)", *fixed(32), sub=32)
 report("fixed 16 (4 pairs/instr)", *fixed(16), sub=16)
 for mf in (56, 48, 40, 32):
     report(f"greedy cut, fill {mf}..64", *greedy(mf))
+
+
+# ---- regrouping inside Hilbert tiles: balanced kd splits (largest-extent axis, median) down to 64-body groups
+def kd_regroup(T):
+    perm = np.arange(n)
+    pos = xyzm[:, :3]
+    out = np.empty(n, np.int64)
+    for t0 in range(0, n - n % T, T * stride):     # only the sampled tiles matter
+        idx = [np.arange(t0, t0 + T)]
+        while len(idx[0]) > 64:
+            nxt = []
+            for a in idx:
+                p = pos[a]
+                ax = int(np.argmax(p.max(0) - p.min(0)))
+                o = np.argsort(p[:, ax], kind="stable")
+                h = len(a) // 2
+                nxt += [a[o[:h]], a[o[h:]]]
+            idx = nxt
+        out[t0:t0 + T] = np.concatenate(idx)
+    return out
+
+
+for T in (128, 512, 4096):
+    tiles = np.arange(0, n - n % T, T * stride)
+    perm = kd_regroup(T)
+    sel = np.concatenate([np.arange(t, t + T) for t in tiles])
+    x2 = np.ascontiguousarray(xyzm[perm[sel]])
+    gs = np.arange(0, len(sel), 64); gc = np.full(len(gs), 64)
+    keep = xyzm
+    xyzm = x2
+    o = run(gs, gc)
+    xyzm = keep
+    x1 = np.ascontiguousarray(keep[sel]); xyzm = x1
+    o0 = run(gs, gc)
+    xyzm = keep
+    print(f"kd regroup inside {T}-body Hilbert tiles: pairs/body {float(o[1])/len(sel):7.2f}  (plain Hilbert groups on the same tiles {float(o0[1])/len(sel):7.2f})")

@@ -141,8 +141,9 @@ def test_dd_eight_ranks_vs_the_oracle_itself():
     65,536 Plummer bodies (BASELINE configs[0] size), K = 5 whole steps vs oracle.Oracle.step from identical
     inputs.  Same distribution form as tests/test_gpu_fullsize.py; the stitched tree accepts the same cells, the
     fp32 summation order differs (top tree first, LET segments interleaved).  Stated tolerance after 5 steps:
-        |dx| median <= 3.1e-5, p99.99 <= 2e-4, max <= 5e-4;  |dv| median <= 1e-6, p99.99 <= 4e-5, max <= 2e-4;
-        first-step... last-step accelerations: relative median <= 4e-6"""
+        |dx| median and p99.99 <= 3.1e-5 (one ulp of a position below 512), max <= 6.2e-5;
+        |dv| median <= 1e-7, p99.99 <= 4e-6, max <= 5e-6;  last step's accelerations: relative median <= 1e-6, max <= 1e-4
+    (<= 2x measured on MI355X, round 3: |dx| 0 / 5.5e-6 / 3.1e-5, |dv| 0 / 1.9e-6 / 2.4e-6, acc 5.1e-7 / max 4.1e-5)"""
     import oracle as O
     pkg = bhpkg.load()
     n, K, world = 65536, 5, 8
@@ -161,9 +162,9 @@ def test_dd_eight_ranks_vs_the_oracle_itself():
     print(f"DD x8 vs oracle, n={n} K={K}: |dx| p50 {np.median(dx):.3e} p99.99 {np.percentile(dx, 99.99):.3e} max {dx.max():.3e}; "
           f"|dv| p50 {np.median(dv):.3e} p99.99 {np.percentile(dv, 99.99):.3e} max {dv.max():.3e}; "
           f"acc rel p50 {np.median(e):.3e} max {e.max():.3e}")
-    assert np.median(dx) <= 3.1e-5 and np.percentile(dx, 99.99) <= 2e-4 and dx.max() <= 5e-4
-    assert np.median(dv) <= 1e-6 and np.percentile(dv, 99.99) <= 4e-5 and dv.max() <= 2e-4
-    assert np.median(e) <= 4e-6
+    assert np.median(dx) <= 3.1e-5 and np.percentile(dx, 99.99) <= 3.1e-5 and dx.max() <= 6.2e-5
+    assert np.median(dv) <= 1e-7 and np.percentile(dv, 99.99) <= 4e-6 and dv.max() <= 5e-6
+    assert np.median(e) <= 1e-6 and e.max() <= 1e-4
 
 
 def test_dd_disc_initial_conditions():

@@ -422,24 +422,35 @@ def test_integrate_bit_exact(pkg, orc, n):
 
 @pytest.mark.parametrize("n,steps", [(4096, 100), (65536, 10)])
 def test_steps_end_to_end(pkg, orc, n, steps):
-    """K whole steps, Plummer sphere, theta = 0.5 (BASELINE config 1 at 65,536).
-    Tolerance after K steps (positions in units where the sphere has a = 400, velocities ~10):
-    strict kernel max |dx| <= 2e-3 and |dv| <= 2e-3; fast kernel max |dx| <= 1e-2, |dv| <= 1e-2."""
+    """K whole steps, Plummer sphere, theta = 0.5 (BASELINE config 1 at 65,536) vs the oracle's step loop, as a
+    distribution over the bodies of max(|dx|,|dy|,|dz|) and max |dv| (positions: sphere scale a = 400, one ulp of
+    a coordinate below 512 is 3.1e-5; velocities ~10).  Stated tolerance (strict kernel / fast kernel), <= 2x the
+    values measured on MI355X in round 3 — see TOL below."""
     ic = pkg.plummer(n, seed=42)
     o = orc.Oracle(n)
     o.upload(*ic)
     o.step(steps, order=orc.ORDER_BATCHED)
-    ref = np.stack(o.download(), 1)
-    for strict, tol in ((1, 2e-3), (0, 1e-2)):
+    ref = np.stack(o.download(), 1).astype(np.float64)
+    for strict in (1, 0):
         e = _engine(pkg, ic, strict_fp=strict)
         e.step(steps)
-        got = np.stack(e.download(), 1)
+        got = np.stack(e.download(), 1).astype(np.float64)
         st = e.stats()
         assert st.status_flags == 0 and st.steps == steps
-        assert np.abs(got[:, :3] - ref[:, :3]).max() <= tol, strict
-        assert np.abs(got[:, 3:] - ref[:, 3:]).max() <= tol, strict
+        dx = np.abs(got[:, :3] - ref[:, :3]).max(axis=1)
+        dv = np.abs(got[:, 3:] - ref[:, 3:]).max(axis=1)
+        print(f"n={n} K={steps} strict={strict}: |dx| p50 {np.median(dx):.3e} p99.9 {np.percentile(dx, 99.9):.3e} max {dx.max():.3e}; "
+              f"|dv| p50 {np.median(dv):.3e} p99.9 {np.percentile(dv, 99.9):.3e} max {dv.max():.3e}")
+        t = TOL_STEPS[(n, strict)]
+        assert np.median(dx) <= t[0] and np.percentile(dx, 99.9) <= t[1] and dx.max() <= t[2], (strict, t)
+        assert np.median(dv) <= t[3] and np.percentile(dv, 99.9) <= t[4] and dv.max() <= t[5], (strict, t)
         e.close()
     o.close()
+
+
+# (n, strict) -> |dx| median, p99.9, max, |dv| median, p99.9, max
+TOL_STEPS = {(4096, 1): (3.1e-5, 2e-3, 2e-3, 1e-4, 2e-3, 2e-3), (4096, 0): (3.1e-5, 1e-2, 1e-2, 1e-4, 1e-2, 1e-2),
+             (65536, 1): (3.1e-5, 2e-3, 2e-3, 1e-4, 2e-3, 2e-3), (65536, 0): (3.1e-5, 1e-2, 1e-2, 1e-4, 1e-2, 1e-2)}
 
 
 def _state(e):
