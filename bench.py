@@ -26,9 +26,15 @@ FP32_VECTOR_TFLOPS = 157.3  # MI355X peak FP32 vector rate (same guide): 256 CUs
 # resident, measured on MI355X by tools/ubench_forms.hip / tools/ubench_issue.hip (loop overhead removed);
 # committed output: profiles/r02_ubench/ubench_forms.txt, ubench_issue.txt.  Only two-source all-VGPR VOP2 runs
 # at the 2.3-cycle full rate; SGPR operands, three sources, SGPR results and packed fp32 cost 3.8-4.3.
+# "scalar_in_context": what one more SALU instruction per pair chain costs the SIMD while seven other waves issue
+# VALU work (tools/ubench_exec.hip, profiles/r03_ubench/ubench_exec.txt: pair chain + 0 / 2 / 4 / 8 SALU =
+# 73.8 / 79.0 / 81.0 / 83.7 cycles): scalar issue overlaps other waves' vector issue to a large part, so it is
+# NOT added to the floor (round 2 added 2.2 cycles per scalar instruction and called the sum a floor; the 8M and
+# theta = 0.3 configurations ran faster than that "floor").
 ISSUE_CYCLES = {"pk_add_sgpr": 3.78, "pk_mul": 3.78, "pk_fma": 4.30, "cmp_e64": 4.30, "cndmask_e64": 4.30,
-                "rsq": 7.76, "lane_rw": 2.80, "scalar": 2.20}
-ISSUE_PROVENANCE = "committed profile r02_ubench (tools/ubench_forms.hip, tools/ubench_issue.hip on MI355X)"
+                "rsq": 7.76, "lane_rw": 2.80, "scalar_in_context": 1.25}
+ISSUE_PROVENANCE = ("committed profiles r02_ubench (tools/ubench_forms.hip, tools/ubench_issue.hip) and r03_ubench "
+                    "(tools/ubench_exec.hip) on MI355X")
 
 
 def b_alg(V, O, P, n):
@@ -71,29 +77,33 @@ def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=10):
 
 
 def issue_roofline(ws, simds, launch_ms):
-    """Issue-rate floor of one force launch from the walk's own event counters (bh_force_walk_stats, counted in
+    """VALU-issue floor of one force launch from the walk's own event counters (bh_force_walk_stats, counted in
     THIS run) priced with the per-form issue costs above.  Instruction counts follow csrc/bh_force.hip:
     a pair = 3 v_pk_add + 3 v_pk_fma + 2 v_cmp + 2 v_rsq + 3 v_pk_mul + 3 v_pk_fma (+ 2 v_cndmask if a record was
-    opened) and 4 scalar; a block = 5 v_readlane + 4 s_load + 11 scalar; a push = 4 v_writelane + 5 scalar."""
+    opened) and 2 scalar (s_or + branch); a block = 4 v_readlane + 2-4 s_load + ~11 scalar / branch; a push =
+    4 v_writelane + ~7 scalar.  The BOUND is the VALU-only figure (no configuration can beat it); the estimate
+    with scalar issue at its measured in-context cost is reported beside it and is an estimate, not a floor."""
     c = ISSUE_CYCLES
     pairs, blocks, masked, waves = float(ws.pairs), float(ws.blocks), float(ws.masked_pairs), float(ws.waves)
     pushes = blocks - waves
     pair_cycles = 3 * c["pk_add_sgpr"] + 6 * c["pk_fma"] + 2 * c["cmp_e64"] + 2 * c["rsq"] + 3 * c["pk_mul"]
-    valu_insts = 16 * pairs + 2 * masked + 5 * blocks + 4 * pushes
-    valu_cycles = pair_cycles * pairs + 2 * c["cndmask_e64"] * masked + c["lane_rw"] * (5 * blocks + 4 * pushes)
-    scalar_insts = 4 * pairs + 15 * blocks + 5 * pushes
+    valu_insts = 16 * pairs + 2 * masked + 4 * blocks + 4 * pushes
+    valu_cycles = pair_cycles * pairs + 2 * c["cndmask_e64"] * masked + c["lane_rw"] * (4 * blocks + 4 * pushes)
+    scalar_insts = 2 * pairs + 13 * blocks + 7 * pushes
     clock_hz = ws.clock_ghz * 1e9
     floor_valu_ms = valu_cycles / simds / clock_hz * 1e3
-    floor_all_ms = (valu_cycles + c["scalar"] * scalar_insts) / simds / clock_hz * 1e3
+    est_ms = (valu_cycles + c["scalar_in_context"] * scalar_insts) / simds / clock_hz * 1e3
     return {
         "counted_this_run": {"waves": int(waves), "record_pairs": int(pairs), "blocks": int(blocks),
                              "pairs_with_opened_record": int(masked)},
         "valu_insts_per_launch": valu_insts, "scalar_insts_per_launch": scalar_insts,
         "cycles_per_pair_valu": pair_cycles, "issue_cycles_per_form": c, "issue_cycles_provenance": ISSUE_PROVENANCE,
         "clock_ghz_in_kernel": ws.clock_ghz, "simds": simds,
-        "floor_ms_valu_only": floor_valu_ms, "floor_ms_valu_plus_scalar": floor_all_ms,
-        "kernel_ms": launch_ms, "frac_of_valu_floor": floor_valu_ms / launch_ms,
-        "frac_of_valu_plus_scalar_floor": floor_all_ms / launch_ms,
+        "floor_ms_valu_only": floor_valu_ms, "kernel_ms": launch_ms, "frac_of_valu_floor": floor_valu_ms / launch_ms,
+        "estimate_ms_valu_plus_scalar_in_context": est_ms,
+        "estimate_note": "VALU floor + scalar instructions at their measured marginal cost beside other waves' VALU "
+                         "issue; an estimate of the issue time, not a bound (launch ramp / drain, scalar-load waits "
+                         "and lone-wave issue rates at the end of the launch are not in it)",
         "wave_lifetime_ms": {"mean": ws.wave_cycles_mean / clock_hz * 1e3, "max": ws.wave_cycles_max / clock_hz * 1e3},
     }
 
@@ -113,34 +123,69 @@ def _oracle_steps(O, n, theta, ic, nthreads, budget_s, max_steps):
     tm = st.times()
     cnt = st.counts()
     st.close()
-    return min(per), len(per), tm, cnt
+    return per, tm, cnt
 
 
-def cpu_baseline(pkg, n, theta, ic, budget_s=16.0):
+def cpu_baseline_child(n, theta, seed, budget_s, max_steps):
+    """One leg of the CPU baseline, run in a CHILD process of bench.py so that the OpenMP runtime starts with
+    this leg's own team size and binding (OMP_NUM_THREADS / OMP_PROC_BIND=close / OMP_PLACES=cores are set by the
+    parent; an OpenMP runtime that torch already initialised in the parent would ignore them).  Never touches the GPU."""
+    import statistics
+    import bhpkg
+    import oracle as O
+    pkg = bhpkg.load()
+    O.build()
+    ic = pkg.plummer(n, seed=seed)
+    per, tm, cnt = _oracle_steps(O, n, theta, ic, 0, budget_s, max_steps)
+    print(json.dumps({"threads": O.max_threads(), "best_s": min(per), "median_s": statistics.median(per), "steps": len(per),
+                      "force_s_last": tm["force"], "counts": cnt}))
+
+
+def _cpu_leg(n, theta, seed, threads, budget_s, max_steps):
+    import subprocess
+    env = dict(os.environ)
+    env.update({"OMP_NUM_THREADS": str(threads), "OMP_PROC_BIND": "close", "OMP_PLACES": "cores"})
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--bodies", str(n),
+                          "--theta", str(theta), "--seed", str(seed), "--child-budget", str(budget_s),
+                          "--child-steps", str(max_steps)], env=env, capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        raise RuntimeError("cpu baseline leg failed: " + out.stderr[-400:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline(n, theta, seed):
     """The CPU oracle ("port": this repo's restatement of the reference recurrence — the reference has no CPU
     path; gcc -O3, iterative walk, OpenMP) timed on this box's host cores: whole steps, all stages.  `value` =
-    the bench workload on all cores; plus BASELINE.json configs[0] (65,536 bodies) on all cores and on ONE
-    thread.  Bounded: about 25 s of CPU wall time in total."""
-    import oracle as O
-    O.build()
-    cores = O.max_threads()
-    t_step, steps, tm, cnt = _oracle_steps(O, n, theta, ic, 0, budget_s, 5)
+    the bench workload on all cores; plus BASELINE.json configs[0] (65,536 bodies) on a team sized to the problem
+    (one thread per 2,048 bodies, at most all cores: 128 threads on a 65k-body problem measured 6x apart between
+    two boxes in round 2) and on ONE thread (SURVEY §8d).  Threads are bound (OMP_PROC_BIND=close, OMP_PLACES=cores);
+    best and median step are both reported.  Bounded: about 25 s of CPU wall time in total."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    r = _cpu_leg(n, theta, seed, cores, 16.0, 5)
     out = {
-        "value": n / t_step, "unit": "particles/s/step", "cores": cores, "kind": "port",
-        "sample": f"{steps} whole step(s) of the same {n}-body theta={theta} workload, all stages, "
-                  f"OpenMP x{cores}; best step {t_step:.3f} s (force stage of the last step {tm['force']:.3f} s)",
-        "ms_per_step": t_step * 1e3,
-        "oracle_counts_per_body": {"V": cnt["V"] / n, "O": cnt["O"] / n, "P": cnt["P"] / n},
+        "value": n / r["best_s"], "unit": "particles/s/step", "cores": r["threads"], "kind": "port",
+        "sample": f"{r['steps']} whole step(s) of the same {n}-body theta={theta} workload, all stages, "
+                  f"OpenMP x{r['threads']} bound to cores; best step {r['best_s']:.3f} s, median {r['median_s']:.3f} s "
+                  f"(force stage of the last step {r['force_s_last']:.3f} s)",
+        "ms_per_step": r["best_s"] * 1e3, "ms_per_step_median": r["median_s"] * 1e3,
+        "oracle_counts_per_body": {k: r["counts"][k] / n for k in ("V", "O", "P")},
     }
     n1 = 65536
-    ic1 = pkg.plummer(n1, seed=42)
-    ta, sa, tma, _ = _oracle_steps(O, n1, 0.5, ic1, 0, 3.0, 10)
-    t1, s1, tm1, _ = _oracle_steps(O, n1, 0.5, ic1, 1, 6.0, 3)
+    team = max(1, min(cores, n1 // 2048))
+    ra = _cpu_leg(n1, 0.5, 42, team, 3.0, 20)
+    r1 = _cpu_leg(n1, 0.5, 42, 1, 6.0, 3)
     out["config0_65536_bodies_theta0.5"] = {
-        "all_cores": {"value": n1 / ta, "unit": "particles/s/step", "cores": cores, "ms_per_step": ta * 1e3,
-                      "sample": f"best of {sa} whole steps (force stage of the last step {tma['force'] * 1e3:.1f} ms)"},
-        "one_thread": {"value": n1 / t1, "unit": "particles/s/step", "cores": 1, "ms_per_step": t1 * 1e3,
-                       "sample": f"best of {s1} whole steps (force stage of the last step {tm1['force'] * 1e3:.1f} ms)"},
+        "team": {"value": n1 / ra["median_s"], "unit": "particles/s/step", "cores": ra["threads"],
+                 "ms_per_step": ra["median_s"] * 1e3, "ms_per_step_best": ra["best_s"] * 1e3,
+                 "sample": f"median of {ra['steps']} whole steps, {ra['threads']} threads = one per 2,048 bodies, bound to "
+                           f"cores (force stage of the last step {ra['force_s_last'] * 1e3:.1f} ms)"},
+        "one_thread": {"value": n1 / r1["median_s"], "unit": "particles/s/step", "cores": 1,
+                       "ms_per_step": r1["median_s"] * 1e3, "ms_per_step_best": r1["best_s"] * 1e3,
+                       "sample": f"median of {r1['steps']} whole steps (force stage of the last step {r1['force_s_last'] * 1e3:.1f} ms)"},
     }
     return out
 
@@ -157,6 +202,9 @@ def main():
     ap.add_argument("--theta", type=float, default=0.5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--child-budget", type=float, default=10.0, help=argparse.SUPPRESS)
+    ap.add_argument("--child-steps", type=int, default=5, help=argparse.SUPPRESS)
     ap.add_argument("--xcd-mode", type=int, default=3, help="tuning: block->chunk placement (bh_params.xcd_mode, 3 = automatic)")
     ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
     ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
@@ -166,6 +214,8 @@ def main():
     ap.add_argument("--force-variant", type=int, default=0,
                     help="A/B: 0 = hand-scheduled force walk (default), 1 = compiler-scheduled walk")
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.n, args.theta, args.seed, args.child_budget, args.child_steps)
 
     import numpy as np
     import torch
@@ -251,10 +301,10 @@ def main():
         eng.force_count()
         s = eng.stats()
         counts0 = (s.count_V, s.count_O, s.count_P)
-    # 1-GPU path: one hipEvent pair per step around the force launch, on the engine's stream, inside the timed
-    # region (the per-stage breakdown comes from 10 further steps: an event after every stage costs the stream
-    # ~60 us per step)
-    eng.set_timing(2 if (not multi and not args.graph) else 0)
+    # 1-GPU path: a hipEvent pair around the force launch of every 4th step, on the engine's stream, inside the
+    # timed region (each record costs the stream ~7 us: a pair per step is 1 % of a 1M-body step and 4 % of a
+    # 65,536-body one; the per-stage breakdown comes from 10 further steps with an event after every stage)
+    eng.set_timing(3 if (not multi and not args.graph) else 0)
 
     barrier()
     t0 = time.perf_counter()
@@ -322,10 +372,11 @@ def main():
             ws = eng.force_walk_stats()          # the walk's event counters + in-kernel clock, counted now
             props = torch.cuda.get_device_properties(local_rank)
             issue = issue_roofline(ws, 4 * props.multi_processor_count, avg_force_ms)
-            # useful arithmetic of the recurrence (ref:205-213): 20 flop per interaction actually taken or tested
-            # by a body (V cell MACs + P body interactions): 3 sub, 5 for d2 + eps2, rsq, 2 for the MAC,
-            # 3 for f, 6 for the accumulate
-            useful_tflops = (V + P) * 20.0 / (avg_force_ms * 1e-3) / 1e12
+            # useful arithmetic of the recurrence (ref:205-213): 20 flop per interaction TAKEN by a body (accepted
+            # cells V - O and body interactions P: 3 sub, 5 for d2 + eps2, rsq, 2 for the MAC, 3 for f, 6 for the
+            # accumulate) and 11 per cell a body OPENS (the MAC half only: its force half is discarded)
+            useful_flop = (V - O + P) * 20.0 + O * 11.0
+            useful_tflops = useful_flop / (avg_force_ms * 1e-3) / 1e12
             traffic, traffic_src = load_traffic(n_total, args.theta)
             alg_gbs = bytes_alg / (avg_force_ms * 1e-3) / 1e9
             roofline = {
@@ -338,9 +389,11 @@ def main():
                 "why_valu": "the walk is bound by VALU instruction ISSUE: every record field arrives in SGPRs, and "
                             "SGPR-operand / packed / compare / rsq forms issue at 3.8-7.8 cycles per wave64 "
                             "instruction (full rate 2.3 only for 2-source all-VGPR ops); the 97 %-L2-resident tree "
-                            "keeps HBM at a few per cent (DESIGN.md §4)",
+                            "keeps HBM at a few per cent (DESIGN.md §4); frac = useful flop of the recurrence (20 per interaction "
+                            "taken, 11 per cell opened) / FP32 vector peak, lane_efficiency = share of the issued lane "
+                            "slots that carry a body's interaction",
                 "issue": issue,
-                "useful_flop_per_launch": (V + P) * 20.0,
+                "useful_flop_per_launch": useful_flop,
                 "lane_efficiency": (V + P) / max(1.0, 2.0 * float(ws.pairs) * 64.0),
                 "per_body": {"V": V / n_total, "O": O / n_total, "P": P / n_total, "bytes": bytes_alg / n_total},
                 "hbm": {
@@ -391,7 +444,7 @@ def main():
     if dist is not None:
         dist.barrier()
     if rank == 0 and not multi and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pkg, n_total, args.theta, ic)
+        out["cpu_baseline"] = cpu_baseline(n_total, args.theta, args.seed)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -265,7 +265,7 @@ int bh_set_timing(bh_ctx* c, int on) {
     for (int i = 0; i < BH_TIMING_RING * 8; i++) BH_HIP(c, hipEventCreate(&c->evring[i]));
   }
   c->timing = on != 0;
-  c->timing_mode = (on == 2) ? 2 : 1;
+  c->timing_mode = (on == 2 || on == 3) ? on : 1;
   c->timed_steps = 0;
   return BH_OK;
 }
@@ -434,11 +434,12 @@ int bh_force_count(bh_ctx* c) {
 
 // ---- the step: ref:255-283, same stage order, no host sync ----
 static int step_launch(bh_ctx* c) {
-  const bool t = c->timing;
-  hipEvent_t* ev = t ? c->evring + (size_t)(c->timed_steps % BH_TIMING_RING) * 8 : nullptr;
   // mode 2 records only the pair around the force launch: an event record costs the stream ~7-16 us between
-  // two dependent kernels, eight of them ~60 us per 1M-body step (seen as gaps in the rocprofv3 kernel trace)
-  const bool all = t && c->timing_mode != 2;
+  // two dependent kernels, eight of them ~60 us per 1M-body step (seen as gaps in the rocprofv3 kernel trace);
+  // mode 3 records that pair on every 4th step only (14 us per step is 4 % of a 65,536-body step)
+  const bool t = c->timing && (c->timing_mode != 3 || (c->steps & 3) == 0);
+  hipEvent_t* ev = t ? c->evring + (size_t)(c->timed_steps % BH_TIMING_RING) * 8 : nullptr;
+  const bool all = t && c->timing_mode == 1;
 #define BH_MARK(i) if (all || (t && ((i) == 5 || (i) == 6))) BH_HIP(c, hipEventRecord(ev[i], c->stream))
   BH_MARK(0);
   if (c->bounds_next_ok) {  // the previous step's integrate already folded the cube of these positions
@@ -455,16 +456,21 @@ static int step_launch(bh_ctx* c) {
   BH_MARK(2);
   BH_HIP(c, bhk_sort(c, true));                // ref:262-264 (the body gather may be left pending)
   BH_MARK(3);
-  // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan
-  // on the side stream while the main stream builds the tree (both are small, latency-bound grids)
-  BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
-  BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
-  BH_HIP(c, bhk_gather_bodies(c, c->stream2));  // splitter sort: the bodies follow the keys here, beside the build
-  BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, true));
-  BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
+  // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan on the side
+  // stream while the main stream builds the tree (both are small, latency-bound grids).  Each event hand-over
+  // costs the streams ~7 us (seen as gaps in the kernel trace), so below BH_FORK_MIN_N bodies — where gather +
+  // scan are ~20 us — everything stays on the main stream.
+  const bool fork = c->n >= BH_FORK_MIN_N;
+  if (fork) {
+    BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
+    BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
+  }
+  BH_HIP(c, bhk_gather_bodies(c, fork ? c->stream2 : c->stream));  // splitter sort: the bodies follow the keys here
+  BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, fork));
+  if (fork) BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
   BH_HIP(c, bhk_build(c));                     // ref:266-275
   BH_MARK(4);
-  BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
+  if (fork) BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
   BH_HIP(c, bhk_com_records(c));               // ref:279-280
   BH_MARK(5);
   BH_HIP(c, bhk_force(c, 0, c->n, false));     // ref:281
@@ -674,7 +680,7 @@ int bh_get_stats(bh_ctx* c, bh_stats* st) {
   st->max_level = hi.max_level;
   st->status_flags = hi.flags;
   st->steps = c->steps;
-  if (c->timing && c->timing_mode == 2 && c->timed_steps > 0) {
+  if (c->timing && c->timing_mode >= 2 && c->timed_steps > 0) {
     hipEvent_t* ev = c->evring + (size_t)((c->timed_steps - 1) % BH_TIMING_RING) * 8;
     BH_HIP(c, hipEventElapsedTime(&st->ms_force, ev[5], ev[6]));
   } else if (c->timing && c->timed_steps > 0) {
@@ -705,7 +711,7 @@ int bh_timing_history(bh_ctx* c, float* ms_force, float* ms_step, int capacity, 
     hipEvent_t* ev = c->evring + (size_t)(step % BH_TIMING_RING) * 8;
     if (ms_force) BH_HIP(c, hipEventElapsedTime(&ms_force[i], ev[5], ev[6]));
     if (ms_step) {
-      if (c->timing_mode == 2) ms_step[i] = 0.0f;  // not recorded in this mode
+      if (c->timing_mode >= 2) ms_step[i] = 0.0f;  // not recorded in these modes
       else BH_HIP(c, hipEventElapsedTime(&ms_step[i], ev[0], ev[7]));
     }
   }

@@ -193,6 +193,9 @@ struct bh_ctx {
 #define BH_INTEGRATE_TILE 4096  // bodies per integrate block (1024 threads x 4)
 #define BH_PAIR_SMALL_N 163840  // bodies up to which the tree build uses 256-pair tiles (A/B per step: 16,384 -15 us,
                                 // 65,536 -14 us, 125,000 -8 us, 262,144 +5 us)
+#ifndef BH_FORK_MIN_N
+#define BH_FORK_MIN_N 163840  // bodies from which bh_step runs body gather + COM prefix scan on the second stream
+#endif
 #define BH_BLKDONE_STRIDE(n) ((size_t)(n) / 8192 + 4)  // one counter per 32 tiles of >= 256 pairs
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
 #ifndef BH_SORT_TILE

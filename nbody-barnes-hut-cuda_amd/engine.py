@@ -162,8 +162,9 @@ class Engine:
         self._ck(lib.bh_sync(self._h), "bh_sync")
 
     def set_timing(self, on=True):
-        """True / 1: events after every stage of a step; 2: only around the force launch (cheap); False: off"""
-        self._ck(lib.bh_set_timing(self._h, 2 if on == 2 else (1 if on else 0)), "bh_set_timing")
+        """True / 1: events after every stage of a step; 2: only around the force launch (cheap); 3: that pair on
+        every 4th step; False: off"""
+        self._ck(lib.bh_set_timing(self._h, on if on in (2, 3) else (1 if on else 0)), "bh_set_timing")
 
     # -- data out
     def download(self):

@@ -522,11 +522,12 @@ def test_step_graph_replay_matches_plain_launches(pkg):
 def test_timing_modes(pkg):
     """bh_set_timing: 1 = an event after every stage (every ms_* of bh_stats filled, the history carries force and
     step times), 2 = only the pair around the force launch (what bench.py's timed region uses: ms_force and the
-    force history only), 0 = off; the physics does not depend on it"""
+    force history only), 3 = that pair on every 4th step (steps 0 and 4 of these 5), 0 = off; the physics does not
+    depend on it"""
     n = 40000
     ic = pkg.plummer(n, seed=12)
     states = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         e = _engine(pkg, ic)
         e.set_timing(mode)
         e.step(5)
@@ -539,11 +540,11 @@ def test_timing_modes(pkg):
             assert min(st.ms_morton, st.ms_sort, st.ms_build, st.ms_com, st.ms_force, st.ms_integrate) > 0.0
             assert st.ms_step >= st.ms_force
         else:
-            assert len(f) == 5 and (f > 0).all() and (t == 0).all()
+            assert len(f) == (5 if mode == 2 else 2) and (f > 0).all() and (t == 0).all()
             assert st.ms_force > 0.0 and st.ms_sort == 0.0 and st.ms_step == 0.0
         states.append(_state(e))
         e.close()
-    assert states[0] == states[1] == states[2]
+    assert states[0] == states[1] == states[2] == states[3]
 
 
 def test_step_cube_from_integrate_is_the_bbox_cube(pkg, orc):
