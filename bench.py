@@ -216,6 +216,11 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.n, args.theta, args.seed, args.child_budget, args.child_steps)
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL prints its version
+    # block at communicator creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -448,7 +453,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

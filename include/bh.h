@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 2 /* 2: bh_params grew key_curve (72 bytes) */
+#define BH_ABI_VERSION 3 /* 2: bh_params grew key_curve (72 bytes); 3: bh_dd_phase_*, timing mode 3 */
 
 typedef struct bh_ctx bh_ctx; /* opaque; replaces the globals ref:31-40 */
 
@@ -292,6 +292,18 @@ int bh_dd_force(bh_ctx* c);
    BH_OK, or BH_ERR_SMALL_BUFFER when some count exceeds stride (repeat let_pack..force larger) */
 int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts);
 /* local bodies in local Morton order: posm[4 n_loc] = x,y,z,m; velid[4 n_loc] = vx,vy,vz,bits(id) */
+/* One entry point per phase group (the same sequences as the calls above; what dist.DomainStepper uses):
+     bh_dd_phase_migrate = bh_dd_cube_apply + bh_dd_migrate_pack
+     bh_dd_phase_tree    = bh_dd_migrate_apply, then bh_dd_tree unless *more (another migration round comes first)
+     bh_dd_phase_let     = bh_dd_force_local (if own_pass) + bh_dd_let_pack
+     bh_dd_phase_force   = bh_dd_top + bh_dd_force + bh_dd_let_check (*fits = 0: repeat X4 with a larger stride)
+     bh_dd_phase_end     = bh_integrate + bh_dd_cube_pack (the next step's X1 payload: this rank's min / max are
+                           folded by the integrate kernel, no bounding-box launches) */
+int bh_dd_phase_migrate(bh_ctx* c, const void* gathered_x1, void* send_x2, int limit);
+int bh_dd_phase_tree(bh_ctx* c, const void* gathered_x2, int limit, void* send_x3, int* n_loc, int* more, int* most);
+int bh_dd_phase_let(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride, int own_pass);
+int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* counts, int* fits);
+int bh_dd_phase_end(bh_ctx* c, void* send_x1);
 int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc);
 
 /* per-step device times (hipEvent pairs recorded on the context's stream while

@@ -118,6 +118,11 @@ SYMBOLS = [
     ("bh_dd_top", C.c_int, [_P, _P, C.c_int]),
     ("bh_dd_force", C.c_int, [_P]),
     ("bh_dd_let_check", C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),
+    ("bh_dd_phase_migrate", C.c_int, [_P, _P, _P, C.c_int]),
+    ("bh_dd_phase_tree", C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("bh_dd_phase_let", C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    ("bh_dd_phase_force", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
+    ("bh_dd_phase_end", C.c_int, [_P, _P]),
     ("bh_dd_download", C.c_int, [_P, _F, _F, _F]),
     ("bh_ic_plummer", C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_float] + [_F] * 7),
     ("bh_ic_disc", C.c_int, [C.c_int, C.c_uint64, C.c_float] + [_F] * 7),

@@ -93,9 +93,13 @@ struct bh_dd_state {
   hipEvent_t ev_x3, ev_top1, ev_own;
   hipStream_t stream_own;  // lowest priority: the own pass is background work behind the LET export and X4
   bool split;      // two-pass force: own pieces while X4 is in flight, remote pieces after it
-  int* host;       // pinned: [world] LET counts, [world .. world+3] migration results
+  int* host;       // pinned: [world] LET counts, [64 .. 67] migration results, [68] their sequence number
   hipEvent_t ev_let;
   bool let_copy_pending;
+  u32* cls_done;   // bh_last_block counters of dd_classify_kernel
+  u32* abs_done;   // ... of dd_absorb_flag_kernel
+  int* arrive;     // [64] immigrants per rank of the current round (left at zero by the kernel)
+  int absorb_seq;  // sequence number of the last dd_absorb_kernel launch
 };
 
 namespace {
@@ -122,11 +126,13 @@ __device__ __forceinline__ int owner_of(u64 key, const u64* sk, int nsplit) {
 
 // ------------------------------------------------------------------ X1
 // samples k = 0 .. : the body at local index (k + 1/2) * g, g = n_total / kSampTotal — the same
-// stride on every rank, so the merged samples weight every body equally
-__global__ __launch_bounds__(256) void dd_x1_tail_kernel(float* __restrict__ send, int n_loc,
-                                                         const float4* __restrict__ posm, double g,
+// stride on every rank, so the merged samples weight every body equally.  send[0..5] = the rank's min / max
+// (mm: folded by the previous step's integrate kernel, or by bbox_partial/final after an upload).
+__global__ __launch_bounds__(256) void dd_x1_pack_kernel(float* __restrict__ send, const float* __restrict__ mm,
+                                                         int n_loc, const float4* __restrict__ posm, double g,
                                                          int samp_cap) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 6) send[t] = mm[t];
   if (t == 0) {
     send[6] = __int_as_float(n_loc);
     send[7] = 0.0f;
@@ -141,14 +147,31 @@ __global__ __launch_bounds__(256) void dd_x1_tail_kernel(float* __restrict__ sen
   reinterpret_cast<float4*>(send + 8)[t] = o;
 }
 
-// keys of all samples under the new cube, bitonic sort, equal-count quantiles -> splitter keys
+// the global cube from the gathered per-rank min / max (exact: min and max are associative; same arithmetic as
+// write_cube of bh_tree.hip, ref:148-154), then: keys of all samples under the new cube, bitonic sort,
+// equal-count quantiles -> splitter keys
 __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict__ g, int world, int xf,
-                                                        int samp_cap, const float* __restrict__ bounds,
+                                                        int samp_cap, float* __restrict__ bounds,
                                                         int curve, u64* __restrict__ skeys) {
   __shared__ u64 k[kSampTotal];
   __shared__ int nvalid;
+  __shared__ float cube[8];
   const int tid = threadIdx.x;
-  if (tid == 0) nvalid = 0;
+  if (tid == 0) {
+    nvalid = 0;
+    float mn[3] = {1e10f, 1e10f, 1e10f}, mx[3] = {-1e10f, -1e10f, -1e10f};  // sentinels ref:138
+    for (int r = 0; r < world; r++) {
+      const float* o = g + (size_t)r * xf;
+      mn[0] = fminf(mn[0], o[0]); mn[1] = fminf(mn[1], o[1]); mn[2] = fminf(mn[2], o[2]);
+      mx[0] = fmaxf(mx[0], o[3]); mx[1] = fmaxf(mx[1], o[4]); mx[2] = fmaxf(mx[2], o[5]);
+    }
+    const float size = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));  // ref:148
+    cube[0] = mn[0]; cube[1] = mn[1]; cube[2] = mn[2];
+    cube[3] = mn[0] + size; cube[4] = mn[1] + size; cube[5] = mn[2] + size;  // ref:152-154
+    cube[6] = fmaxf(cube[3] - cube[0], 1.0f);                                 // root edge s0, ref:55
+    cube[7] = 0.0f;
+    for (int q = 0; q < 8; q++) bounds[q] = cube[q];
+  }
   __syncthreads();
   int mine = 0;
   for (int i = tid; i < kSampTotal; i += 1024) {
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
     if (r < world) {
       const float4 p = reinterpret_cast<const float4*>(g + (size_t)r * xf + 8)[t];
       if (p.w > 0.5f) {
-        key = body_key<kB>(curve, p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
+        key = body_key<kB>(curve, p.x, p.y, p.z, cube[0], cube[1], cube[2], cube[6]);
         mine++;
       }
     }
@@ -186,130 +209,268 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ X2
-__global__ __launch_bounds__(256) void dd_classify_kernel(const u64* __restrict__ keys, int n,
+// Two kernels pack the emigrants (round 2: keys, classify, two scan launches, compact), one absorbs the
+// immigrants (round 2: six launches).  All orders are by body index / (rank, slot): deterministic.
+constexpr int kClsTile = 1024;  // bodies per block of the classify / compact kernels (256 threads x 4 rounds)
+
+// kept[i] = 1 if body i stays (owner(key under the new cube) == me); bcnt[b] = emigrants of block b; the block
+// that finishes last turns the counts into exclusive bases and writes the X2 header:
+//   [0] emigrants found, [1] kept, [2] sent, [3] bodies still held  (+ 4 zero words)
+__global__ __launch_bounds__(256) void dd_classify_kernel(const float4* __restrict__ posm, int n,
+                                                          const float* __restrict__ bounds, int curve,
                                                           const u64* __restrict__ skeys, int nsplit, int me,
-                                                          int* __restrict__ flag) {
+                                                          unsigned char* __restrict__ kept, int* __restrict__ bcnt,
+                                                          int* __restrict__ bbase, u32* __restrict__ done,
+                                                          int* __restrict__ header, int limit) {
   __shared__ u64 sk[64];
+  __shared__ int wsum[4];
+  __shared__ int s_last;
   if ((int)threadIdx.x < nsplit) sk[threadIdx.x] = skeys[threadIdx.x];
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  flag[i] = owner_of(keys[i], sk, nsplit) == me ? 1 : 0;
+  const float b0 = bounds[0], b1 = bounds[1], b2 = bounds[2], size = bounds[6];
+  int gone = 0;
+#pragma unroll
+  for (int r = 0; r < kClsTile / 256; r++) {
+    const int i = blockIdx.x * kClsTile + r * 256 + (int)threadIdx.x;
+    if (i < n) {
+      const float4 p = posm[i];
+      const u64 key = body_key<kB>(curve, p.x, p.y, p.z, b0, b1, b2, size);
+      const int mine = owner_of(key, sk, nsplit) == me ? 1 : 0;
+      kept[i] = (unsigned char)mine;
+      gone += 1 - mine;
+    }
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) gone += __shfl_xor(gone, dd, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = gone;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bh_publish_i32(bcnt + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    bh_published();  // (bh_internal.h: last-block hand-off without a fence)
+    s_last = bh_last_block(done, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // exclusive scan of the block counts by this one block (<= n_cap / 1024 + 1 entries)
+  __shared__ int carry;
+  __shared__ int part[256];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int nb = (int)gridDim.x;
+  for (int c0 = 0; c0 < nb; c0 += 256) {
+    const int b = c0 + (int)threadIdx.x;
+    const int v = b < nb ? bh_collect_i32(bcnt + b) : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int dd = 1; dd < 256; dd <<= 1) {  // Hillis-Steele inclusive scan
+      const int u = (int)threadIdx.x >= dd ? part[threadIdx.x - dd] : 0;
+      __syncthreads();
+      part[threadIdx.x] += u;
+      __syncthreads();
+    }
+    if (b < nb) bbase[b] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry += part[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int found = carry;
+    const int sent = min(found, limit);
+    bbase[nb] = found;
+    header[0] = found;
+    header[1] = n - found;
+    header[2] = sent;
+    header[3] = n - sent;
+    header[4] = header[5] = header[6] = header[7] = 0;
+  }
 }
 
 // kept bodies -> the other ping-pong buffer (stable); the first `limit` emigrants -> X2 payload
 // (header 2 x float4); emigrants beyond the limit stay behind the kept bodies and leave in a later
-// round of the same step.  Header: [0] emigrants found, [1] kept, [2] sent, [3] bodies still held.
+// round of the same step.
 __global__ __launch_bounds__(256) void dd_compact_kernel(const float4* __restrict__ posm,
                                                          const float4* __restrict__ velid, int n,
-                                                         const int* __restrict__ flag,
-                                                         const int* __restrict__ fpos,
+                                                         const unsigned char* __restrict__ kept,
+                                                         const int* __restrict__ bbase,
                                                          float4* __restrict__ posm2,
                                                          float4* __restrict__ velid2, float4* __restrict__ send,
                                                          int limit) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int kept = fpos[n];
-  if (i == 0) {
-    int* h = reinterpret_cast<int*>(send);
-    const int sent = min(n - kept, limit);
-    h[0] = n - kept;
-    h[1] = kept;
-    h[2] = sent;
-    h[3] = n - sent;
-    h[4] = h[5] = h[6] = h[7] = 0;
+  __shared__ int wcnt[kClsTile / 256][4];
+  const int nb = (int)gridDim.x;
+  const int total_gone = bbase[nb];
+  const int n_kept = n - total_gone;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int f[kClsTile / 256];
+  u64 bal[kClsTile / 256];
+#pragma unroll
+  for (int r = 0; r < kClsTile / 256; r++) {
+    const int i = blockIdx.x * kClsTile + r * 256 + (int)threadIdx.x;
+    f[r] = (i < n && !kept[i]) ? 1 : 0;  // emigrant
+    bal[r] = __ballot(f[r]);
+    if (lane == 0) wcnt[r][wv] = __popcll(bal[r]);
   }
-  if (i >= n) return;
-  const float4 p = posm[i], v = velid[i];
-  const int k = fpos[i];
-  if (flag[i]) {
-    posm2[k] = p;
-    velid2[k] = v;
-  } else {
-    const int slot = i - k;
-    if (slot < limit) {
-      send[2 + 2 * (size_t)slot] = p;
-      send[3 + 2 * (size_t)slot] = v;
-    } else {
-      posm2[kept + slot - limit] = p;
-      velid2[kept + slot - limit] = v;
+  __syncthreads();
+  int before = bbase[blockIdx.x];  // emigrants of earlier blocks
+#pragma unroll
+  for (int r = 0; r < kClsTile / 256; r++) {
+    int pre = before;
+    for (int w2 = 0; w2 < wv; w2++) pre += wcnt[r][w2];
+    pre += __popcll(bal[r] & ((1ull << lane) - 1ull));
+    const int i = blockIdx.x * kClsTile + r * 256 + (int)threadIdx.x;
+    if (i < n) {
+      const float4 p = posm[i], v = velid[i];
+      if (!f[r]) {
+        posm2[i - pre] = p;
+        velid2[i - pre] = v;
+      } else if (pre < limit) {
+        send[2 + 2 * (size_t)pre] = p;
+        send[3 + 2 * (size_t)pre] = v;
+      } else {
+        posm2[n_kept + pre - limit] = p;
+        velid2[n_kept + pre - limit] = v;
+      }
     }
+    before += wcnt[r][0] + wcnt[r][1] + wcnt[r][2] + wcnt[r][3];
   }
 }
 
-__global__ __launch_bounds__(64) void dd_nloc_init_kernel(const float4* __restrict__ g, int world, size_t f4,
-                                                          int* __restrict__ nloc) {
-  const int q = threadIdx.x;
-  if (q < world) nloc[q] = reinterpret_cast<const int*>(g + (size_t)q * f4)[3];
-}
-
-// one thread per gathered emigrant slot: owner under the current cube; mine -> flag; every rank's
-// body count after this round (block-reduced: a global atomic per thread serialises)
-__global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __restrict__ g, int world,
-                                                             int limit, size_t f4,
-                                                             const float* __restrict__ bounds, int curve,
-                                                             const u64* __restrict__ skeys, int me,
-                                                             int* __restrict__ flag2, int* __restrict__ nloc) {
+// Absorbing the immigrants, two kernels.  Slot (q, k) = emigrant k of rank q's payload; block b covers 1024 slots
+// of one rank.  dd_absorb_flag_kernel: owner of each emigrant under the current cube -> mine[slot], per-block
+// count of mine, arrivals per owner (integer atomics: order-free); the block that finishes last turns the block
+// counts into bases (arrival order = (rank, slot): deterministic), computes every rank's body count and hands the
+// results to the device (out) and straight to pinned host memory, which the host polls (hres[4] = sequence number,
+// written last with a system-scope release) instead of synchronising the stream.  dd_absorb_copy_kernel then
+// appends the immigrants behind the bodies this rank still holds.
+//   out / hres: [0] bodies this rank now holds, [1] flags, [2] most emigrants still waiting on any rank,
+//               [3] most emigrants found on any rank (sizes the next exchange)
+__global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __restrict__ g, int world, int limit,
+                                                             size_t f4, int cpr, const float* __restrict__ bounds,
+                                                             int curve, const u64* __restrict__ skeys, int me,
+                                                             int n_cap, unsigned char* __restrict__ mine_f,
+                                                             int* __restrict__ bcnt, int* __restrict__ bbase,
+                                                             int* __restrict__ arrive, u32* __restrict__ done,
+                                                             bh_devinfo* __restrict__ info, int* __restrict__ nloc,
+                                                             int* __restrict__ out, int* __restrict__ hres, int seq) {
   __shared__ u64 sk[64];
   __shared__ int cnt[64];
+  __shared__ int wsum[4];
+  __shared__ int s_last;
   const int nsplit = world - 1;
-  if ((int)threadIdx.x < nsplit) sk[threadIdx.x] = skeys[threadIdx.x];
-  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  const int tid = threadIdx.x;
+  if (tid < nsplit) sk[tid] = skeys[tid];
+  if (tid < 64) cnt[tid] = 0;
   __syncthreads();
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot < world * limit) {
-    const int q = slot / limit, k = slot - q * limit;
-    const int* h = reinterpret_cast<const int*>(g + (size_t)q * f4);
-    const int ne = min(h[2], limit);
-    int f = 0;
-    if (k < ne) {
-      const float4 p = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
-      const u64 key = body_key<kB>(curve, p.x, p.y, p.z, bounds[0], bounds[1], bounds[2], bounds[6]);
-      const int o = owner_of(key, sk, nsplit);
-      atomicAdd(&cnt[o], 1);
-      f = (o == me && q != me) ? 1 : 0;
+  const int q = blockIdx.x / cpr, k0 = (blockIdx.x - q * cpr) * 1024;
+  const int ne = min(reinterpret_cast<const int*>(g + (size_t)q * f4)[2], limit);
+  const float b0 = bounds[0], b1 = bounds[1], b2 = bounds[2], size = bounds[6];
+  int got = 0;
+  if (k0 < ne) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int k = k0 + r * 256 + tid;
+      int mine = 0;
+      if (k < ne) {
+        const float4 p = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
+        const u64 key = body_key<kB>(curve, p.x, p.y, p.z, b0, b1, b2, size);
+        const int o = owner_of(key, sk, nsplit);
+        atomicAdd(&cnt[o], 1);
+        mine = (o == me && q != me) ? 1 : 0;
+      }
+      if (k < limit) mine_f[(size_t)q * limit + k] = (unsigned char)mine;
+      got += mine;
     }
-    flag2[slot] = f;
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) got += __shfl_xor(got, dd, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = got;
+  __syncthreads();
+  if (tid < world && cnt[tid]) atomicAdd(&arrive[tid], cnt[tid]);
+  __syncthreads();
+  if (tid == 0) {
+    bh_publish_i32(bcnt + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    bh_published();  // also covers the arrive[] atomics above: issued by lanes of this same wave (tid < world <= 13)
+    s_last = bh_last_block(done, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
   }
   __syncthreads();
-  if ((int)threadIdx.x < world && cnt[threadIdx.x]) atomicAdd(&nloc[threadIdx.x], cnt[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void dd_absorb_copy_kernel(const float4* __restrict__ g, int world,
-                                                             int limit, size_t f4, int me,
-                                                             const int* __restrict__ flag2,
-                                                             const int* __restrict__ fpos2, int n_cap,
-                                                             float4* __restrict__ posm2,
-                                                             float4* __restrict__ velid2,
-                                                             bh_devinfo* __restrict__ info) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= world * limit || !flag2[slot]) return;
-  const int q = slot / limit, k = slot - q * limit;
-  const int held = reinterpret_cast<const int*>(g + (size_t)me * f4)[3];
-  const int d = held + fpos2[slot];
-  if (d >= n_cap) {
-    atomicOr(&info->flags, BH_FLAG_DD_BODIES);
-    return;
+  if (!s_last) return;
+  __shared__ int carry;
+  __shared__ int part[256];
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  const int nb = (int)gridDim.x;
+  for (int c0 = 0; c0 < nb; c0 += 256) {
+    const int b = c0 + tid;
+    const int v = b < nb ? bh_collect_i32(bcnt + b) : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int dd = 1; dd < 256; dd <<= 1) {
+      const int u = tid >= dd ? part[tid - dd] : 0;
+      __syncthreads();
+      part[tid] += u;
+      __syncthreads();
+    }
+    if (b < nb) bbase[b] = carry + part[tid] - v;
+    __syncthreads();
+    if (tid == 255) carry += part[255];
+    __syncthreads();
   }
-  posm2[d] = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
-  velid2[d] = g[(size_t)q * f4 + 3 + 2 * (size_t)k];
-}
-
-// out: [0] bodies this rank now holds, [1] flags, [2] most emigrants still waiting on any rank,
-// [3] most emigrants found on any rank (sizes the next exchange)
-__global__ void dd_migrate_result_kernel(const float4* __restrict__ g, int world, size_t f4,
-                                         const int* __restrict__ nloc, int me,
-                                         const bh_devinfo* __restrict__ info, int* __restrict__ out) {
-  if (threadIdx.x == 0) {
+  if (tid < world) {
+    const int held = reinterpret_cast<const int*>(g + (size_t)tid * f4)[3];
+    const int a = __hip_atomic_load(arrive + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cnt[tid] = held + a;
+    nloc[tid] = held + a;
+    __hip_atomic_store(arrive + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next call
+  }
+  __syncthreads();
+  if (tid == 0) {
     int left = 0, most = 0;
-    for (int q = 0; q < world; q++) {
-      const int* h = reinterpret_cast<const int*>(g + (size_t)q * f4);
+    for (int r = 0; r < world; r++) {
+      const int* h = reinterpret_cast<const int*>(g + (size_t)r * f4);
       left = max(left, h[0] - h[2]);
       most = max(most, h[0]);
     }
-    out[0] = nloc[me];
-    out[1] = info->flags;
-    out[2] = left;
-    out[3] = most;
+    if (cnt[me] > n_cap) atomicOr(&info->flags, BH_FLAG_DD_BODIES);  // the copy kernel drops what does not fit
+    const int flags = __hip_atomic_load(&info->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[0] = cnt[me]; out[1] = flags; out[2] = left; out[3] = most;
+    hres[0] = cnt[me]; hres[1] = flags; hres[2] = left; hres[3] = most;
+    __hip_atomic_store(hres + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ __launch_bounds__(256) void dd_absorb_copy_kernel(const float4* __restrict__ g, int world, int limit,
+                                                             size_t f4, int cpr, int me, int n_cap,
+                                                             const unsigned char* __restrict__ mine_f,
+                                                             const int* __restrict__ bbase,
+                                                             float4* __restrict__ posm2,
+                                                             float4* __restrict__ velid2) {
+  __shared__ int wcnt[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = blockIdx.x / cpr, k0 = (blockIdx.x - q * cpr) * 1024;
+  const int ne = min(reinterpret_cast<const int*>(g + (size_t)q * f4)[2], limit);
+  if (k0 >= ne) return;
+  const int held = reinterpret_cast<const int*>(g + (size_t)me * f4)[3];
+  int f[4];
+  u64 bal[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int k = k0 + r * 256 + tid;
+    f[r] = (k < ne && mine_f[(size_t)q * limit + k]) ? 1 : 0;
+    bal[r] = __ballot(f[r]);
+    if (lane == 0) wcnt[r][wv] = __popcll(bal[r]);
+  }
+  __syncthreads();
+  int before = held + bbase[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int pre = before;
+    for (int w2 = 0; w2 < wv; w2++) pre += wcnt[r][w2];
+    pre += __popcll(bal[r] & ((1ull << lane) - 1ull));
+    const int k = k0 + r * 256 + tid;
+    if (f[r] && pre < n_cap) {
+      posm2[pre] = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
+      velid2[pre] = g[(size_t)q * f4 + 3 + 2 * (size_t)k];
+    }
+    before += wcnt[r][0] + wcnt[r][1] + wcnt[r][2] + wcnt[r][3];
   }
 }
 
@@ -970,7 +1131,8 @@ void bh_dd_free(bh_ctx* c) {
     (void)hipStreamDestroy(d->stream_own);
   }
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
-                  d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2};
+                  d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2,
+                  d->cls_done, d->abs_done, d->arrive, c->dd_minmax};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->host) (void)hipHostFree(d->host);
@@ -980,6 +1142,8 @@ void bh_dd_free(bh_ctx* c) {
   if (d->ev_top1) (void)hipEventDestroy(d->ev_top1);
 
   c->acc2 = nullptr;
+  c->dd_minmax = nullptr;
+  c->dd_minmax_ok = false;
   free(d);
   c->dd = nullptr;
   c->bounds_next_ok = false;  // the domain-decomposed steps moved and exchanged bodies
@@ -1065,6 +1229,19 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
     ok = ok && hipStreamCreateWithPriority(&d->stream_own, hipStreamNonBlocking, least) == hipSuccess;
   }
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
+  if (ok) memset(d->host, 0, (64 + 8) * sizeof(int));
+  ok = ok && hipMalloc((void**)&c->dd_minmax, 8 * sizeof(float)) == hipSuccess;
+  c->dd_minmax_ok = false;
+  {
+    const size_t nc = (size_t)n_cap / kClsTile / 32 + 8;
+    ok = ok && hipMalloc((void**)&d->cls_done, nc * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMemset(d->cls_done, 0, nc * sizeof(u32)) == hipSuccess;
+    const size_t na = (size_t)world * ((size_t)mig_cap / 1024 + 1) / 32 + 8;
+    ok = ok && hipMalloc((void**)&d->abs_done, na * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMemset(d->abs_done, 0, na * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&d->arrive, 64 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemset(d->arrive, 0, 64 * sizeof(int)) == hipSuccess;
+  }
   ok = ok && hipEventCreateWithFlags(&d->ev_let, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     bh_dd_free(c);
@@ -1096,6 +1273,7 @@ int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const flo
   c->cur = 0;
   c->order_hint = false;  // caller order
   c->bounds_next_ok = false;
+  c->dd_minmax_ok = false;
   dd_pack_ids_kernel<<<(n_loc + 255) / 256, 256, 0, c->stream>>>(c->stage_buf, (const int*)c->vals[0], n_loc,
                                                                   c->posm[0], c->velid[0]);
   BH_HIP(c, hipGetLastError());
@@ -1112,11 +1290,15 @@ int bh_dd_cube_pack(bh_ctx* c, void* send_x1) {
   if (!c || !c->dd || !send_x1) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_UPLOADED)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
-  BH_HIP(c, bhk_bbox_raw(c, (float*)send_x1));
+  // the previous step's integrate kernel already folded this rank's min / max (bh_integrate in dd mode);
+  // after an upload two bbox kernels do
+  if (!c->dd_minmax_ok) BH_HIP(c, bhk_bbox_raw(c, c->dd_minmax));
+  c->dd_minmax_ok = false;
   // stride sized so that a rank holding up to 1.34x its fair share still fits its sample slots
   const double g = 1.34 * (double)d->n_total / (double)kSampTotal;
-  dd_x1_tail_kernel<<<(d->samp_cap + 255) / 256, 256, 0, c->stream>>>((float*)send_x1, c->n, c->posm[c->cur],
-                                                                       g > 1.0 ? g : 1.0, d->samp_cap);
+  const int th = d->samp_cap > 8 ? d->samp_cap : 8;
+  dd_x1_pack_kernel<<<(th + 255) / 256, 256, 0, c->stream>>>((float*)send_x1, c->dd_minmax, c->n, c->posm[c->cur],
+                                                             g > 1.0 ? g : 1.0, d->samp_cap);
   BH_HIP(c, hipGetLastError());
   return BH_OK;
 }
@@ -1125,7 +1307,6 @@ int bh_dd_cube_apply(bh_ctx* c, const void* gathered_x1) {
   if (!c || !c->dd || !gathered_x1) return BH_ERR_BAD_ARG;
   bh_dd_state* d = c->dd;
   const int xf = x1_floats(d->world);
-  BH_HIP(c, bhk_bounds_from_rows(c, (const float*)gathered_x1, d->world, xf));
   dd_split_kernel<<<1, 1024, 0, c->stream>>>((const float*)gathered_x1, d->world, xf, d->samp_cap, c->bounds,
                                              c->p.key_curve, d->skeys);
   BH_HIP(c, hipGetLastError());
@@ -1140,15 +1321,21 @@ int bh_dd_migrate_pack(bh_ctx* c, void* send_x2, int limit) {
   bh_dd_state* d = c->dd;
   if (limit < 1 || limit > d->mig_cap) return BH_ERR_BAD_ARG;
   const int n = c->n;
-  BH_HIP(c, bhk_keys(c, false));  // classification only: no sort follows
-  const int blocks = (n + 255) / 256 > 0 ? (n + 255) / 256 : 1;
-  dd_classify_kernel<<<blocks, 256, 0, c->stream>>>(c->keys[0], n, d->skeys, d->world - 1, d->rank, d->flag);
-  BH_HIP(c, hipGetLastError());
-  BH_HIP(c, bhk_scan_i32(c, d->flag, d->fpos, n, nullptr));
-  dd_compact_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], n, d->flag, d->fpos,
+  const int blocks = (n + kClsTile - 1) / kClsTile > 0 ? (n + kClsTile - 1) / kClsTile : 1;
+  unsigned char* kept = reinterpret_cast<unsigned char*>(d->flag);
+  int* bcnt = d->fpos;
+  int* bbase = d->fpos + blocks + 1;
+  dd_classify_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], n, c->bounds, c->p.key_curve, d->skeys,
+                                                    d->world - 1, d->rank, kept, bcnt, bbase, d->cls_done,
+                                                    (int*)send_x2, limit);
+  dd_compact_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], n, kept, bbase,
                                                    c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], (float4*)send_x2,
                                                    limit);
   BH_HIP(c, hipGetLastError());
+  if (c->keys_split) {  // bucket counts of keys that no sort consumed (an earlier round of this step): void them
+    BH_HIP(c, hipMemsetAsync(c->sp_count + 256 * (c->sp_par & 1), 0, 256 * sizeof(u32), c->stream));
+    c->keys_split = false;
+  }
   c->cur ^= 1;
   return BH_OK;
 }
@@ -1160,21 +1347,37 @@ int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_lo
   if (limit < 1 || limit > d->mig_cap) return BH_ERR_BAD_ARG;
   const float4* g = (const float4*)gathered_x2;
   const size_t f4 = 2 + 2 * (size_t)limit;
-  const int slots = d->world * limit;
   const int n_cap = (c->rec_cap - 8) / 3;
-  dd_nloc_init_kernel<<<1, 64, 0, c->stream>>>(g, d->world, f4, d->nloc);
-  dd_absorb_flag_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, c->bounds,
-                                                                    c->p.key_curve, d->skeys, d->rank, d->flag,
-                                                                    d->nloc);
+  const int seq = ++d->absorb_seq;
+  const int cpr = (limit + 1023) / 1024;  // blocks per rank
+  const int blocks = d->world * cpr;
+  unsigned char* mine_f = reinterpret_cast<unsigned char*>(d->flag);
+  int* bcnt = d->fpos;
+  int* bbase = d->fpos + blocks + 1;
+  dd_absorb_flag_kernel<<<blocks, 256, 0, c->stream>>>(g, d->world, limit, f4, cpr, c->bounds, c->p.key_curve, d->skeys,
+                                                       d->rank, n_cap, mine_f, bcnt, bbase, d->arrive, d->abs_done,
+                                                       c->info, d->nloc, d->ddi + 4, d->host + 64, seq);
+  dd_absorb_copy_kernel<<<blocks, 256, 0, c->stream>>>(g, d->world, limit, f4, cpr, d->rank, n_cap, mine_f, bbase,
+                                                       c->posm[c->cur], c->velid[c->cur]);
   BH_HIP(c, hipGetLastError());
-  BH_HIP(c, bhk_scan_i32(c, d->flag, d->fpos, slots, nullptr));
-  dd_absorb_copy_kernel<<<(slots + 255) / 256, 256, 0, c->stream>>>(g, d->world, limit, f4, d->rank, d->flag,
-                                                                    d->fpos, n_cap, c->posm[c->cur],
-                                                                    c->velid[c->cur], c->info);
-  dd_migrate_result_kernel<<<1, 64, 0, c->stream>>>(g, d->world, f4, d->nloc, d->rank, c->info, d->ddi + 4);
-  BH_HIP(c, hipGetLastError());
-  BH_HIP(c, hipMemcpyAsync(d->host + 64, d->ddi + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  BH_HIP(c, hipStreamSynchronize(c->stream));
+  // the host needs the new body count before it can size the next launches: poll the pinned result words (a
+  // few microseconds after the kernel's store) instead of hipStreamSynchronize (tens of microseconds of wake-up
+  // latency: a 40 us hole on the stream in round 2's trace); bounded, then the stream wait decides
+  {
+    volatile int* hs = d->host + 68;
+    bool seen = false;
+    for (long spin = 0; spin < 400000000L; spin++) {
+      if (__atomic_load_n(hs, __ATOMIC_ACQUIRE) == seq) {
+        seen = true;
+        break;
+      }
+      if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(c->stream) != hipErrorNotReady) break;
+    }
+    if (!seen) {
+      BH_HIP(c, hipStreamSynchronize(c->stream));
+      if (__atomic_load_n(hs, __ATOMIC_ACQUIRE) != seq) return BH_ERR_HIP;
+    }
+  }
   const int nl = d->host[64], flags = d->host[65];
   if (n_loc) *n_loc = nl;
   if (more) *more = d->host[66] > 0 ? 1 : 0;
@@ -1321,6 +1524,44 @@ int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts) {
     if (d->host[q] > worst) worst = d->host[q];
   }
   return worst > stride ? BH_ERR_SMALL_BUFFER : BH_OK;
+}
+
+// ---- one entry point per phase group: the per-step protocol of dist.DomainStepper in five calls (each is the
+// plain sequence of the fine-grained entry points above, which stay for tests and for the failure paths)
+int bh_dd_phase_migrate(bh_ctx* c, const void* gathered_x1, void* send_x2, int limit) {
+  const int s = bh_dd_cube_apply(c, gathered_x1);
+  return s ? s : bh_dd_migrate_pack(c, send_x2, limit);
+}
+
+int bh_dd_phase_tree(bh_ctx* c, const void* gathered_x2, int limit, void* send_x3, int* n_loc, int* more,
+                     int* most) {
+  int m = 0;
+  const int s = bh_dd_migrate_apply(c, gathered_x2, limit, n_loc, &m, most);
+  if (more) *more = m;
+  if (s || m) return s;  // another migration round first
+  return bh_dd_tree(c, send_x3);
+}
+
+int bh_dd_phase_let(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride, int own_pass) {
+  if (own_pass) {
+    const int s = bh_dd_force_local(c, gathered_x3);
+    if (s) return s;
+  }
+  return bh_dd_let_pack(c, gathered_x3, send_x4, stride);
+}
+
+int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* counts, int* fits) {
+  int s = bh_dd_top(c, gathered_x3, stride);
+  if (!s) s = bh_dd_force(c);
+  if (s) return s;
+  s = bh_dd_let_check(c, stride, counts);
+  if (fits) *fits = (s == BH_OK) ? 1 : 0;
+  return (s == BH_ERR_SMALL_BUFFER) ? BH_OK : s;
+}
+
+int bh_dd_phase_end(bh_ctx* c, void* send_x1) {
+  const int s = bh_integrate(c);
+  return s ? s : bh_dd_cube_pack(c, send_x1);
 }
 
 int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc) {

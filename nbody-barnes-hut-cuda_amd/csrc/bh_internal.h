@@ -164,6 +164,8 @@ struct bh_ctx {
   // domain-decomposed stepping (bh_dd.hip); null until bh_dd_init
   struct bh_dd_state* dd;
   bh_frec* frec_own;  // the context's own record pool while frec points into a caller pool
+  float* dd_minmax;   // [8] dd mode: this rank's min / max of the positions the last integrate wrote (X1 payload)
+  bool dd_minmax_ok;  // set by bh_integrate in dd mode, cleared by anything else that writes positions
 
   // counters (bh_force_count)
   u32 *cV, *cO, *cP;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void integrate_kernel(float4* __restrict__ po
                                                          const float4* __restrict__ acc2, int n, float DT,
                                                          float MAX_SPEED, float* __restrict__ rows,
                                                          u32* __restrict__ done_count,
-                                                         float* __restrict__ bounds_next) {
+                                                         float* __restrict__ bounds_next, int raw) {
   float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
   float mx[3] = {-1e10f, -1e10f, -1e10f};
   constexpr int kPer = BH_INTEGRATE_TILE / 1024;
@@ -201,7 +201,14 @@ __global__ __launch_bounds__(1024) void integrate_kernel(float4* __restrict__ po
   }
   __syncthreads();  // lds is reused
   block_minmax(fn, fx, lds);
-  if (threadIdx.x == 0) write_cube(fn, fx, bounds_next);
+  if (threadIdx.x == 0) {
+    if (raw) {  // domain-decomposed step: this rank's min / max go into the X1 exchange, the cube comes after it
+      bounds_next[0] = fn[0]; bounds_next[1] = fn[1]; bounds_next[2] = fn[2];
+      bounds_next[3] = fx[0]; bounds_next[4] = fx[1]; bounds_next[5] = fx[2];
+    } else {
+      write_cube(fn, fx, bounds_next);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ keys
@@ -1159,11 +1166,11 @@ hipError_t bhk_integrate(bh_ctx* c, bool with_bbox) {
     integrate_kernel<true><<<blocks, 1024, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2, n,
                                                            c->p.dt, c->p.max_speed, c->ibox_rows,
                                                            c->blk_done2,
-                                                           c->bounds_next);
+                                                           c->dd ? c->dd_minmax : c->bounds_next, c->dd ? 1 : 0);
   else
     integrate_kernel<false><<<blocks, 1024, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2,
                                                             n, c->p.dt, c->p.max_speed, nullptr, nullptr,
-                                                            nullptr);
+                                                            nullptr, 0);
   return hipGetLastError();
 }
 

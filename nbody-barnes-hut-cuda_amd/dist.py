@@ -35,11 +35,20 @@ def slab_bounds(n, world, rank):
     return slab, lo, hi
 
 
-def all_gather_rows(out, send, group=None):
+def _into_tensor_ok(group=None):
+    """all_gather_into_tensor exists on the "nccl" (= RCCL) backend; gloo (CPU rehearsal) takes the list form.
+    Decided from the backend NAME, once — never by catching the failure of a collective: a rank that falls back
+    alone after a failed collective would leave the others inside a different one."""
+    return str(dist.get_backend(group)).lower() == "nccl"
+
+
+def all_gather_rows(out, send, group=None, into_tensor=None):
     """out[world*slab, 4] <- concatenation of every rank's send[slab, 4]."""
-    try:
+    if into_tensor is None:
+        into_tensor = _into_tensor_ok(group)
+    if into_tensor:
         dist.all_gather_into_tensor(out, send, group=group)
-    except (RuntimeError, NotImplementedError):
+    else:
         world = dist.get_world_size(group)
         chunks = list(out.view(world, -1, out.shape[-1]).unbind(0))
         dist.all_gather(chunks, send, group=group)
@@ -57,6 +66,7 @@ class ShardedStepper:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.slab, self.lo, self.hi = slab_bounds(self.n, self.world, self.rank)
+        self.into_tensor = _into_tensor_ok(group) if dist.is_initialized() else False
         assert acc.shape == (self.world * self.slab, 4) and acc.dtype == torch.float32
         self.send = torch.zeros((self.slab, 4), dtype=acc.dtype, device=acc.device)
 
@@ -67,7 +77,7 @@ class ShardedStepper:
             if self.world > 1:                   # the one exchange step
                 row0 = self.rank * self.slab
                 self.send.copy_(self.acc[row0:row0 + self.slab])
-                all_gather_rows(self.acc, self.send, self.group)
+                all_gather_rows(self.acc, self.send, self.group, self.into_tensor)
             self.e.integrate()                   # replicated
 
 
@@ -100,9 +110,10 @@ class TorchComm:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.into_tensor = _into_tensor_ok(group)   # chosen once, from the backend
 
     def all_gather(self, out, send):
-        all_gather_rows(out.view(self.world, -1), send.view(1, -1), self.group)
+        all_gather_rows(out.view(self.world, -1), send.view(1, -1), self.group, self.into_tensor)
 
 
 class LocalGroup:
@@ -233,8 +244,8 @@ class DomainStepper:
         return self
 
     # ---- optional per-phase device timing (events on the main stream; bench.py reports the means) ----
-    PHASES = ("x1_cube_splitters", "x2_migration", "local_tree_x3", "let_export_x4", "top_remote_force",
-              "integrate")
+    PHASES = ("x1_exchange", "cube_splitters_x2_migration_local_tree", "x3_exchange", "let_export_x4",
+              "top_remote_force", "integrate_pack_x1")
 
     def set_profile(self, on=True):
         self._prof = [] if on and self.stream is not None else None
@@ -268,27 +279,81 @@ class DomainStepper:
         import contextlib
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
+    # ---- phase groups: one C call each (bh_dd_phase_*) when the engine has them; the scripted stand-in of
+    # tests/dd_cpu_worker.py only has the fine-grained calls, which these fall back to
+    def _phase_migrate(self, limit):
+        e = self.e
+        if hasattr(e, "dd_phase_migrate"):
+            e.dd_phase_migrate(self.x1r.data_ptr(), self.x2s.data_ptr(), limit)
+        else:
+            e.dd_cube_apply(self.x1r.data_ptr())
+            e.dd_migrate_pack(self.x2s.data_ptr(), limit)
+
+    def _phase_tree(self, limit):
+        e = self.e
+        if hasattr(e, "dd_phase_tree"):
+            return e.dd_phase_tree(self.x2r.data_ptr(), limit, self.x3s.data_ptr())
+        n_loc, more, most = e.dd_migrate_apply(self.x2r.data_ptr(), limit)
+        if not more:
+            e.dd_tree(self.x3s.data_ptr())
+        return n_loc, more, most
+
+    def _phase_let(self, stride, own_pass):
+        e = self.e
+        if hasattr(e, "dd_phase_let"):
+            e.dd_phase_let(self.x3r.data_ptr(), self.lets.data_ptr(), stride, own_pass)
+        else:
+            if own_pass:
+                e.dd_force_local(self.x3r.data_ptr())
+            e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
+
+    def _phase_force(self, stride):
+        e = self.e
+        if hasattr(e, "dd_phase_force"):
+            return e.dd_phase_force(self.x3r.data_ptr(), stride, self.world)
+        e.dd_top(self.x3r.data_ptr(), stride)
+        e.dd_force()
+        return e.dd_let_check(stride, self.world)
+
+    def _phase_end(self):
+        e = self.e
+        if hasattr(e, "dd_phase_end"):
+            e.dd_phase_end(self.x1s.data_ptr())
+        else:
+            e.integrate()
+            e.dd_cube_pack(self.x1s.data_ptr())
+        self._x1_ready = True   # the next step's X1 payload is packed
+
     def step(self, steps=1):
+        """Five library calls and four all-gathers per step in the common case:
+             [X1] phase_migrate [X2] phase_tree [X3] phase_let [X4] phase_force, phase_end
+           (extra migration rounds, a LET retry and the collective handling of a rank-local failure use the
+           fine-grained entry points)."""
         e, c, sz, P = self.e, self.comm, self.sz, self.world
         with self._on_stream():
             for _ in range(int(steps)):
                 self._mark(0)
-                e.dd_cube_pack(self.x1s.data_ptr())                    # X1: cube + splitters
+                if not getattr(self, "_x1_ready", False):
+                    e.dd_cube_pack(self.x1s.data_ptr())                # X1: cube + splitters (first step only:
+                self._x1_ready = False                                 # afterwards the previous step packed it)
                 c.all_gather(self.x1r, self.x1s)
-                e.dd_cube_apply(self.x1r.data_ptr())
                 self._mark(1)
                 limit, first = self.mig_stride, None                   # X2: bodies that changed owner
                 failed = None   # a rank-local failure must not strand the others inside a collective: the
-                while True:     # failing rank keeps taking part with empty payloads and marks its LET segment
+                rounds = 0      # failing rank keeps taking part with empty payloads and marks its LET segment
+                while True:
                     nb = 32 + 32 * limit
-                    if failed is None:
-                        e.dd_migrate_pack(self.x2s.data_ptr(), limit)
-                    else:
+                    if failed is not None:
                         self.x2s[:32].zero_()
+                    elif rounds == 0:
+                        self._phase_migrate(limit)                     # global cube + splitters, emigrants packed
+                    else:
+                        e.dd_migrate_pack(self.x2s.data_ptr(), limit)
+                    rounds += 1
                     c.all_gather(self.x2r[:P * nb], self.x2s[:nb])
                     if failed is None:
-                        try:
-                            self.n_loc, more, most = e.dd_migrate_apply(self.x2r.data_ptr(), limit)
+                        try:   # immigrants absorbed; once no rank has emigrants left: local sort / build / COM,
+                            self.n_loc, more, most = self._phase_tree(limit)   # X3 piece descriptors packed
                         except Exception as ex:  # noqa: BLE001 - e.g. more bodies than this context can hold
                             failed = ex
                     if failed is not None:
@@ -302,14 +367,11 @@ class DomainStepper:
                 self.mig_last = first
                 self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 2.0 + 4096, 256)))
                 self._mark(2)
-                if failed is None:
-                    e.dd_tree(self.x3s.data_ptr())                     # local sort/build/COM; X3: pieces
-                else:
+                if failed is not None:
                     self.x3s.zero_()
                 c.all_gather(self.x3r, self.x3s)
                 self._mark(3)
-                if failed is None and self.split:
-                    e.dd_force_local(self.x3r.data_ptr())              # own pieces, side stream, overlaps X4
+                tries = 0
                 while True:
                     stride = self.stride
                     seg = self.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32]
@@ -319,12 +381,12 @@ class DomainStepper:
                         # digest pair: field `first` is dword 10, csrc/bh_internal.h)
                         c.all_gather(seg, self.lets[:stride * 32])
                         raise DomainLeft(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
-                    e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
+                    # own pieces on the side stream (first try only: it overlaps X4), LET marked / exported
+                    self._phase_let(stride, self.split and tries == 0)
+                    tries += 1
                     c.all_gather(seg, self.lets[:stride * 32])          # X4: LET records, in place
                     self._mark(4)
-                    e.dd_top(self.x3r.data_ptr(), stride)
-                    e.dd_force()
-                    ok, counts = e.dd_let_check(stride, P)
+                    ok, counts = self._phase_force(stride)              # top tree, remote (or whole) pass, X4 sizes
                     self.let_counts = counts
                     if int(counts.min()) < 0:
                         raise DomainLeft(f"rank {int(counts.argmin())} left the domain-decomposed step")
@@ -338,7 +400,7 @@ class DomainStepper:
                 # every rank sees the same counts, so every rank picks the same next stride
                 self.stride = max(sz.let_min, min(self.let_cap, _round_up(need * 1.15 + 1024, 256)))
                 self._mark(5)
-                e.integrate()
+                self._phase_end()                                       # integrate + the next step's X1 payload
                 self._mark(6)
                 self._close_marks()
 

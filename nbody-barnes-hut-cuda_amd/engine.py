@@ -338,6 +338,35 @@ class Engine:
             raise BhError(st, "bh_dd_let_check")
         return st == 0, counts
 
+    # one call per phase group (bh_dd_phase_*): what DomainStepper.step uses
+    def dd_phase_migrate(self, gathered_x1_ptr, send_x2_ptr, limit):
+        self._ck(lib.bh_dd_phase_migrate(self._h, C.c_void_p(int(gathered_x1_ptr)), C.c_void_p(int(send_x2_ptr)),
+                                         int(limit)), "bh_dd_phase_migrate")
+
+    def dd_phase_tree(self, gathered_x2_ptr, limit, send_x3_ptr):
+        """(bodies now held, another migration round needed, most emigrants found on any rank)"""
+        n_loc, more, most = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._ck(lib.bh_dd_phase_tree(self._h, C.c_void_p(int(gathered_x2_ptr)), int(limit),
+                                      C.c_void_p(int(send_x3_ptr)), C.byref(n_loc), C.byref(more), C.byref(most)),
+                 "bh_dd_phase_tree")
+        self.n = n_loc.value
+        return self.n, bool(more.value), most.value
+
+    def dd_phase_let(self, gathered_x3_ptr, send_x4_ptr, stride, own_pass):
+        self._ck(lib.bh_dd_phase_let(self._h, C.c_void_p(int(gathered_x3_ptr)), C.c_void_p(int(send_x4_ptr)),
+                                     int(stride), 1 if own_pass else 0), "bh_dd_phase_let")
+
+    def dd_phase_force(self, gathered_x3_ptr, stride, world):
+        """(fits, counts): top tree + remote (or whole) force pass + the records every rank needed in X4"""
+        counts = np.zeros(world, np.int32)
+        fits = C.c_int(0)
+        self._ck(lib.bh_dd_phase_force(self._h, C.c_void_p(int(gathered_x3_ptr)), int(stride),
+                                       counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(fits)), "bh_dd_phase_force")
+        return bool(fits.value), counts
+
+    def dd_phase_end(self, send_x1_ptr):
+        self._ck(lib.bh_dd_phase_end(self._h, C.c_void_p(int(send_x1_ptr))), "bh_dd_phase_end")
+
     def dd_download(self):
         """local bodies in local Morton order: posm [n,4], vel [n,3], ids [n], acc [n,3]"""
         n = self.n

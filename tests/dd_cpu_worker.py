@@ -35,10 +35,12 @@ class ScriptedEngine:
         self.st = st
 
     # X1
-    def dd_cube_pack(self, ptr):
+    def dd_cube_pack(self, ptr):   # the product packs the NEXT step's X1 payload at the end of every step
+        self.calls.append("cube_pack")
+        if self.step_no + 1 >= len(self.emig):
+            return                 # the pack after the last scripted step
         self.step_no += 1
         self.left = self.emig[self.step_no][self.rank]
-        self.calls.append("cube_pack")
 
     def dd_cube_apply(self, ptr):
         pass
@@ -110,7 +112,7 @@ def main():
     except RuntimeError as ex:
         err = str(ex)
     res = {"rank": r, "error": err, "mig_rounds": st.mig_rounds, "let_retries": st.let_retries,
-           "stride": int(st.stride), "mig_stride": int(st.mig_stride), "steps_done": eng.step_no + 1,
+           "stride": int(st.stride), "mig_stride": int(st.mig_stride), "steps_done": eng.calls.count("integrate"),
            "integrates": eng.calls.count("integrate"), "force_local": eng.calls.count("force_local")}
     gathered = [None] * P
     dist.all_gather_object(gathered, res)
