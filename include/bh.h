@@ -194,6 +194,9 @@ int bh_download_bounds(bh_ctx* c, float bounds[6]);                      /* ref:
 int bh_download_keys(bh_ctx* c, uint64_t* keys);   /* current (sorted after bh_sort) order      */
 int bh_download_order(bh_ctx* c, int32_t* ids);    /* caller index of the body at each sorted slot */
 int bh_download_sorted_bodies(bh_ctx* c, float* xyzm /* 4n floats */);
+/* the canonical tree records: valid after bh_com (stage calls) or after a bh_step of a strict_fp / literal_force
+   context; a bh_step of the default engine writes only the force kernel's digests and bh_build alone leaves the
+   centres of mass unset — BH_ERR_ORDER in both cases (the entry count is still returned when out == NULL) */
 int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries);
 int bh_download_counters(bh_ctx* c, uint32_t* V, uint32_t* O, uint32_t* P); /* caller order */
 int bh_download_mass(bh_ctx* c, float* m);                              /* caller order      */

@@ -473,7 +473,8 @@ static int step_launch(bh_ctx* c) {
   BH_HIP(c, bhk_build(c));                     // ref:266-275
   BH_MARK(4);
   if (fork) BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
-  BH_HIP(c, bhk_com_records(c));               // ref:279-280
+  // digests only unless something reads the canonical records after this step (strict / literal kernels)
+  BH_HIP(c, bhk_com_records(c, c->p.strict_fp || c->p.literal_force || c->dd));  // ref:279-280
   BH_MARK(5);
   BH_HIP(c, bhk_force(c, 0, c->n, false));     // ref:281
   BH_MARK(6);
@@ -658,6 +659,9 @@ static int fetch_info(bh_ctx* c, bh_devinfo* h) {
 
 int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries) {
   BH_NEED_EVER(c, BH_ST_BUILD);
+  // bh_step of the default engine writes only the force kernel's digests; the canonical records exist after the
+  // stage calls (bh_build + bh_com) or after a step of a strict_fp / literal_force context
+  if (out && c->rec_proto) return BH_ERR_ORDER;
   bh_devinfo hi;
   int s = fetch_info(c, &hi);
   if (s) return s;

@@ -1407,7 +1407,7 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
   BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
   BH_HIP(c, bhk_build(c));
   BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
-  BH_HIP(c, bhk_com_records(c));
+  BH_HIP(c, bhk_com_records(c, true));
   dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->er_lo, c->er_hi, c->info, c->rec_cap,
                                                                    c->n, d->piece_tmp, d->ddi);
   dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, d->ddi, c->rec, c->er_lo, c->er_hi,

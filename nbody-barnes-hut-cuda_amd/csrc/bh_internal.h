@@ -145,8 +145,9 @@ struct bh_ctx {
   bh_node* rec;   // [rec_cap] tree records (canonical: ABI download, strict/counting kernels)
   bh_frec* frec;  // [BH_FREC_POOL] digests for the fast force kernel (written by COM, pair layout): tree records,
                   // then BH_BODY_DIGEST slots (used only for the bodies of unsplit multi-body cells)
-  int* er_lo;     // [rec_cap] body range of each record
+  int* er_lo;     // [rec_cap] body range of each record (written by the canonical COM stage)
   int* er_hi;
+  bool rec_proto; // rec / er_lo / er_hi were NOT made canonical by the last COM stage (bh_step of the default engine)
   int rec_cap;
   bh_d4* P;       // [n+1] fp64 exclusive prefix of (m, m x, m y, m z) over sorted bodies
   bh_devinfo* info;
@@ -268,6 +269,6 @@ void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);
 hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out /* n+1 */, int n);  // of (in[i]+1)&~1
 hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n, bool side);
-hipError_t bhk_com_records(bh_ctx* c);  // second half of bhk_com: records from the prefix sums
+hipError_t bhk_com_records(bh_ctx* c, bool canonical);  // second half of bhk_com: records from the prefix sums
 size_t bhk_scan_tmp_bytes(int n);
 size_t bhk_scan_cnt_offset(int n);

@@ -782,6 +782,15 @@ __device__ __forceinline__ bh_node make_child(const u64* __restrict__ k, int B, 
   return r;
 }
 
+// The build writes ONE 32-byte store per record: the record's body range [lo, hi) travels in the bit patterns of
+// x and y (the centre of mass is not known yet).  The COM stage reads it from there; the separate er_lo / er_hi
+// arrays and the record's x, y, z, m are written by the COM stage only in its canonical mode (com_kernel<true>).
+__device__ __forceinline__ void put_rec(bh_node* __restrict__ rec, int e, bh_node r, int lo, int hi) {
+  r.x = __int_as_float(lo);
+  r.y = __int_as_float(hi);
+  rec[e] = r;
+}
+
 __device__ __forceinline__ bh_node pad_entry() {
   bh_node r;
   r.x = r.y = r.z = r.m = r.s = 0.0f;
@@ -845,11 +854,8 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     const int E = BH_BLOCK0 + tpre[ntiles];
     info->n_entries = E;
     if (E > rec_cap) atomicOr(&info->flags, BH_FLAG_POOL_OVERFLOW);
-    rec[0] = make_child(k, B, D, cap, s0, pn, cb, tpre, tshift, 0, n, 0);
-    er_lo[0] = 0;
-    er_hi[0] = n;
-    rec[1] = pad_entry();  // child blocks start at even entries (BH_BLOCK0)
-    er_lo[1] = er_hi[1] = 0;
+    put_rec(rec, 0, make_child(k, B, D, cap, s0, pn, cb, tpre, tshift, 0, n, 0), 0, n);
+    put_rec(rec, 1, pad_entry(), 0, 0);  // child blocks start at even entries (BH_BLOCK0)
   }
   // Every record is written by a thread that knows it without searching: an emitted cell's thread (its
   // representative pair) writes the cell's OWN record into its parent's child block, and with leaf_cap = 1 the
@@ -908,8 +914,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       continue;
     }
     if (nc & 1) {  // a block of an odd number of children is followed by one padding entry
-      rec[e + nc] = pad_entry();
-      er_lo[e + nc] = er_hi[e + nc] = 0;
+      put_rec(rec, e + nc, pad_entry(), 0, 0);
     }
     // ---- leaf_cap > 1: the parent writes its leaf children (runs between the positions with d == L in (qa, qb),
     // p being the first); internal children still write themselves
@@ -938,9 +943,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
           r.s = ldexpf(s0, -D);
         }
         if (leaf) {
-          rec[e + q] = r;
-          er_lo[e + q] = base + c0;
-          er_hi[e + q] = base + c1;
+          put_rec(rec, e + q, r, base + c0, base + c1);
         }
         c0 = c1;
         if (c1 < qb) {
@@ -975,9 +978,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       rr.first = e_[r];
       rr.count = nc_[r];
       rr.kind = BH_KIND_INTERNAL;
-      rec[ep_[r]] = rr;
-      er_lo[ep_[r]] = a_[r];
-      er_hi[ep_[r]] = b_[r];
+      put_rec(rec, ep_[r], rr, a_[r], b_[r]);
     }
     if (el_[r] < rec_cap) {
       bh_node rr;
@@ -991,9 +992,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
         rr.kind = BH_KIND_MULTI;  // never branches above the depth cap: unsplit multi-body cell at level D
         rr.s = ldexpf(s0, -D);
       }
-      rec[el_[r]] = rr;
-      er_lo[el_[r]] = base + p;
-      er_hi[el_[r]] = base + p + cntl_[r];
+      put_rec(rec, el_[r], rr, base + p, base + p + cntl_[r]);
     }
   }
   __syncthreads();
@@ -1025,17 +1024,14 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       if (nonempty) {
         const int e = BH_BLOCK0 + BH_CB(j) + __popcll(grp & ((1ull << sub) - 1ull));
         if (e < rec_cap) {
-          rec[e] = make_child(k, B, D, cap, s0, pn, cb, tpre, tshift, l, nxt, L + 1, n, s_samp, ns, ss);
-          er_lo[e] = l;
-          er_hi[e] = nxt;
+          put_rec(rec, e, make_child(k, B, D, cap, s0, pn, cb, tpre, tshift, l, nxt, L + 1, n, s_samp, ns, ss), l, nxt);
         }
       }
       if (sub == 0) {
         const int nc = __popcll(grp);
         const int e = BH_BLOCK0 + BH_CB(j) + nc;
         if ((nc & 1) && e < rec_cap) {
-          rec[e] = pad_entry();
-          er_lo[e] = er_hi[e] = 0;
+          put_rec(rec, e, pad_entry(), 0, 0);
         }
       }
     }
@@ -1044,10 +1040,14 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
 }
 
 // ------------------------------------------------------------------ COM
+// CANON: also write the canonical tree — the record's centre of mass / mass and the er_lo / er_hi arrays (what
+// bh_download_tree, the strict and counting kernels and the domain-decomposed step read).  A whole step of the
+// default engine needs only the digests (CANON = false): 24 bytes less traffic per record in an HBM-bound kernel.
+template <bool CANON>
 __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_frec* __restrict__ frec,
                                                   float G, float theta,
-                                                  const int* __restrict__ er_lo,
-                                                  const int* __restrict__ er_hi,
+                                                  int* __restrict__ er_lo,
+                                                  int* __restrict__ er_hi,
                                                   const bh_devinfo* __restrict__ info, int rec_cap,
                                                   const float4* __restrict__ posm,
                                                   const bh_d4* __restrict__ P) {
@@ -1058,8 +1058,13 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
   // then write the 64-byte pair of records 2p, 2p+1 with four 16-byte stores (pair layout: bh_internal.h)
   bh_frec fr = frec_null();
   if (e < E) {
-    const int lo = er_lo[e], hi = er_hi[e];
     const bh_node r = rec[e];
+    const int lo = __float_as_int(r.x), hi = __float_as_int(r.y);  // put_rec: the body range
+    if (CANON) {
+      er_lo[e] = lo;
+      er_hi[e] = hi;
+      if (r.kind == BH_KIND_PAD) *reinterpret_cast<float4*>(&rec[e]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (r.kind != BH_KIND_PAD) {
       float4 o;
       if (r.kind == BH_KIND_BODY) {
@@ -1081,7 +1086,7 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
         }
       }
       // x,y,z,m are the first 16 bytes of the record
-      *reinterpret_cast<float4*>(&rec[e]) = o;
+      if (CANON) *reinterpret_cast<float4*>(&rec[e]) = o;
       fr.x = o.x; fr.y = o.y; fr.z = o.z;
       const bool massive = o.w > 0.0f;  // ref:203: records with mass <= 0 are skipped
       fr.gm = massive ? G * o.w : 0.0f;
@@ -1199,6 +1204,7 @@ extern "C" int bh_debug_tree_trace(void* out) {
 
 hipError_t bhk_build(bh_ctx* c) {
   const int n = c->n;
+  c->rec_proto = true;  // records carry their body range in x / y until the (canonical) COM stage has run
   const u64* k = c->keys[c->key_buf];
   // every 2^ss-th key, at most kSampMax of them: bisection seeds of the wide-cell searches
   int ss = 12;
@@ -1231,12 +1237,19 @@ hipError_t bhk_build(bh_ctx* c) {
 hipError_t bhk_com(bh_ctx* c) {
   hipError_t e = bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, false);
   if (e != hipSuccess) return e;
-  return bhk_com_records(c);
+  return bhk_com_records(c, true);
 }
 
-hipError_t bhk_com_records(bh_ctx* c) {
+// canonical = false: digests only (bh_step of the default engine); the canonical records then stay in the
+// build's form (body range in x / y) until a stage call (bh_com) or a canonical step rewrites them
+hipError_t bhk_com_records(bh_ctx* c, bool canonical) {
   const int blocks = (c->rec_cap + 255) / 256;
-  com_kernel<<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info, c->rec_cap,
-                                            c->posm[c->cur], c->P);
+  if (canonical)
+    com_kernel<true><<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info,
+                                                    c->rec_cap, c->posm[c->cur], c->P);
+  else
+    com_kernel<false><<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info,
+                                                     c->rec_cap, c->posm[c->cur], c->P);
+  c->rec_proto = !canonical;
   return hipGetLastError();
 }
