@@ -133,7 +133,11 @@ typedef struct bh_stats {
   int32_t force_redo_waves; /* fast force kernel: waves (64 bodies) since upload that redid their walk with the
                                generic loop (cross-lane stack deeper than 64 entries, or an unsplit cell of
                                more than 8 bodies); a speed matter only                                   */
-  int32_t reserved[7];
+  int32_t sort_slow_buckets; /* splitter sort: buckets since upload that did not fit LDS and were sorted by one
+                                workgroup through global memory (many equal keys, or an order that drifted far);
+                                once bh_get_stats has seen one, the context sorts with the radix passes until the
+                                next upload                                                                */
+  int32_t reserved[6];
 } bh_stats;
 
 #define BH_FLAG_POOL_OVERFLOW 1

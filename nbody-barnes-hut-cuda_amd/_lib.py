@@ -41,7 +41,7 @@ class BhStats(C.Structure):
         ("ms_build", C.c_float), ("ms_com", C.c_float), ("ms_force", C.c_float),
         ("ms_integrate", C.c_float), ("ms_step", C.c_float),
         ("count_V", C.c_uint64), ("count_O", C.c_uint64), ("count_P", C.c_uint64),
-        ("force_redo_waves", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("force_redo_waves", C.c_int32), ("sort_slow_buckets", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 

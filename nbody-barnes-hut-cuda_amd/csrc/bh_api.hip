@@ -281,6 +281,8 @@ int bh_upload(bh_ctx* c, const float* x, const float* y, const float* z, const f
     BH_HIP(c, hipMemcpyAsync(c->stage_buf + k * N, src[k], nb, hipMemcpyHostToDevice, c->stream));
   c->cur = 0;
   c->order_hint = false;  // caller order: nothing for the splitter sort to exploit
+  c->splitter_off = false;
+  c->slow_seen = 0;       // (the counter itself is cleared with the device info block below)
   c->bounds_next_ok = false;
   BH_HIP(c, bhk_pack(c));
   BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));  // clears the sticky flags
@@ -697,6 +699,11 @@ int bh_get_stats(bh_ctx* c, bh_stats* st) {
     BH_HIP(c, hipEventElapsedTime(&st->ms_step, ev[0], ev[7]));
   }
   st->force_redo_waves = hi.redo_waves;
+  st->sort_slow_buckets = hi.slow_buckets;
+  if (hi.slow_buckets > c->slow_seen) {  // the splitter sort met buckets beyond its LDS capacity: stop using it
+    c->slow_seen = hi.slow_buckets;
+    c->splitter_off = true;
+  }
   st->count_V = c->tV;
   st->count_O = c->tO;
   st->count_P = c->tP;

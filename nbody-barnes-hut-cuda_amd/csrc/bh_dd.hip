@@ -1277,6 +1277,8 @@ int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const flo
   dd_pack_ids_kernel<<<(n_loc + 255) / 256, 256, 0, c->stream>>>(c->stage_buf, (const int*)c->vals[0], n_loc,
                                                                   c->posm[0], c->velid[0]);
   BH_HIP(c, hipGetLastError());
+  c->splitter_off = false;
+  c->slow_seen = 0;
   BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));
   BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));
   BH_HIP(c, hipStreamSynchronize(c->stream));

@@ -77,7 +77,8 @@ struct bh_devinfo {
   int max_level;
   int flags;       // BH_FLAG_*
   int redo_waves;  // force waves that redid their walk with the generic loop (stack > 64 entries or a block of > 8 children)
-  int pad[3];
+  int slow_buckets;  // splitter-sort buckets that did not fit LDS (sorted by one workgroup through global memory)
+  int pad[2];
 };
 
 struct bh_ctx {
@@ -122,6 +123,8 @@ struct bh_ctx {
   bool keys_split;  // keys[0] and sp_count[sp_par] come from keys_split_kernel and no sort has consumed them
   bool order_hint;  // the bodies are stored in the key order of an earlier sort (set by every sort, cleared by
                     // uploads): what makes evenly spaced bodies good splitters
+  bool splitter_off;  // bh_get_stats saw LDS-overflowing buckets: radix passes until the next upload
+  int slow_seen;
 
   // bbox
   float* bbox_partial;  // [BH_BBOX_BLOCKS][6]

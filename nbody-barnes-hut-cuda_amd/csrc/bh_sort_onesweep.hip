@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
     u64* kout, u32* vout,    // sorted keys / permutation
     const u32* __restrict__ bcount, u32* __restrict__ bcount_next,
     const float4* __restrict__ posm_in, const float4* __restrict__ velid_in, float4* __restrict__ posm_out,
-    float4* __restrict__ velid_out, u32* __restrict__ sw_ticket, int gather) {
+    float4* __restrict__ velid_out, u32* __restrict__ sw_ticket, int gather, bh_devinfo* __restrict__ info) {
   __shared__ u64 skey[kLsCap];
   __shared__ u32 sval[kLsCap];
   __shared__ u32 wcnt[kLsWaves][256];
@@ -695,6 +695,8 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
   // ---- a bucket that does not fit LDS: stable LSD radix over all 8 digits by this one workgroup, ping-pong
   // between the bucket's own ranges of (kbuf, vbuf) and (kout, vout); 4096-key chunks in order, running
   // per-digit cursors in LDS.  Slow (one CU), only for buckets the splitters failed to balance.
+  if (tid == 0) atomicAdd(&info->slow_buckets, 1);  // surfaces in bh_stats.sort_slow_buckets (bh_get_stats then
+                                                     // sends this context's next sorts to the radix passes)
   u64* sk = kbuf + start;
   u32* sv = vbuf + start;
   u64* dk = kout + start;
@@ -792,6 +794,9 @@ bool bhk_sort_split_eligible(const bh_ctx* c) {
   if (v != 0 && v != 3) return false;
   if (c->p.step_graph == 1) return false;  // the call parity of the bucket counters is not a graph constant
   if (c->n > 256 * 6144) return false;     // (domain-decomposed contexts: n is the current local body count)
+  // buckets that overflowed LDS were seen (bh_get_stats): many equal keys or an order that drifted too far — the
+  // one-workgroup global-memory path is orders of magnitude slower than eight radix passes
+  if (v != 3 && c->splitter_off) return false;
   return v == 3 || c->order_hint;
 }
 
@@ -825,7 +830,7 @@ hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather) {
       c->info, c->sp_keys, (float)split_buckets(n) / (float)n);
   local_sort_kernel<<<split_buckets(n), kLsThreads, 0, c->stream>>>(
       c->keys[1], c->vals[1], c->keys[0], c->vals[0], bc, c->sp_count + 256 * (par ^ 1), c->posm[c->cur],
-      c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket, defer_gather ? 0 : 1);
+      c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket, defer_gather ? 0 : 1, c->info);
   c->gather_pending = defer_gather;
   c->key_buf = 0;
   c->cur ^= 1;

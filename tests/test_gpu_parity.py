@@ -114,6 +114,32 @@ def test_splitter_sort_bucket_paths(pkg, orc, n, shuffle):
     e.close()
 
 
+def test_splitter_sort_gives_way_when_buckets_overflow(pkg, orc):
+    """many identical keys (120,000 coincident bodies among 200,000) land in ONE bucket of the splitter sort, far
+    beyond the 8,192 keys its workgroup sorts in LDS: that bucket goes through the slow global-memory path (still
+    the exact stable order), bh_stats.sort_slow_buckets reports it, and once bh_get_stats has seen it the context
+    sorts with the radix passes until the next upload — results identical either way"""
+    n = 200000
+    x, y, z, vx, vy, vz, m = [a.copy() for a in pkg.plummer(n, seed=23)]
+    x[:120000] = 1.5; y[:120000] = -2.5; z[:120000] = 3.25
+    vx[:120000] = vy[:120000] = vz[:120000] = 0.0
+    ic = (x, y, z, vx, vy, vz, m)
+    e = _engine(pkg, ic)
+    e.step(2)                       # radix (first sort), then the splitter sort meets the overfull bucket
+    st = e.stats()
+    assert st.status_flags == 0 and st.sort_slow_buckets >= 1
+    slow = st.sort_slow_buckets
+    e.step(3)                       # bh_get_stats saw the counter: radix passes from now on
+    st = e.stats()
+    assert st.status_flags == 0 and st.sort_slow_buckets == slow
+    a = _state(e)
+    e.close()
+    r = _engine(pkg, ic, sort_variant=2)   # pinned to the radix sort
+    r.step(5)
+    assert _state(r) == a
+    r.close()
+
+
 def test_splitter_sort_in_steps(pkg, orc):
     """automatic choice: the first sort after an upload is the radix sort, later steps use the splitter sort;
     the body order after 6 steps equals that of a context pinned to the radix sort, bit for bit"""
@@ -584,6 +610,38 @@ def test_stage_order_errors(pkg):
         pkg.Engine(10, eps2=0.0)
     with pytest.raises(pkg.BhError):
         pkg.Engine(10, key_bits=48)
+
+
+def test_canonical_tree_records_exist_when_asked_for(pkg, orc):
+    """bh_step of the default engine writes only the force kernel's digests (the COM stage skips the canonical
+    x/y/z/m and body-range arrays: 24 B less traffic per record); bh_download_tree then refuses (BH_ERR_ORDER) until
+    the stage calls have built a canonical tree.  A strict_fp step keeps them (its kernel reads them), and the
+    canonical tree after stage calls that follow steps equals the oracle's."""
+    n = 3000
+    ic = pkg.plummer(n, seed=17)
+    e = _engine(pkg, ic)
+    e.step(2)
+    with pytest.raises(pkg.BhError):
+        e.download_tree()
+    e.bbox(); e.morton(); e.sort(); e.build()
+    with pytest.raises(pkg.BhError):
+        e.download_tree()          # centres of mass not set yet
+    e.com()
+    rec = e.download_tree()
+    bodies = e.download_sorted_bodies()
+    p = oparams(orc, e.params)
+    state = [np.ascontiguousarray(a) for a in e.download()]
+    o = oracle_pipeline(orc, tuple(state) + (e.download_mass(),), p)
+    for f in ("kind", "first", "count"):
+        assert np.array_equal(rec[f], o["rec"][f]), f
+    assert np.array_equal(bodies[:, 0], o["xyzm"][:, 0])
+    assert e.stats().status_flags == 0
+    e.close()
+    s = _engine(pkg, ic, strict_fp=1)
+    s.step(2)
+    rec2 = s.download_tree()       # a strict step reads the canonical records, so it writes them
+    assert (rec2["kind"] == 1).sum() > 0 and np.isfinite(rec2["x"]).all()
+    s.close()
 
 
 @pytest.mark.parametrize("variant", [0])
