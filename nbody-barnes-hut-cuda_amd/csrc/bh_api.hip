@@ -184,7 +184,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->bbox_partial, (size_t)BH_BBOX_BLOCKS * 6) == hipSuccess;
   ok = ok && dalloc(&c->bounds, 8) == hipSuccess;
   ok = ok && dalloc(&c->bounds_next, 8) == hipSuccess;
-  ok = ok && dalloc(&c->ibox_rows, (N / BH_INTEGRATE_TILE + 1) * 6) == hipSuccess;
+  ok = ok && dalloc(&c->ibox_rows, (N / 1024 + 2) * 6) == hipSuccess;  // one row per integrate block (>= 1024 bodies)
   ok = ok && dalloc(&c->d8, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->ksamp, (size_t)2048 + 8) == hipSuccess;
   ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;

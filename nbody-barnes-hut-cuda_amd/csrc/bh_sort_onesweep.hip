@@ -444,7 +444,9 @@ constexpr int kLsCap = 8192;  // keys per bucket sorted in LDS
 constexpr int kLsItems = kLsCap / kLsThreads;
 
 constexpr int kKsThreads = 1024;  // x 4 keys: 4 waves per SIMD hide the LDS round trips of the bucket lookups
-template <int B>
+// TILE = keys per block: kTile (4 per thread), or 1024 (1 per thread) for small n, where kTile-sized blocks leave
+// most of the 256 CUs idle (65,536 bodies: 16 blocks)
+template <int B, int TILE>
 __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __restrict__ posm,
                                                                const float* __restrict__ bounds, int n, int nb,
                                                                int curve, float nb_over_n,
@@ -458,10 +460,10 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
   const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
   const int tid = threadIdx.x, lane = tid & 63;
   // the tile's own keys first (their loads overlap the splitter work)
-  const int base = blockIdx.x * kTile;
-  u64 k[kTile / kKsThreads];
+  const int base = blockIdx.x * TILE;
+  u64 k[TILE / kKsThreads];
 #pragma unroll
-  for (int r = 0; r < kTile / kKsThreads; r++) {
+  for (int r = 0; r < TILE / kKsThreads; r++) {
     const int i = base + r * kKsThreads + tid;
     k[r] = 0ull;
     if (i < n) {
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
   __syncthreads();
   if (blockIdx.x == 0 && tid < 256) splitters[tid] = sp[tid];
 #pragma unroll
-  for (int r = 0; r < kTile / kKsThreads; r++) {
+  for (int r = 0; r < TILE / kKsThreads; r++) {
     const int i = base + r * kKsThreads + tid;
     const bool valid = i < n;
     const u32 g = splitter_bucket_guess(sp, k[r], i, nb_over_n);
@@ -808,12 +810,23 @@ hipError_t bhk_keys_split(bh_ctx* c) {
     if (e != hipSuccess) return e;
   }
   const int nb = split_buckets(n);
-  if (c->B == 10)
-    keys_split_kernel<10><<<c->sort_tiles, kKsThreads, 0, c->stream>>>(
-        c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
-  else
-    keys_split_kernel<21><<<c->sort_tiles, kKsThreads, 0, c->stream>>>(
-        c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+  const bool small = n <= BH_PAIR_SMALL_N;  // one key per thread: four times the blocks (65,536 bodies: 64)
+  const int grid = small ? (n + 1023) / 1024 : c->sort_tiles;
+  if (c->B == 10) {
+    if (small)
+      keys_split_kernel<10, 1024><<<grid, kKsThreads, 0, c->stream>>>(
+          c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+    else
+      keys_split_kernel<10, kTile><<<grid, kKsThreads, 0, c->stream>>>(
+          c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+  } else {
+    if (small)
+      keys_split_kernel<21, 1024><<<grid, kKsThreads, 0, c->stream>>>(
+          c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+    else
+      keys_split_kernel<21, kTile><<<grid, kKsThreads, 0, c->stream>>>(
+          c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+  }
   c->keys_split = true;
   return hipGetLastError();
 }

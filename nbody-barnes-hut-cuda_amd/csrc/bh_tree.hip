@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const float* __restrict
 // bounding cube (ref:134-156) — into one row per block, and the block that finishes last folds the rows into
 // `bounds_next`: a step that follows a step needs no bbox kernels.  min/max are exact, so the cube is the
 // same bit for bit.
-template <bool BBOX>
+// TILE = bodies per block: BH_INTEGRATE_TILE (4 per thread), or 1024 for small n (65,536 bodies: 64 blocks, not 16)
+template <bool BBOX, int TILE = BH_INTEGRATE_TILE>
 __global__ __launch_bounds__(1024) void integrate_kernel(float4* __restrict__ posm,
                                                          float4* __restrict__ velid,
                                                          const float4* __restrict__ acc,
@@ -132,11 +133,11 @@ __global__ __launch_bounds__(1024) void integrate_kernel(float4* __restrict__ po
                                                          float* __restrict__ bounds_next, int raw) {
   float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
   float mx[3] = {-1e10f, -1e10f, -1e10f};
-  constexpr int kPer = BH_INTEGRATE_TILE / 1024;
+  constexpr int kPer = TILE / 1024;
   float4 p[kPer], v[kPer], a[kPer];
 #pragma unroll
   for (int r = 0; r < kPer; r++) {
-    const int i = blockIdx.x * BH_INTEGRATE_TILE + r * 1024 + (int)threadIdx.x;
+    const int i = blockIdx.x * TILE + r * 1024 + (int)threadIdx.x;
     if (i < n) {
       p[r] = posm[i];
       v[r] = velid[i];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(1024) void integrate_kernel(float4* __restrict__ po
   }
 #pragma unroll
   for (int r = 0; r < kPer; r++) {
-    const int i = blockIdx.x * BH_INTEGRATE_TILE + r * 1024 + (int)threadIdx.x;
+    const int i = blockIdx.x * TILE + r * 1024 + (int)threadIdx.x;
     if (i < n) {
       float vx = v[r].x + a[r].x * DT;
       float vy = v[r].y + a[r].y * DT;
@@ -1167,7 +1168,11 @@ hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int str
 hipError_t bhk_integrate(bh_ctx* c, bool with_bbox) {
   const int n = c->n;
   const int blocks = (n + BH_INTEGRATE_TILE - 1) / BH_INTEGRATE_TILE;
-  if (with_bbox)
+  if (with_bbox && n <= BH_PAIR_SMALL_N)
+    integrate_kernel<true, 1024><<<(n + 1023) / 1024, 1024, 0, c->stream>>>(
+        c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2, n, c->p.dt, c->p.max_speed, c->ibox_rows, c->blk_done2,
+        c->dd ? c->dd_minmax : c->bounds_next, c->dd ? 1 : 0);
+  else if (with_bbox)
     integrate_kernel<true><<<blocks, 1024, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2, n,
                                                            c->p.dt, c->p.max_speed, c->ibox_rows,
                                                            c->blk_done2,
