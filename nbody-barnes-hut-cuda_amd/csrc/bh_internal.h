@@ -215,6 +215,21 @@ struct bh_ctx {
 // those stores are acknowledged (bh_published: then they are visible device-wide), only then counts itself
 // done with a relaxed atomic; the block that sees the full count reads the results with agent-scope loads
 // (bh_collect_*), which bypass the non-coherent caches.
+// ISA ASSUMPTION (gfx942 / gfx950, the only targets this library is built for): an agent-scope relaxed atomic
+// store compiles to a global_store with sc1 (write-through to the memory-side level shared by all XCDs) and
+// increments vmcnt; `s_waitcnt vmcnt(0)` returns only when the write has been acknowledged there, i.e. when an
+// agent-scope load of any other CU (sc1 load: misses the XCD-private L2) returns the new value.  The HIP / LLVM
+// memory model does NOT promise a happens-before edge between these relaxed operations and the relaxed counter
+// increment that follows — the ordering is this ISA behaviour plus the `asm volatile(... "memory")` compiler
+// barrier.  Any other target gets the formally correct (slower) release / acquire pair below; tools/soak.py and
+// tests/test_gpu_soak.py are the regression check for the fast form.
+#if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
+#define BH_FENCE_FREE_HANDOFF 1  // host pass: the device pass below decides
+#elif defined(__gfx942__) || defined(__gfx950__)
+#define BH_FENCE_FREE_HANDOFF 1
+#else
+#define BH_FENCE_FREE_HANDOFF 0
+#endif
 #ifdef __HIPCC__
 __device__ __forceinline__ void bh_publish_i32(int* p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -222,7 +237,13 @@ __device__ __forceinline__ void bh_publish_i32(int* p, int v) {
 __device__ __forceinline__ void bh_publish_f32(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void bh_published() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void bh_published() {
+#if BH_FENCE_FREE_HANDOFF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+  __atomic_thread_fence(__ATOMIC_RELEASE);  // formally ordered before the counter increment that follows
+#endif
+}
 __device__ __forceinline__ int bh_collect_i32(const int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
