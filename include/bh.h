@@ -135,8 +135,8 @@ typedef struct bh_stats {
                                more than 8 bodies); a speed matter only                                   */
   int32_t sort_slow_buckets; /* splitter sort: buckets since upload that did not fit LDS and were sorted by one
                                 workgroup through global memory (many equal keys, or an order that drifted far);
-                                once bh_get_stats has seen one, the context sorts with the radix passes until the
-                                next upload                                                                */
+                                when bh_get_stats finds that more than every fourth sort since its last call had
+                                one, the context sorts with the radix passes until the next upload          */
   int32_t reserved[6];
 } bh_stats;
 

@@ -283,6 +283,7 @@ int bh_upload(bh_ctx* c, const float* x, const float* y, const float* z, const f
   c->order_hint = false;  // caller order: nothing for the splitter sort to exploit
   c->splitter_off = false;
   c->slow_seen = 0;       // (the counter itself is cleared with the device info block below)
+  c->slow_seen_sorts = c->sort_calls;
   c->bounds_next_ok = false;
   BH_HIP(c, bhk_pack(c));
   BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));  // clears the sticky flags
@@ -700,9 +701,16 @@ int bh_get_stats(bh_ctx* c, bh_stats* st) {
   }
   st->force_redo_waves = hi.redo_waves;
   st->sort_slow_buckets = hi.slow_buckets;
-  if (hi.slow_buckets > c->slow_seen) {  // the splitter sort met buckets beyond its LDS capacity: stop using it
+  // The splitter sort met buckets beyond its LDS capacity.  An isolated one is normal (two neighbouring splitter
+  // bodies that both crossed a high-level cell plane: about once in 60 steps of the 1M Plummer run, a 0.18 ms
+  // sort); when more than every fourth sort since the last look had one, the input defeats the splitters (many
+  // equal keys) and the context goes back to the radix passes until the next upload.
+  {
+    const int d_slow = hi.slow_buckets - c->slow_seen;
+    const long d_sorts = (long)c->sort_calls - (long)c->slow_seen_sorts;
+    if (d_slow > 0 && d_sorts > 0 && 4L * d_slow > d_sorts) c->splitter_off = true;
     c->slow_seen = hi.slow_buckets;
-    c->splitter_off = true;
+    c->slow_seen_sorts = c->sort_calls;
   }
   st->count_V = c->tV;
   st->count_O = c->tO;

@@ -1279,6 +1279,7 @@ int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const flo
   BH_HIP(c, hipGetLastError());
   c->splitter_off = false;
   c->slow_seen = 0;
+  c->slow_seen_sorts = c->sort_calls;
   BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));
   BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));
   BH_HIP(c, hipStreamSynchronize(c->stream));

@@ -125,6 +125,7 @@ struct bh_ctx {
                     // uploads): what makes evenly spaced bodies good splitters
   bool splitter_off;  // bh_get_stats saw LDS-overflowing buckets: radix passes until the next upload
   int slow_seen;
+  u32 slow_seen_sorts;  // sort_calls at the last look
 
   // bbox
   float* bbox_partial;  // [BH_BBOX_BLOCKS][6]
@@ -199,6 +200,12 @@ struct bh_ctx {
 #define BH_INTEGRATE_TILE 4096  // bodies per integrate block (1024 threads x 4)
 #define BH_PAIR_SMALL_N 163840  // bodies up to which the tree build uses 256-pair tiles (A/B per step: 16,384 -15 us,
                                 // 65,536 -14 us, 125,000 -8 us, 262,144 +5 us)
+#ifndef BH_KS_SMALL_N
+#define BH_KS_SMALL_N 163840   // bodies up to which keys_split_kernel takes one key per thread (1024-key blocks)
+#endif
+#ifndef BH_INT_SMALL_N
+#define BH_INT_SMALL_N 163840  // bodies up to which integrate_kernel<true> uses 1024-body blocks
+#endif
 #ifndef BH_FORK_MIN_N
 #define BH_FORK_MIN_N 163840  // bodies from which bh_step runs body gather + COM prefix scan on the second stream
 #endif

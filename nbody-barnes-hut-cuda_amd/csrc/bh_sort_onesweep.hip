@@ -440,7 +440,10 @@ __global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ pe
 // memory: slow, correct.  Not used for the first sort after an upload (no order to exploit).
 constexpr int kLsThreads = 512;
 constexpr int kLsWaves = kLsThreads / 64;
-constexpr int kLsCap = 8192;  // keys per bucket sorted in LDS
+#ifndef BH_LS_CAP
+#define BH_LS_CAP 12288  // 144 KB of the 160 KB LDS for keys + values
+#endif
+constexpr int kLsCap = BH_LS_CAP;  // keys per bucket sorted in LDS
 constexpr int kLsItems = kLsCap / kLsThreads;
 
 constexpr int kKsThreads = 1024;  // x 4 keys: 4 waves per SIMD hide the LDS round trips of the bucket lookups
@@ -537,6 +540,134 @@ __device__ __forceinline__ u32 scan256(u32 v, u32* dsum, u32* total) {
   return wp + incl - v;
 }
 
+// One bucket of <= ITEMS * kLsThreads keys sorted in LDS (keys in registers between the passes).  ITEMS = 8 covers a
+// bucket of up to 4096 keys — the normal case: n / 256 is at most 6144 / 1.5 — with loops of 8; 16 and 24 take
+// the buckets that came out up to 3x the average (neighbouring splitter bodies that both crossed a high-level
+// cell plane; in the domain-decomposed step the immigrants, which cluster at the two ends of the rank's key range).
+template <int ITEMS>
+__device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __restrict__ sval, u32 (*wcnt)[256],
+                                               u32* __restrict__ toff, u32* __restrict__ dsum,
+                                               u64* __restrict__ s_diff, const u64* kbuf, const u32* vbuf,
+                                               u64* kout, u32* vout, const float4* __restrict__ posm_in,
+                                               const float4* __restrict__ velid_in, float4* __restrict__ posm_out,
+                                               float4* __restrict__ velid_out, int gather, int start, int size,
+                                               int tid, int lane, int w, int b, u64 lt) {
+    // ---- the bucket in registers, blocked by wave: wave w owns positions [w chunk, (w+1) chunk)
+    const int chunk = ((size + kLsThreads - 1) / kLsThreads) * 64;
+    const int nit = chunk / 64;
+    const int wbase = w * chunk;
+    u64 key[ITEMS];
+    u32 val[ITEMS];
+    u64 diff = 0ull;
+    const u64 k0 = kbuf[start];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      key[r] = ~0ull;
+      val[r] = 0u;
+      if (r < nit) {
+        const int idx = wbase + r * 64 + lane;
+        if (idx < size) {
+          key[r] = kbuf[start + idx];
+          val[r] = vbuf[start + idx];
+          diff |= key[r] ^ k0;
+        }
+      }
+    }
+    // digit positions that vary inside the bucket (the keys of a bucket share their leading bits)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) diff |= __shfl_xor(diff, d, 64);
+    if (lane == 0) s_diff[w] = diff;
+    __syncthreads();
+    diff = 0ull;
+#pragma unroll
+    for (int q = 0; q < kLsWaves; q++) diff |= s_diff[q];
+    LS_STAMP(1, wall_clock64())
+    LS_STAMP(5, diff)
+
+#pragma unroll 1
+    for (int p = 0; p < 8; p++) {
+      const int shift = 8 * p;
+      if (((diff >> shift) & 255ull) == 0ull) continue;  // block-uniform
+#ifdef BH_OS_TRACE
+      const bool tr = (p == 1);
+#define LS_PSTAMP(k) if (tr) { LS_STAMP(k, wall_clock64()) }
+#else
+#define LS_PSTAMP(k)
+#endif
+      LS_PSTAMP(8)
+      for (int q = tid; q < kLsWaves * 256; q += kLsThreads) (&wcnt[0][0])[q] = 0;
+      __syncthreads();
+      LS_PSTAMP(9)
+      u32 rk[ITEMS];
+#pragma unroll
+      for (int r = 0; r < ITEMS; r++) {
+        rk[r] = 0;
+        if (r < nit) {
+          const int idx = wbase + r * 64 + lane;
+          rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, idx < size, wcnt[w], (u32)lt, (u32)(lt >> 32));
+        }
+      }
+      __syncthreads();
+      LS_PSTAMP(10)
+      u32 h = 0;
+      if (tid < 256) {
+#pragma unroll
+        for (int q = 0; q < kLsWaves; q++) {
+          const u32 cq = wcnt[q][tid];
+          wcnt[q][tid] = h;
+          h += cq;
+        }
+      }
+      const u32 lo = scan256(h, dsum, nullptr);
+      if (tid < 256) toff[tid] = lo;
+      __syncthreads();
+      LS_PSTAMP(11)
+#pragma unroll
+      for (int r = 0; r < ITEMS; r++) {
+        if (r < nit) {
+          const int idx = wbase + r * 64 + lane;
+          if (idx < size) {
+            const u32 g = (u32)(key[r] >> shift) & 255u;
+            const u32 lp = toff[g] + wcnt[w][g] + rk[r];
+            skey[lp] = key[r];
+            sval[lp] = val[r];
+          }
+        }
+      }
+      __syncthreads();
+      LS_PSTAMP(12)
+#pragma unroll
+      for (int r = 0; r < ITEMS; r++) {
+        if (r < nit) {
+          const int idx = wbase + r * 64 + lane;
+          if (idx < size) {
+            key[r] = skey[idx];
+            val[r] = sval[idx];
+          }
+        }
+      }
+      LS_PSTAMP(13)
+      // (the barrier at the top of the next pass, or none needed after the last, orders these reads)
+    }
+    LS_STAMP(2, wall_clock64())
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      if (r < nit) {
+        const int idx = wbase + r * 64 + lane;
+        if (idx < size) {
+          const u32 v = val[r];
+          kout[start + idx] = key[r];
+          vout[start + idx] = v;
+          if (gather) {  // else: bhk_gather_bodies, beside the tree build (bh_step)
+            posm_out[start + idx] = posm_in[v];
+            velid_out[start + idx] = velid_in[v];
+          }
+        }
+      }
+    }
+    LS_STAMP(3, wall_clock64())
+}
+
 __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
     u64* kbuf, u32* vbuf,    // the partitioned keys / values (scratch of the slow path)
     u64* kout, u32* vout,    // sorted keys / permutation
@@ -576,121 +707,16 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
   LS_STAMP(4, (unsigned long long)size)
   if (size == 0) return;
 
-  if (size <= kLsCap) {
-    // ---- the bucket in registers, blocked by wave: wave w owns positions [w chunk, (w+1) chunk)
-    const int chunk = ((size + kLsThreads - 1) / kLsThreads) * 64;
-    const int nit = chunk / 64;
-    const int wbase = w * chunk;
-    u64 key[kLsItems];
-    u32 val[kLsItems];
-    u64 diff = 0ull;
-    const u64 k0 = kbuf[start];
-#pragma unroll
-    for (int r = 0; r < kLsItems; r++) {
-      key[r] = ~0ull;
-      val[r] = 0u;
-      if (r < nit) {
-        const int idx = wbase + r * 64 + lane;
-        if (idx < size) {
-          key[r] = kbuf[start + idx];
-          val[r] = vbuf[start + idx];
-          diff |= key[r] ^ k0;
-        }
-      }
-    }
-    // digit positions that vary inside the bucket (the keys of a bucket share their leading bits)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) diff |= __shfl_xor(diff, d, 64);
-    if (lane == 0) s_diff[w] = diff;
-    __syncthreads();
-    diff = 0ull;
-#pragma unroll
-    for (int q = 0; q < kLsWaves; q++) diff |= s_diff[q];
-    LS_STAMP(1, wall_clock64())
-    LS_STAMP(5, diff)
-
-#pragma unroll 1
-    for (int p = 0; p < 8; p++) {
-      const int shift = 8 * p;
-      if (((diff >> shift) & 255ull) == 0ull) continue;  // block-uniform
-#ifdef BH_OS_TRACE
-      const bool tr = (p == 1);
-#define LS_PSTAMP(k) if (tr) { LS_STAMP(k, wall_clock64()) }
-#else
-#define LS_PSTAMP(k)
-#endif
-      LS_PSTAMP(8)
-      for (int q = tid; q < kLsWaves * 256; q += kLsThreads) (&wcnt[0][0])[q] = 0;
-      __syncthreads();
-      LS_PSTAMP(9)
-      u32 rk[kLsItems];
-#pragma unroll
-      for (int r = 0; r < kLsItems; r++) {
-        rk[r] = 0;
-        if (r < nit) {
-          const int idx = wbase + r * 64 + lane;
-          rk[r] = wave_rank((u32)(key[r] >> shift) & 255u, idx < size, wcnt[w], (u32)lt, (u32)(lt >> 32));
-        }
-      }
-      __syncthreads();
-      LS_PSTAMP(10)
-      u32 h = 0;
-      if (tid < 256) {
-#pragma unroll
-        for (int q = 0; q < kLsWaves; q++) {
-          const u32 cq = wcnt[q][tid];
-          wcnt[q][tid] = h;
-          h += cq;
-        }
-      }
-      const u32 lo = scan256(h, dsum, nullptr);
-      if (tid < 256) toff[tid] = lo;
-      __syncthreads();
-      LS_PSTAMP(11)
-#pragma unroll
-      for (int r = 0; r < kLsItems; r++) {
-        if (r < nit) {
-          const int idx = wbase + r * 64 + lane;
-          if (idx < size) {
-            const u32 g = (u32)(key[r] >> shift) & 255u;
-            const u32 lp = toff[g] + wcnt[w][g] + rk[r];
-            skey[lp] = key[r];
-            sval[lp] = val[r];
-          }
-        }
-      }
-      __syncthreads();
-      LS_PSTAMP(12)
-#pragma unroll
-      for (int r = 0; r < kLsItems; r++) {
-        if (r < nit) {
-          const int idx = wbase + r * 64 + lane;
-          if (idx < size) {
-            key[r] = skey[idx];
-            val[r] = sval[idx];
-          }
-        }
-      }
-      LS_PSTAMP(13)
-      // (the barrier at the top of the next pass, or none needed after the last, orders these reads)
-    }
-    LS_STAMP(2, wall_clock64())
-#pragma unroll
-    for (int r = 0; r < kLsItems; r++) {
-      if (r < nit) {
-        const int idx = wbase + r * 64 + lane;
-        if (idx < size) {
-          const u32 v = val[r];
-          kout[start + idx] = key[r];
-          vout[start + idx] = v;
-          if (gather) {  // else: bhk_gather_bodies, beside the tree build (bh_step)
-            posm_out[start + idx] = posm_in[v];
-            velid_out[start + idx] = velid_in[v];
-          }
-        }
-      }
-    }
-    LS_STAMP(3, wall_clock64())
+  if (size <= kLsCap) {  // block-uniform
+    if (size <= 8 * kLsThreads)
+      ls_sort_in_lds<8>(skey, sval, wcnt, toff, dsum, s_diff, kbuf, vbuf, kout, vout, posm_in, velid_in, posm_out,
+                        velid_out, gather, start, size, tid, lane, w, b, lt);
+    else if (size <= 16 * kLsThreads)
+      ls_sort_in_lds<16>(skey, sval, wcnt, toff, dsum, s_diff, kbuf, vbuf, kout, vout, posm_in, velid_in, posm_out,
+                         velid_out, gather, start, size, tid, lane, w, b, lt);
+    else
+      ls_sort_in_lds<kLsItems>(skey, sval, wcnt, toff, dsum, s_diff, kbuf, vbuf, kout, vout, posm_in, velid_in,
+                               posm_out, velid_out, gather, start, size, tid, lane, w, b, lt);
     return;
   }
 
@@ -810,7 +836,7 @@ hipError_t bhk_keys_split(bh_ctx* c) {
     if (e != hipSuccess) return e;
   }
   const int nb = split_buckets(n);
-  const bool small = n <= BH_PAIR_SMALL_N;  // one key per thread: four times the blocks (65,536 bodies: 64)
+  const bool small = n <= BH_KS_SMALL_N;  // one key per thread: four times the blocks (65,536 bodies: 64)
   const int grid = small ? (n + 1023) / 1024 : c->sort_tiles;
   if (c->B == 10) {
     if (small)

@@ -1168,7 +1168,7 @@ hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int str
 hipError_t bhk_integrate(bh_ctx* c, bool with_bbox) {
   const int n = c->n;
   const int blocks = (n + BH_INTEGRATE_TILE - 1) / BH_INTEGRATE_TILE;
-  if (with_bbox && n <= BH_PAIR_SMALL_N)
+  if (with_bbox && n <= BH_INT_SMALL_N)
     integrate_kernel<true, 1024><<<(n + 1023) / 1024, 1024, 0, c->stream>>>(
         c->posm[c->cur], c->velid[c->cur], c->acc, c->acc2, n, c->p.dt, c->p.max_speed, c->ibox_rows, c->blk_done2,
         c->dd ? c->dd_minmax : c->bounds_next, c->dd ? 1 : 0);

@@ -40,6 +40,7 @@ def main():
     group = bhdist.LocalGroup(P)
     stream = torch.cuda.Stream(0)
     steppers = [None] * P
+    slow = [0] * P
     errs = []
 
     def log(*a):
@@ -55,14 +56,16 @@ def main():
             for s in range(args.steps):
                 t0 = time.time()
                 st.step(1)
-                flags = st.e.stats().status_flags
+                sst = st.e.stats()
+                flags = sst.status_flags
+                slow[r] = sst.sort_slow_buckets
                 group.barrier.wait()
                 if r == 0 and not args.quiet:
                     hdr = st.x3r.cpu().numpy().view(np.int32).reshape(P, -1)[:, 0]
                     log(f"   pieces per rank {hdr.tolist()}")
                     log(f"step {s}: n_loc={[x.n_loc for x in steppers]} stride={st.stride} "
                         f"let={st.let_counts.tolist()} retries={st.let_retries} emig={st.mig_last} "
-                        f"mig_rounds={st.mig_rounds} flags={flags} "
+                        f"mig_rounds={st.mig_rounds} flags={flags} slow_buckets={slow} "
                         f"{(time.time() - t0) * 1e3:.1f} ms")
                 group.barrier.wait()
         except BaseException as ex:  # noqa: BLE001

@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; O=gpurun_out; mkdir -p $O
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 tail -c 600 $O/bench_final.json; echo
 tools/profile.sh > $O/profile_sh.log 2>&1
-for cfg in "65536 0.5" "125000 0.5" "500000 0.5" "1000000 0.3" "8000000 0.5"; do
+for cfg in "16384 0.5" "65536 0.5" "125000 0.5" "500000 0.5" "1000000 0.3" "8000000 0.5"; do
   set -- $cfg
   python bench.py --bodies $1 --theta $2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null > $O/cfg_$1_$2.json
   python -c "
