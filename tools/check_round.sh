@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: GPU suite + the bench configurations in one call.  tools/r3_check.sh <tag>
+# round 3: GPU suite + the bench configurations in one call.  tools/check_round.sh <tag>
 cd $GRAFT_REPO_ROOT
 T=${1:-chk}; O=gpurun_out; mkdir -p $O
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $O/pytest_$T.log 2>&1
