@@ -429,7 +429,7 @@ def main():
                 "n_total": n_total,
                 "parallelism": "1 GPU" if not multi else (
                     f"{world} ranks, domain decomposition: per-rank octree of one Morton-key range, top tree + "
-                    "locally-essential records by 4 all-gathers per step (RCCL)" if dist_mode == "domain" else
+                    "locally-essential records: 3 all-gathers + 1 all-to-all per step (RCCL)" if dist_mode == "domain" else
                     f"{world} ranks: replicated tree, Morton-slab sharded traversal, acc all-gather (RCCL)"),
                 "tree": {"cells": st.n_internal, "records": st.n_entries, "max_level": st.max_level},
             },
@@ -443,6 +443,8 @@ def main():
             out["config"]["domain"] = {
                 "bodies_rank0": int(stepper.n_loc), "let_records_per_rank": [int(v) for v in stepper.let_counts],
                 "let_stride": int(stepper.stride), "emigrants_last_step_max": int(stepper.mig_last),
+                "x4": "per-destination segments, all-to-all" if stepper.let_mode == 1 else "union segment, all-gather",
+                "x4_bytes_received_per_gpu_per_step": int(world * stepper.stride * 32),
                 "let_retries": int(stepper.let_retries), "extra_migration_rounds": int(stepper.mig_rounds),
                 "phase_ms_rank0": stepper.phase_ms()}
         assert st.status_flags == 0, st.status_flags

@@ -287,6 +287,13 @@ int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_lo
 int bh_dd_tree(bh_ctx* c, void* send_x3);
 /* stride = records per LET segment in this step's X4 (let_min <= stride <= let_cap) */
 int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride);
+/* X4 flavour (default 0).  0: send_x4 is ONE segment of `stride` records — the union of what any other rank may
+   open — and the caller ALL-GATHERS it into the pool's segment area.  1: send_x4 is `world` segments of `stride`
+   records, segment q holding only what rank q may open (own slot: a closed header), and the caller exchanges them
+   with an ALL-TO-ALL (rank q receives this rank's segment q at segment index `rank` of its pool): about a third of
+   the received bytes at 8 ranks.  Every segment carries its sender's needs for all receivers (records 1..3), so all
+   ranks still take the same stride decision in bh_dd_let_check. */
+int bh_dd_set_let_mode(bh_ctx* c, int mode);
 /* optional, right after the X3 all-gather: walk the rank's OWN pieces on a side stream while the LET
    marking, export and the X4 all-gather run on the main stream.  bh_dd_top / bh_dd_force then cover
    only the other ranks' pieces and bh_integrate adds the two partial accelerations.  The split is

@@ -118,6 +118,7 @@ SYMBOLS = [
     ("bh_dd_top", C.c_int, [_P, _P, C.c_int]),
     ("bh_dd_force", C.c_int, [_P]),
     ("bh_dd_let_check", C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),
+    ("bh_dd_set_let_mode", C.c_int, [_P, C.c_int]),
     ("bh_dd_phase_migrate", C.c_int, [_P, _P, _P, C.c_int]),
     ("bh_dd_phase_tree", C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("bh_dd_phase_let", C.c_int, [_P, _P, _P, C.c_int, C.c_int]),

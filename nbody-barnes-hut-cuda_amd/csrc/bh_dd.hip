@@ -96,6 +96,16 @@ struct bh_dd_state {
   int* host;       // pinned: [world] LET counts, [64 .. 67] migration results, [68] their sequence number
   hipEvent_t ev_let;
   bool let_copy_pending;
+  int* host_rows;  // pinned: [world][32] header + needs row (records 0..3) of every received X4 segment
+  int let_mode;    // 0: X4 is an all-gather of the union every other rank may open; 1: per-destination segments
+                   // (all-to-all)
+  unsigned* wmask; // [rec_cap + 1] per-destination mode: ranks (bit q) that may open cell e
+  int* list_e;     // [n_cap] exporting cells in record order
+  int* list_w;     // [n_cap] their block sizes (child count rounded up to even)
+  unsigned* list_m;  // [n_cap] their rank masks
+  int* dstd;       // [world][n_cap] per destination: block offset of every exporting cell inside that segment
+  int* dtot;       // [64] per destination: records of its blocks
+  int* csum;       // [world][n_cap / 8192 + 1] chunk sums of the per-destination scan
   u32* cls_done;   // bh_last_block counters of dd_classify_kernel
   u32* abs_done;   // ... of dd_absorb_flag_kernel
   int* arrive;     // [64] immigrants per rank of the current round (left at zero by the kernel)
@@ -107,10 +117,18 @@ namespace {
 constexpr int kB = 21;
 constexpr int kTopMax = 4096;  // pieces in the whole system
 constexpr int kDescPerRank = 1 + BH_DD_PIECE_CAP;
-// X4 segment: record 0 header, records 1 .. PIECE_CAP the pieces' own records, one padding record, then the
-// exported child blocks from an EVEN record on (digest pairs: bh_internal.h)
-constexpr int kSegBlocks0 = 2 + BH_DD_PIECE_CAP;
+// X4 segment: record 0 header (first = records the sender needed for THIS receiver, meta = its pieces), records
+// 1 .. 3 the sender's NEEDS ROW (24 ints: records it needed for receiver j — every rank thus sees the whole
+// world x world matrix and takes the same decision on the next stride), records kSegPieces0 .. + PIECE_CAP the
+// pieces' own records, then the exported child blocks from an EVEN record on (digest pairs: bh_internal.h)
+constexpr int kSegPieces0 = 4;
+constexpr int kSegBlocks0 = kSegPieces0 + BH_DD_PIECE_CAP;
 static_assert(kSegBlocks0 % 2 == 0, "child blocks start at even records");
+// dword of needs-row entry j inside a segment (pair layout: record r, field f -> (r >> 1) * 16 + 2 f + (r & 1))
+__host__ __device__ inline int seg_row_dword(int j) {
+  const int r = 1 + j / 8, f = j % 8;
+  return (r >> 1) * 16 + 2 * f + (r & 1);
+}
 constexpr int kTopCap = 4 * 4096 + 8;  // records of one top tree incl. padding (kTopMax pieces)
 
 constexpr int kSampTotal = 2048;  // position samples in the whole system (bitonic sort in LDS by one block, on the
@@ -636,7 +654,7 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
                                                       const float4* __restrict__ boxes,
                                                       const float4* __restrict__ rbox, int world,
                                                       const int* __restrict__ ddi, float eps2,
-                                                      int* __restrict__ w) {
+                                                      int* __restrict__ w, unsigned* __restrict__ wmask) {
   __shared__ float4 sb[kMarkBoxes];
   __shared__ float4 srb[128];
   __shared__ float4 cxyz[kMarkChunk];  // candidate: com, threshold
@@ -666,6 +684,7 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
       ccnt[k] = r.meta & 0x7fffffff;
     } else {
       w[e] = 0;
+      if (wmask) wmask[e] = 0u;
     }
   }
   __syncthreads();
@@ -673,7 +692,8 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
   for (int c = threadIdx.x; c < nc; c += 256) {
     const float4 q = cxyz[c];
     bool open = false;
-    for (int r = 0; r < world && !open; r++) {
+    unsigned mask = 0u;  // per-destination mode: every rank is tested, not only up to the first that opens
+    for (int r = 0; r < world && (wmask || !open); r++) {
       const float4 lo = srb[2 * r], hi = srb[2 * r + 1];
       const int b0 = __float_as_int(lo.w), b1 = __float_as_int(hi.w);
       if (b1 <= b0) continue;
@@ -690,11 +710,13 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
         const float dz = fmaxf(fmaxf(b.z - q.z, q.z - (b.z + b.w)), 0.0f);
         if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 <= q.w) {
           open = true;
+          mask |= 1u << r;
           break;
         }
       }
     }
     w[cidx[c]] = open ? ccnt[c] : 0;
+    if (wmask) wmask[cidx[c]] = mask;
   }
 }
 
@@ -724,7 +746,7 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
                                                         const int* __restrict__ w, const int* __restrict__ dst,
                                                         const int* __restrict__ piece_idx,
                                                         const int* __restrict__ ddi, int seg0, int stride,
-                                                        bh_frec* __restrict__ send) {
+                                                        int world, bh_frec* __restrict__ send) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int blocks0 = seg0 + kSegBlocks0;
   const int np = ddi[8];
@@ -734,7 +756,8 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
     h.first = kSegBlocks0 + dst[rec_cap];  // records this rank needs (may exceed stride)
     h.meta = np;
     frec_put(send, 0, h);
-    frec_put(send, 1 + BH_DD_PIECE_CAP, frec_null());
+    for (int j = 0; j < 24; j++)             // the union goes to every receiver: one need for all of them
+      reinterpret_cast<int*>(send)[seg_row_dword(j)] = j < world ? h.first : 0;
   }
   // a segment that does not fit is sent closed: its pieces are made unopenable, so the (discarded)
   // force pass that runs before the host sees the header never walks unwritten records
@@ -743,7 +766,7 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
     bh_frec fr = frec_null();
     if (e < np) fr = reloc(frec_get(frec, piece_idx[e]), piece_idx[e], w, dst, blocks0, rec_cap);
     if (!fits) fr.thr2 = -1.0f;
-    frec_put(send, 1 + e, fr);
+    frec_put(send, kSegPieces0 + e, fr);
   }
   if (e >= rec_cap || !fits) return;
   const int wv = w[e];
@@ -757,6 +780,227 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
   if ((wv & 1) && off + wv < stride) frec_put(send, off + wv, frec_null());
 }
 
+// ------------------------------------------------------------------ X4, per-destination segments (let_mode 1)
+// The union above goes to every rank although a receiver only opens what ITS boxes can reach (about a third of
+// it at 8 ranks).  Per destination: dd_mark_kernel records WHICH ranks may open a cell (wmask); the exporting cells
+// are compacted into a list (lpos = exclusive scan of w > 0); one block per destination scans the list entries
+// that carry its bit (dstd[q][i] = offset of cell i's child block inside the segment for q); the export kernel
+// writes every exporting cell's block once per interested destination, child pointers relocated with THAT
+// destination's offsets — a child cell this destination cannot open is closed in its copy.  The `world` segments
+// (stride records each) are exchanged with an all-to-all; a receiver finds the sender's segment where the
+// all-gather put it, so the top tree, the validation and the walk are unchanged.
+__global__ __launch_bounds__(256) void dd_let_list_kernel(const int* __restrict__ w,
+                                                          const unsigned* __restrict__ wmask,
+                                                          const int* __restrict__ lpos, int rec_cap, int lcap,
+                                                          int* __restrict__ list_e, int* __restrict__ list_w,
+                                                          unsigned* __restrict__ list_m) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rec_cap || w[e] <= 0) return;
+  const int i = lpos[e];
+  if (i >= lcap) return;
+  list_e[i] = e;
+  list_w[i] = (w[e] + 1) & ~1;  // blocks start at even records
+  list_m[i] = wmask[e];
+}
+
+// dstd[q][i] = exclusive prefix, over the list, of the (even) block sizes of the entries that carry bit q.
+// Two launches over (chunk of 8192 entries, destination): chunk sums, then every block adds up the sums of the
+// chunks before it (a few dozen) and scans its own chunk.  (One block per destination looping over the list took
+// 67-87 us per rank-step at 8 x 1M: each round is a dependent load -> scan -> store chain.)
+constexpr int kLetChunk = 8192;
+__global__ __launch_bounds__(1024) void dd_let_sums_kernel(const int* __restrict__ list_w,
+                                                           const unsigned* __restrict__ list_m,
+                                                           const int* __restrict__ lpos, int rec_cap, int lcap,
+                                                           int nch, int* __restrict__ csum) {
+  __shared__ int wsum[16];
+  const int j = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+  const int L = min(lpos[rec_cap], lcap);
+  const int i0 = j * kLetChunk;
+  if (i0 >= L) {
+    if (tid == 0) csum[q * nch + j] = 0;
+    return;
+  }
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kLetChunk / 1024; k++) {
+    const int i = i0 + k * 1024 + tid;
+    if (i < L && ((list_m[i] >> q) & 1u)) s += list_w[i];
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int k = 0; k < 16; k++) t += wsum[k];
+    csum[q * nch + j] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void dd_let_scan_kernel(const int* __restrict__ list_w,
+                                                           const unsigned* __restrict__ list_m,
+                                                           const int* __restrict__ lpos, int rec_cap, int lcap,
+                                                           int nch, const int* __restrict__ csum,
+                                                           int* __restrict__ dstd, int* __restrict__ dtot) {
+  __shared__ int wsum[16];
+  __shared__ int s_base;
+  constexpr int kPer = kLetChunk / 1024;
+  const int j = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int L = min(lpos[rec_cap], lcap);
+  const int i0 = j * kLetChunk;
+  if (i0 >= L && j > 0) return;  // (chunk 0 always runs: it writes the total of an empty list)
+  if (tid < 64) {                // base = chunk sums before this one
+    int b = 0;
+    for (int k = tid; k < j; k += 64) b += csum[q * nch + k];
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) b += __shfl_xor(b, dd, 64);
+    if (tid == 0) s_base = b;
+  }
+  int x[kPer], s = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int i = i0 + kPer * tid + k;
+    x[k] = (i < L && ((list_m[i] >> q) & 1u)) ? list_w[i] : 0;
+    s += x[k];
+  }
+  int inc = s;
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const int u = __shfl_up(inc, dd, 64);
+    if (lane >= dd) inc += u;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int pre = s_base;
+  for (int k = 0; k < wv; k++) pre += wsum[k];
+  int run = pre + inc - s;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int i = i0 + kPer * tid + k;
+    if (i < L) dstd[(size_t)q * lcap + i] = run;
+    run += x[k];
+  }
+  // the block of the list's last chunk (or chunk 0 of an empty list) knows the destination's total
+  if (tid == 1023 && (i0 + kLetChunk >= L)) dtot[q] = pre + inc;
+}
+
+// the copy of record `fr` (pool index c on the sender) that goes to destination q
+__device__ __forceinline__ bh_frec reloc_pd(bh_frec fr, int c, const int* __restrict__ w,
+                                            const unsigned* __restrict__ wmask, const int* __restrict__ lpos,
+                                            const int* __restrict__ dq /* dstd + q * lcap */, int lcap, int blocks0,
+                                            int rec_cap, int q) {
+  if (c >= rec_cap) return fr;  // a body digest (child of an unsplit multi-body cell): no children
+  const int wc = w[c];
+  const int i = wc > 0 ? lpos[c] : lcap;
+  if (wc > 0 && i < lcap && ((wmask[c] >> q) & 1u)) {
+    fr.first = blocks0 + dq[i];
+    fr.meta = wc;
+  } else if (fr.thr2 >= 0.0f) {  // no body of rank q can open this cell: its copy there is closed
+    fr.first = 0;
+    fr.thr2 = -1.0f;
+  }
+  return fr;
+}
+
+// header, needs row and pieces of every destination's segment: one block per destination
+__global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_export_pd_head_kernel(
+    const bh_frec* __restrict__ frec, int rec_cap, const int* __restrict__ w, const unsigned* __restrict__ wmask,
+    const int* __restrict__ lpos, const int* __restrict__ dstd, const int* __restrict__ dtot, int lcap,
+    const int* __restrict__ piece_idx, const int* __restrict__ ddi, int seg0, int stride, int world, int me,
+    bh_frec* __restrict__ send) {
+  const int q = blockIdx.x, t = threadIdx.x;
+  bh_frec* seg = send + (size_t)q * stride;
+  const int blocks0 = seg0 + kSegBlocks0;
+  const int np = ddi[8];
+  const bool over = lpos[rec_cap] > lcap;  // more exporting cells than the list holds: nothing fits
+  const int need = (q == me) ? kSegBlocks0 : kSegBlocks0 + (over ? stride : dtot[q]);
+  const bool fits = need <= stride && q != me;
+  if (t == 0) {
+    bh_frec h = frec_null();
+    h.thr2 = 0.0f;
+    h.first = need;
+    h.meta = np;
+    frec_put(seg, 0, h);
+  }
+  if (t < 24) {
+    int v = 0;
+    if (t < world && t != me) v = kSegBlocks0 + (over ? stride : dtot[t]);
+    reinterpret_cast<int*>(seg)[seg_row_dword(t)] = v;
+  }
+  bh_frec fr = frec_null();
+  if (t < np && q != me)
+    fr = reloc_pd(frec_get(frec, piece_idx[t]), piece_idx[t], w, wmask, lpos, dstd + (size_t)q * lcap, lcap, blocks0,
+                  rec_cap, q);
+  // a segment that does not fit is sent closed: its pieces are made unopenable, so the (discarded) force pass
+  // that runs before the host sees the header never walks unwritten records
+  if (!fits) fr.thr2 = -1.0f;
+  frec_put(seg, kSegPieces0 + t, fr);
+}
+
+__global__ __launch_bounds__(256) void dd_export_pd_kernel(const bh_frec* __restrict__ frec, int rec_cap,
+                                                           const int* __restrict__ w,
+                                                           const unsigned* __restrict__ wmask,
+                                                           const int* __restrict__ lpos,
+                                                           const int* __restrict__ list_e,
+                                                           const int* __restrict__ dstd,
+                                                           const int* __restrict__ dtot, int lcap, int seg0,
+                                                           int stride, int world, int me,
+                                                           bh_frec* __restrict__ send) {
+  __shared__ int s_tot[64];
+  if (threadIdx.x < 64) s_tot[threadIdx.x] = (int)threadIdx.x < world ? dtot[threadIdx.x] : 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ln = lpos[rec_cap];
+  if (i >= Ln || Ln > lcap) return;
+  const int e = list_e[i];
+  const int wv = w[e];
+  // destinations that get this block: may open the cell, are not this rank, and their segment fits (else it is
+  // sent closed) and has room for the block
+  unsigned mask = wmask[e] & ~(1u << me);
+  for (unsigned m = mask; m; m &= m - 1) {
+    const int q = __ffs(m) - 1;
+    if (kSegBlocks0 + s_tot[q] > stride || kSegBlocks0 + dstd[(size_t)q * lcap + i] + wv > stride) mask &= ~(1u << q);
+  }
+  if (!mask) return;
+  const bh_frec fr = frec_get(frec, e);
+  const int blocks0 = seg0 + kSegBlocks0;
+  // children of a cell, or the body digests of an unsplit multi-body cell: one kind of block.  A child's own
+  // export data is fetched once, then relocated per destination.
+  for (int k = 0; k < wv; k++) {
+    const int c = fr.first + k;
+    const bh_frec cr = frec_get(frec, c);
+    int wc = 0, ci = lcap;
+    unsigned cm = 0u;
+    if (c < rec_cap) {
+      wc = w[c];
+      if (wc > 0) {
+        ci = lpos[c];
+        cm = wmask[c];
+      }
+    }
+    for (unsigned m = mask; m; m &= m - 1) {
+      const int q = __ffs(m) - 1;
+      bh_frec o = cr;
+      if (c < rec_cap) {
+        if (wc > 0 && ci < lcap && ((cm >> q) & 1u)) {
+          o.first = blocks0 + dstd[(size_t)q * lcap + ci];
+          o.meta = wc;
+        } else if (o.thr2 >= 0.0f) {  // no body of rank q can open this child: its copy there is closed
+          o.first = 0;
+          o.thr2 = -1.0f;
+        }
+      }
+      frec_put(send + (size_t)q * stride, kSegBlocks0 + dstd[(size_t)q * lcap + i] + k, o);
+    }
+  }
+  if (wv & 1)
+    for (unsigned m = mask; m; m &= m - 1) {
+      const int q = __ffs(m) - 1;
+      const int off = kSegBlocks0 + dstd[(size_t)q * lcap + i];
+      if (off + wv < stride) frec_put(send + (size_t)q * stride, off + wv, frec_null());
+    }
+}
+
 // Gathered LET segments are records written by OTHER ranks: before any wave walks them, every openable record
 // (thr2 >= 0) of every remote segment must keep its child block inside its own segment's block area, start it
 // on an even record and have 1..8 children.  A record that does not is closed (thr2 = -1: accepted by every body,
@@ -768,7 +1012,7 @@ __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ 
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)world * stride) return;
   const int q = (int)(t / stride), k = (int)(t - (long long)q * stride);
-  if (q == me || k == 0) return;  // own segment: written by this rank's export; record 0: the header
+  if (q == me || k < kSegPieces0) return;  // own segment: written by this rank's export; records 0..3: header + needs row
   const long long seg0 = (long long)seg_base + (long long)q * stride;
   // the header's count = records the sender needed: beyond it (or in a segment sent closed because it did
   // not fit) nothing was written this step and nothing is reachable
@@ -840,7 +1084,7 @@ __device__ __forceinline__ bh_frec top_piece_record(const bh_dd_piece* __restric
   if ((side == 1 && d.owner != me) || (side == 2 && d.owner == me)) return frec_null();
   if (d.owner == me) return frec_get(pool, d.rec_idx);
   const int k = slot - d.owner * kDescPerRank - 1;
-  return frec_get(pool, (long long)seg_base + (long long)d.owner * stride + 1 + k);
+  return frec_get(pool, (long long)seg_base + (long long)d.owner * stride + kSegPieces0 + k);
 }
 
 // Per-level bitmasks over the piece boundaries (row v+1: bit p set iff d[p] <= v): nearest-smaller
@@ -1132,10 +1376,12 @@ void bh_dd_free(bh_ctx* c) {
   }
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
                   d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2,
-                  d->cls_done, d->abs_done, d->arrive, c->dd_minmax};
+                  d->cls_done, d->abs_done, d->arrive, c->dd_minmax, d->wmask, d->list_e, d->list_w, d->list_m, d->dstd,
+                  d->dtot, d->csum};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->host) (void)hipHostFree(d->host);
+  if (d->host_rows) (void)hipHostFree(d->host_rows);
   if (d->ev_let) (void)hipEventDestroy(d->ev_let);
   if (d->ev_x3) (void)hipEventDestroy(d->ev_x3);
   if (d->ev_own) (void)hipEventDestroy(d->ev_own);
@@ -1230,6 +1476,15 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   }
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
   if (ok) memset(d->host, 0, (64 + 8) * sizeof(int));
+  ok = ok && hipHostMalloc((void**)&d->host_rows, 64 * 32 * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->wmask, ((size_t)c->rec_cap + 1 + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->list_e, ((size_t)n_cap + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->list_w, ((size_t)n_cap + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->list_m, ((size_t)n_cap + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->dstd, ((size_t)world * n_cap + 64) * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->dtot, 64 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->csum, ((size_t)world * (n_cap / 8192 + 2) + 64) * 4) == hipSuccess;
+  d->let_mode = 0;
   ok = ok && hipMalloc((void**)&c->dd_minmax, 8 * sizeof(float)) == hipSuccess;
   c->dd_minmax_ok = false;
   {
@@ -1432,13 +1687,42 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
                                                    d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;
   dd_mark_kernel<<<(c->rec_cap + kMarkChunk) / kMarkChunk, 256, 0, c->stream>>>(
-      c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w);
+      c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w,
+      d->let_mode == 1 ? d->wmask : nullptr);
   BH_HIP(c, hipGetLastError());
+  if (d->let_mode == 1) {  // `send_x4` holds world segments of `stride` records, exchanged with an all-to-all
+    const int n_cap = (c->rec_cap - 8) / 3;
+    BH_HIP(c, bhk_scan_i32_flag(c, d->w, d->dst, c->rec_cap));  // dst = lpos: list position of every exporting cell
+    dd_let_list_kernel<<<blocks, 256, 0, c->stream>>>(d->w, d->wmask, d->dst, c->rec_cap, n_cap, d->list_e, d->list_w,
+                                                      d->list_m);
+    {
+      const int nch = (n_cap + kLetChunk - 1) / kLetChunk;
+      const dim3 grid((unsigned)nch, (unsigned)d->world);
+      dd_let_sums_kernel<<<grid, 1024, 0, c->stream>>>(d->list_w, d->list_m, d->dst, c->rec_cap, n_cap, nch, d->csum);
+      dd_let_scan_kernel<<<grid, 1024, 0, c->stream>>>(d->list_w, d->list_m, d->dst, c->rec_cap, n_cap, nch, d->csum,
+                                                       d->dstd, d->dtot);
+    }
+    const int seg0 = d->seg_base + d->rank * stride;
+    dd_export_pd_head_kernel<<<d->world, BH_DD_PIECE_CAP, 0, c->stream>>>(
+        c->frec, c->rec_cap, d->w, d->wmask, d->dst, d->dstd, d->dtot, n_cap, d->piece_idx, d->ddi, seg0, stride,
+        d->world, d->rank, (bh_frec*)send_x4);
+    dd_export_pd_kernel<<<(n_cap + 255) / 256, 256, 0, c->stream>>>(c->frec, c->rec_cap, d->w, d->wmask, d->dst,
+                                                                   d->list_e, d->dstd, d->dtot, n_cap, seg0, stride,
+                                                                   d->world, d->rank, (bh_frec*)send_x4);
+    BH_HIP(c, hipGetLastError());
+    return BH_OK;
+  }
   BH_HIP(c, bhk_scan_i32_even(c, d->w, d->dst, c->rec_cap));  // exported blocks start at even records
   dd_export_kernel<<<blocks, 256, 0, c->stream>>>(c->frec, c->rec_cap, d->w, d->dst,
                                                   d->piece_idx, d->ddi, d->seg_base + d->rank * stride, stride,
-                                                  (bh_frec*)send_x4);
+                                                  d->world, (bh_frec*)send_x4);
   BH_HIP(c, hipGetLastError());
+  return BH_OK;
+}
+
+int bh_dd_set_let_mode(bh_ctx* c, int mode) {
+  if (!c || !c->dd || (mode != 0 && mode != 1)) return BH_ERR_BAD_ARG;
+  c->dd->let_mode = mode;
   return BH_OK;
 }
 
@@ -1471,10 +1755,9 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
   bh_dd_state* d = c->dd;
   if (stride < kSegBlocks0 || stride > d->let_cap || (stride & 1)) return BH_ERR_BAD_ARG;
   // the segment headers (records each rank needed) go to the host for bh_dd_let_check
-  BH_HIP(c, hipMemcpy2DAsync(d->host, sizeof(int),
-                             reinterpret_cast<const int*>(d->pool) + BH_FREC_DW(d->seg_base, BH_FF_FIRST),
-                             (size_t)stride * sizeof(bh_frec), sizeof(int), (size_t)d->world,
-                             hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(c, hipMemcpy2DAsync(d->host_rows, 128, reinterpret_cast<const char*>(d->pool) + (size_t)d->seg_base * 32,
+                             (size_t)stride * sizeof(bh_frec), 128, (size_t)d->world, hipMemcpyDeviceToHost,
+                             c->stream));
   BH_HIP(c, hipEventRecord(d->ev_let, c->stream));
   d->let_copy_pending = true;
   {
@@ -1521,10 +1804,16 @@ int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts) {
   if (!d->let_copy_pending) return BH_ERR_ORDER;
   BH_HIP(c, hipEventSynchronize(d->ev_let));
   d->let_copy_pending = false;
+  // counts[q] = the most records rank q needed for any receiver (its needs row: every rank holds the same matrix,
+  // so every rank takes the same decision); a negative header marks a rank that left the step
   int worst = 0;
   for (int q = 0; q < d->world; q++) {
-    if (counts) counts[q] = d->host[q];
-    if (d->host[q] > worst) worst = d->host[q];
+    const int* seg = d->host_rows + 32 * q;
+    int need = seg[10];  // header record 0, field `first`
+    if (need >= 0)
+      for (int j = 0; j < d->world; j++) need = seg[seg_row_dword(j)] > need ? seg[seg_row_dword(j)] : need;
+    if (counts) counts[q] = need;
+    if (need > worst) worst = need;
   }
   return worst > stride ? BH_ERR_SMALL_BUFFER : BH_OK;
 }

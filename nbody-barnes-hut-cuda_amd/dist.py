@@ -115,6 +115,10 @@ class TorchComm:
     def all_gather(self, out, send):
         all_gather_rows(out.view(self.world, -1), send.view(1, -1), self.group, self.into_tensor)
 
+    def all_to_all(self, out, send):
+        """out chunk q <- rank q's send chunk `rank` (equal chunks)"""
+        dist.all_to_all_single(out.view(-1), send.view(-1), group=self.group)
+
 
 class LocalGroup:
     """P ranks as P threads of one process on one device and ONE stream (tests, 1-GPU rehearsal):
@@ -141,6 +145,16 @@ class LocalComm:
             o[q * n:(q + 1) * n].copy_(g.slots[q].view(-1))
         g.barrier.wait()
 
+    def all_to_all(self, out, send):
+        g = self.g
+        g.slots[self.rank] = send
+        g.barrier.wait()
+        k = send.numel() // self.world
+        o = out.view(-1)
+        for q in range(self.world):
+            o[q * k:(q + 1) * k].copy_(g.slots[q].view(-1)[self.rank * k:(self.rank + 1) * k])
+        g.barrier.wait()
+
 
 def _round_up(v, a):
     return (int(v) + a - 1) // a * a
@@ -158,6 +172,12 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
         return e.download_order()
 
 
+import os as _os
+# X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
+# (BH_DD_LET_MODE=0 selects round 2's all-gather of the union for A/B)
+LET_MODE_DEFAULT = int(_os.environ.get("BH_DD_LET_MODE", "1"))
+
+
 class DomainLeft(RuntimeError):
     """Raised by DomainStepper.step ON EVERY RANK after the same exchange (a rank-local failure announced through
     the X4 header, or a LET beyond let_cap decided from all-gathered counts): the only exception a caller may
@@ -170,9 +190,11 @@ class DomainStepper:
     stitched tree for its own bodies.  Four all-gathers per step, no replicated stage."""
 
     def __init__(self, pkg, ic, comm, device, stream=None, params=None, slack=1.3, mig_frac=0.5,
-                 let_cap=None, order=None, split=True, **kw):
+                 let_cap=None, order=None, split=True, let_mode=None, **kw):
         self.comm = comm
         self.split = bool(split)
+        # X4: 0 = all-gather of the union segment (round 2), 1 = per-destination segments, all-to-all
+        self.let_mode = LET_MODE_DEFAULT if let_mode is None else int(let_mode)
         self.world, self.rank = comm.world, comm.rank
         P, r = self.world, self.rank
         n = len(ic[0])
@@ -192,7 +214,7 @@ class DomainStepper:
         self.mig_rounds = 0
         self.mig_last = 0
         e_cls = pkg.Engine
-        lmin = 2 + 512  # header + piece slots + padding (BH_DD_PIECE_CAP, csrc/bh_dd.hip kSegBlocks0)
+        lmin = 4 + 512  # header + needs row + piece slots (BH_DD_PIECE_CAP, csrc/bh_dd.hip kSegBlocks0)
         self.let_cap = int(let_cap) if let_cap else lmin + self.n_cap
         self.let_cap += self.let_cap & 1                        # segments hold whole 64-byte digest pairs
         sz = e_cls.dd_query(self.n_cap, P, self.mig_cap, self.let_cap)
@@ -207,11 +229,13 @@ class DomainStepper:
             self.x2r = torch.zeros(P * sz.x2_bytes, **u8)
             self.x3s = torch.zeros(sz.x3_bytes, **u8)
             self.x3r = torch.zeros(P * sz.x3_bytes, **u8)
-            self.lets = torch.zeros(self.let_cap * 32, **u8)
+            self.lets = torch.zeros((P if self.let_mode == 1 else 1) * self.let_cap * 32, **u8)
             self.pool = torch.zeros(sz.pool_records * 32, **u8)
         self.stream.synchronize()
+        assert sz.let_min == lmin, (sz.let_min, lmin)
         self.e = e_cls(self.n_cap, params=params, device=device, stream=self.stream.cuda_stream, **kw)
         self.e.dd_init(P, r, n, self.mig_cap, self.let_cap, self.pool.data_ptr(), sz.pool_records)
+        self.e.dd_set_let_mode(self.let_mode)
         self.e.dd_upload(x, y, z, vx, vy, vz, m, mine.astype("int32"))
         self.stride = min(self.let_cap, _round_up(lmin + self.n_cap // 8, 256))
         self.let_counts = None
@@ -219,11 +243,12 @@ class DomainStepper:
         self.n_loc = len(mine)
 
     @classmethod
-    def with_engine(cls, engine, sz, comm, n_cap, mig_cap, let_cap, tensor_device="cpu", split=True):
+    def with_engine(cls, engine, sz, comm, n_cap, mig_cap, let_cap, tensor_device="cpu", split=True, let_mode=0):
         """The per-step protocol (exchanges, size negotiation, failure handling) around ANY object with
         the dd_* methods of Engine — tests/dd_cpu_worker.py drives it on CPU tensors over gloo."""
         self = cls.__new__(cls)
         self.comm, self.split = comm, bool(split)
+        self.let_mode = int(let_mode)
         self.world, self.rank = comm.world, comm.rank
         self.e, self.sz, self.stream = engine, sz, None
         self.n_cap, self.mig_cap, self.let_cap = int(n_cap), int(mig_cap), int(let_cap)
@@ -238,7 +263,7 @@ class DomainStepper:
         self.x2r = torch.zeros(P * sz.x2_bytes, **u8)
         self.x3s = torch.zeros(sz.x3_bytes, **u8)
         self.x3r = torch.zeros(P * sz.x3_bytes, **u8)
-        self.lets = torch.zeros(self.let_cap * 32, **u8)
+        self.lets = torch.zeros((P if self.let_mode == 1 else 1) * self.let_cap * 32, **u8)
         self.pool = torch.zeros(sz.pool_records * 32, **u8)
         self.stride = min(self.let_cap, _round_up(sz.let_min + self.n_cap // 8, 256))
         return self
@@ -375,16 +400,20 @@ class DomainStepper:
                 while True:
                     stride = self.stride
                     seg = self.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32]
+                    nseg = P if self.let_mode == 1 else 1               # segments this rank sends
+                    send = self.lets[:nseg * stride * 32]
+                    x4 = c.all_to_all if self.let_mode == 1 else c.all_gather
                     if failed is not None:
-                        self.lets[:stride * 32].zero_()
-                        self.lets[:64].view(torch.int32)[10] = -1       # header count < 0: "this rank failed" (record 0 of a
-                        # digest pair: field `first` is dword 10, csrc/bh_internal.h)
-                        c.all_gather(seg, self.lets[:stride * 32])
+                        send.zero_()
+                        # header count < 0: "this rank failed" (record 0 of a digest pair: field `first` is dword 10,
+                        # csrc/bh_internal.h) — in every segment it sends
+                        send.view(nseg, stride * 32)[:, :64].view(torch.int32)[:, 10] = -1
+                        x4(seg, send)
                         raise DomainLeft(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
                     # own pieces on the side stream (first try only: it overlaps X4), LET marked / exported
                     self._phase_let(stride, self.split and tries == 0)
                     tries += 1
-                    c.all_gather(seg, self.lets[:stride * 32])          # X4: LET records, in place
+                    x4(seg, send)                                       # X4: LET records, in place
                     self._mark(4)
                     ok, counts = self._phase_force(stride)              # top tree, remote (or whole) pass, X4 sizes
                     self.let_counts = counts

@@ -338,6 +338,10 @@ class Engine:
             raise BhError(st, "bh_dd_let_check")
         return st == 0, counts
 
+    def dd_set_let_mode(self, mode):
+        """0: X4 = all-gather of one union segment; 1: per-destination segments exchanged with an all-to-all"""
+        self._ck(lib.bh_dd_set_let_mode(self._h, int(mode)), "bh_dd_set_let_mode")
+
     # one call per phase group (bh_dd_phase_*): what DomainStepper.step uses
     def dd_phase_migrate(self, gathered_x1_ptr, send_x2_ptr, limit):
         self._ck(lib.bh_dd_phase_migrate(self._h, C.c_void_p(int(gathered_x1_ptr)), C.c_void_p(int(send_x2_ptr)),

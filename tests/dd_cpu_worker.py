@@ -69,7 +69,10 @@ class ScriptedEngine:
 
     # X4: record 0 of the segment (slot 0 of a 64-byte digest pair), field `first` = dword 10 = records needed
     def dd_let_pack(self, x3ptr, sendptr, stride):
-        self.st.lets[:64].view(torch.int32)[10] = self.need[self.step_no][self.rank]
+        # all-gather flavour: one segment; per-destination flavour: one segment per receiver, each with the header
+        nseg = self.world if self.st.let_mode == 1 else 1
+        need = self.need[self.step_no][self.rank]
+        self.st.lets[:nseg * stride * 32].view(nseg, stride * 32)[:, :64].view(torch.int32)[:, 10] = need
         self.calls.append(("let_pack", stride))
 
     def dd_top(self, x3ptr, stride):
@@ -90,21 +93,22 @@ class ScriptedEngine:
 
 def main():
     out_path, scenario = sys.argv[1], sys.argv[2]
+    let_mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     dist.init_process_group("gloo")
     bhpkg.load()
     from nbody_barnes_hut_cuda_amd import dist as bhdist
     comm = bhdist.TorchComm()
     P, r = comm.world, comm.rank
-    n_cap, mig_cap, let_cap = 20000, 10000, 2 + PIECES + 20000
+    n_cap, mig_cap, let_cap = 20000, 10000, 4 + PIECES + 20000
     sz = types.SimpleNamespace(x1_bytes=64, x2_bytes=32 + 32 * mig_cap, x3_bytes=80 * (1 + PIECES),
                                pool_records=2 * n_cap + 8 + 100 + P * let_cap + 8, seg_base=2 * n_cap + 108,
-                               let_min=2 + PIECES, let_cap=let_cap, top_base=2 * n_cap + 8)
+                               let_min=4 + PIECES, let_cap=let_cap, top_base=2 * n_cap + 8)
     steps = 4
     emig = [[10, 20, 5][:P] + [0] * (P - 3), [6000] * P, [9000] + [100] * (P - 1), [50] * P]
     need = [[600] * P, [700 + 4000 * (q == 1) for q in range(P)], [15000] * P, [15500] * P]
     fail_at = (2, P - 1) if scenario == "failure" else None
     eng = ScriptedEngine(r, P, emig, need, fail_at)
-    st = bhdist.DomainStepper.with_engine(eng, sz, comm, n_cap, mig_cap, let_cap)
+    st = bhdist.DomainStepper.with_engine(eng, sz, comm, n_cap, mig_cap, let_cap, let_mode=let_mode)
     eng.bind(st)
     err = None
     try:

@@ -75,18 +75,20 @@ def test_torchcomm_all_gather(world):
     assert r.returncode == 0, r.stdout.decode()[-2000:]
 
 
+@pytest.mark.parametrize("let_mode", [0, 1])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("scenario", ["normal", "failure"])
-def test_domain_stepper_protocol(world, scenario, tmp_path):
+def test_domain_stepper_protocol(world, scenario, let_mode, tmp_path):
     """the per-step protocol of the domain-decomposed multi-GPU step (dist.DomainStepper.step) on CPU
     tensors over gloo with a scripted engine: adaptive exchange sizes, extra migration rounds when a
     wave of emigrants exceeds this step's X2 size, the LET retry when a segment outgrows the stride,
-    and a rank-local failure that every rank must leave together (no rank stranded in a collective)"""
+    and a rank-local failure that every rank must leave together (no rank stranded in a collective); with X4 as
+    the all-gather of one union segment (let_mode 0) and as an all-to-all of per-destination segments (1)"""
     import json
     out = str(tmp_path / "proto.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dd_cpu_worker.py"), out, scenario]
+           os.path.join(ROOT, "tests", "dd_cpu_worker.py"), out, scenario, str(let_mode)]
     r = subprocess.run(cmd, timeout=300, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     res = json.load(open(out))

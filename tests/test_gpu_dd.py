@@ -76,13 +76,16 @@ def rel(a, b):
     return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
 
 
+@pytest.mark.parametrize("let_mode", [0, 1])
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_dd_first_step_matches_single_context(world):
+def test_dd_first_step_matches_single_context(world, let_mode):
+    """let_mode 0: X4 = all-gather of the union of what any rank may open; 1 (default): per-destination segments
+    exchanged with an all-to-all — a receiver holds only what its own boxes can open, the rest arrives closed"""
     pkg = bhpkg.load()
     n = 60000
     ic = pkg.plummer(n, seed=7)
     p1, v1, a1 = single(ic, 1)
-    out = run_ranks(world, ic, 1)
+    out = run_ranks(world, ic, 1, let_mode=let_mode)
     p, v, a = merge(out, n)
     e = rel(a, a1)
     # same accepted sets; fp32 summation order differs (top tree first, segments interleaved)
@@ -92,20 +95,41 @@ def test_dd_first_step_matches_single_context(world):
     assert np.abs(p - p1).max() < 1e-3
 
 
-@pytest.mark.parametrize("world,split", [(2, True), (4, True), (4, False)])
-def test_dd_many_steps_conserve_and_track(world, split):
+@pytest.mark.parametrize("world,split,let_mode", [(2, True, 1), (4, True, 1), (4, False, 1), (4, True, 0), (3, False, 0)])
+def test_dd_many_steps_conserve_and_track(world, split, let_mode):
     """split: two-pass force (own pieces on a side stream while X4 is in flight + remote pieces)"""
     pkg = bhpkg.load()
     n = 40000
     ic = pkg.plummer(n, seed=11)
     steps = 12
     p1, v1, a1 = single(ic, steps)
-    out = run_ranks(world, ic, steps, split=split)
+    out = run_ranks(world, ic, steps, split=split, let_mode=let_mode)
     p, v, a = merge(out, n)     # also checks that migration lost / duplicated nobody
     assert sum(o[-1] for o in out) == n
     assert np.abs(p - p1).max() < 5e-2, np.abs(p - p1).max()
     e = rel(a, a1)
     assert np.median(e) < 1e-4, np.median(e)
+
+
+def test_dd_per_destination_let_is_smaller_and_equivalent():
+    """the per-destination X4 (all-to-all) against the union X4 (all-gather) on the same system, 8 ranks x 5 steps:
+    the same canonical tree is walked (the closed copies are exactly the cells the receiver cannot open), so the
+    states agree to the last bit of the summation order; and the largest segment any pair of ranks exchanges is
+    well below the union every rank used to receive from every other"""
+    pkg = bhpkg.load()
+    n = 160000
+    ic = pkg.plummer(n, seed=19)
+    o0 = run_ranks(8, ic, 5, let_mode=0)
+    o1 = run_ranks(8, ic, 5, let_mode=1)
+    p0, v0, a0 = merge(o0, n)
+    p1, v1, a1 = merge(o1, n)
+    e = rel(a1, a0)
+    assert np.median(e) < 1e-6 and e.max() < 2e-3, (np.median(e), e.max())
+    assert np.abs(p1 - p0).max() < 1e-3
+    need0 = max(int(o[4].max()) for o in o0)     # records of the largest union segment
+    need1 = max(int(o[4].max()) for o in o1)     # records of the largest per-destination segment
+    print(f"largest X4 segment: union {need0} records, per destination {need1}")
+    assert need1 < 0.75 * need0, (need0, need1)
 
 
 def test_dd_migration_across_ranks():
@@ -300,7 +324,24 @@ def test_dd_malformed_let_record_is_closed_and_reported(how):
             for q in range(self.world):
                 o[q * k:(q + 1) * k].copy_(g.slots[q].view(-1))
             if self.rank == 0 and k % 64 == 0:      # X4 (the only payload that is whole 64-byte digest pairs)
-                seg = o[k:2 * k].view(torch.int32).view(-1, 16)           # rank 1's segment, one row per pair
+                self._corrupt(o[k:2 * k])
+            g.barrier.wait()
+
+        def all_to_all(self, out, send):             # X4 of the per-destination flavour
+            g = self.g
+            g.slots[self.rank] = send
+            g.barrier.wait()
+            k = send.numel() // self.world
+            o = out.view(-1)
+            for q in range(self.world):
+                o[q * k:(q + 1) * k].copy_(g.slots[q].view(-1)[self.rank * k:(self.rank + 1) * k])
+            if self.rank == 0:
+                self._corrupt(o[k:2 * k])
+            g.barrier.wait()
+
+        def _corrupt(self, segbytes):
+            if True:
+                seg = segbytes.view(torch.int32).view(-1, 16)             # rank 1's segment as rank 0 holds it, a row per pair
                 thr = seg.view(torch.float32)[:, 8]
                 cand = torch.nonzero((thr[300:] >= 0) & (seg[300:, 12] > 0))  # an openable record of the block area
                 if len(cand) > 0:   # (a segment sent closed because it did not fit carries no blocks: wait for the retry)
@@ -308,7 +349,6 @@ def test_dd_malformed_let_record_is_closed_and_reported(how):
                     if how == "nan_threshold":
                         seg.view(torch.float32)[300 + int(cand[0]), 8] = float("nan")
                     CorruptingComm.hits += 1
-            g.barrier.wait()
 
     def work(r):
         try:
