@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ 
                               // `d2 > thr2`, i.e. always opened: it falls through to the range check
   const long long lo = seg0 + kSegBlocks0, hi = seg0 + stride;
   const bool ok = r.meta >= 1 && r.meta <= 8 && (r.first & 1) == 0 && (long long)r.first >= lo &&
-                  (long long)r.first + r.meta <= hi;
+                  (long long)r.first + r.meta <= hi && r.pad == frec_link(r.first, r.meta);  // (the walk follows the link)
   if (!ok) {
     reinterpret_cast<float*>(pool)[BH_FREC_DW(e, BH_FF_THR2)] = -1.0f;
     atomicOr(&info->flags, BH_FLAG_DD_LET_INVALID);

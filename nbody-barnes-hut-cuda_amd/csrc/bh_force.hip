@@ -460,23 +460,23 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // s100 is a dummy target.  Measured (force ms without / with): 16,384 bodies 0.150 / 0.145, 65,536 0.219 / 0.214,
 // 125,000 0.272 / 0.263, 250,000 0.442 / 0.441, 1M 1.217 / 1.226 — on for launches of <= kPrefetchMaxBodies.
 // (Also touching the new stack top at every pop measured slower at every size: +0.4 % at 16k ... +5 % at 1M.)
-#define BH_PF_PUSH(FIRST)                                                                                \
+#define BH_PF_PUSH(LINK)                                                                                 \
   ".if %c[pf]\n"                                                                                          \
-  "s_lshl_b32 s24, " FIRST ", 5\n"                                                                        \
+  "s_andn2_b32 s24, " LINK ", 63\n"                                                                        \
   "s_load_dword s100, s[20:21], s24 offset:0\n"                                                           \
   "s_load_dword s100, s[20:21], s24 offset:64\n"                                                          \
   ".endif\n"
-#define BH_PUSH1(FIRST, META, MLO, MHI)                                                                         \
+// a stack entry = (link, lane mask): link = byte offset of the child block | its child count (bh_internal.h)
+#define BH_PUSH1(LINK, META, MLO, MHI)                                                                         \
   "s_mov_b32 m0, s30\n"                                                                                   \
   "s_add_u32 s30, s30, 1\n"                                                                               \
   ".if %c[stats] == 0\n"                                                                                  \
   "s_max_u32 s31, s31, s30\n"                                                                             \
   "s_max_u32 s16, s16, " META "\n"                                                                        \
   ".endif\n"                                                                                              \
-  "v_writelane_b32 v48, " FIRST ", m0\n"                                                                  \
-  "v_writelane_b32 v49, " META ", m0\n"                                                                   \
+  "v_writelane_b32 v48, " LINK ", m0\n"                                                                   \
   "v_writelane_b32 v50, " MLO ", m0\n"                                                                   \
-  "v_writelane_b32 v51, " MHI ", m0\n" BH_PF_PUSH(FIRST)
+  "v_writelane_b32 v51, " MHI ", m0\n" BH_PF_PUSH(LINK)
 // a pair with at least one opened record: push the opened one(s), then continue in the masked variant of its
 // force half.  MA / MB are the pair's OPEN masks (v_cmp_nlt under EXEC = the block's lane mask).
 #define BH_ARMS_(q, MA, MALO, MAHI, MB, MBLO, MBHI, F0, M0, F1, M1)                                       \
@@ -487,7 +487,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   "s_cbranch_scc1 L_segm" #q "_%=\n"                                                                      \
   "L_pushB" #q "_%=:\n" BH_PUSH1(F1, M1, MBLO, MBHI)                                                      \
   "s_branch L_segm" #q "_%=\n"
-// pair p of the window: x s[36+16p:37+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11, meta +12/+13
+// pair p of the window: x s[36+16p:37+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11, meta +12/+13, link +14/+15
 #define BH_P0 "s[36:37]", "s[38:39]", "s[40:41]", "s44", "s45"
 #define BH_P1 "s[52:53]", "s[54:55]", "s[56:57]", "s60", "s61"
 #define BH_P2 "s[68:69]", "s[70:71]", "s[72:73]", "s76", "s77"
@@ -505,8 +505,8 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_MK1 "s[12:13]", "s12", "s13", "s[10:11]", "s10", "s11"  // set 1 (odd pairs)
 #define BH_ARMS(...) BH_X(BH_ARMS_, __VA_ARGS__)
 #define BH_ARMS_ALL                                                                                      \
-  BH_ARMS(3, BH_MK1, "s94", "s96", "s95", "s97") BH_ARMS(2, BH_MK0, "s78", "s80", "s79", "s81")          \
-  BH_ARMS(1, BH_MK1, "s62", "s64", "s63", "s65") BH_ARMS(0, BH_MK0, "s46", "s48", "s47", "s49")
+  BH_ARMS(3, BH_MK1, "s98", "s96", "s99", "s97") BH_ARMS(2, BH_MK0, "s82", "s80", "s83", "s81")          \
+  BH_ARMS(1, BH_MK1, "s66", "s64", "s67", "s65") BH_ARMS(0, BH_MK0, "s50", "s48", "s51", "s49")
 // end of a block: pop the next one (the test of L_pop folded into the loop-back branch)
 #define BH_POP_TAIL "s_sub_u32 s30, s30, 1\n s_cbranch_scc0 L_popb_%=\n s_branch L_done_%=\n"
 // Dispatch on the child count c (s33) by a two-level branch tree — no jump table, no computed jump:
@@ -547,7 +547,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "v_mov_b32 v20, %[eps2]\n"
       "v_mov_b32 v21, %[eps2]\n"
       "v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
-      "v_mov_b32 v48, 0\n v_mov_b32 v49, 0\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n"
+      "v_mov_b32 v48, 0\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n"
       "s_mov_b32 s30, 0\n"
       "s_mov_b32 s31, 0\n"
       "s_mov_b32 s16, 0\n"
@@ -560,11 +560,11 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_sub_u32 s30, s30, 1\n"
       "s_cbranch_scc1 L_done_%=\n"
       "L_popb_%=:\n"
-      "v_readlane_b32 s33, v49, s30\n"
-      "v_readlane_b32 s32, v48, s30\n"
+      "v_readlane_b32 s32, v48, s30\n"   // link
       "v_readlane_b32 s34, v50, s30\n"
       "v_readlane_b32 s35, v51, s30\n"
-      "s_lshl_b32 s32, s32, 5\n"
+      "s_and_b32 s33, s32, 63\n"         // child count
+      "s_andn2_b32 s32, s32, 63\n"       // byte offset of the block
       "L_block_%=:\n"
       ".if %c[use_budget]\n"
       "s_sub_u32 s17, s17, 1\n"

@@ -16,7 +16,9 @@ struct bh_frec {
   float thr2;     // (s/theta)^2; -1 for a body or a mass<=0 record (always accepted)
   int first;      // child block; body index for a body; digest slot of the first body for an unsplit multi-body cell
   int meta;       // child count (bodies of an unsplit cell count as its children)
-  int pad;
+  int pad;        // LINK = (first << 5) | min(meta, 63): byte offset of the child block and its size in one dword —
+                  // what the hand-scheduled walk keeps on its cross-lane stack (one lane write per push, one lane
+                  // read per pop instead of two); derived by frec_put / the COM stage, never set by callers
 };
 // PHYSICAL layout of a digest pool: records 2p and 2p+1 share one 64-byte PAIR, fields interleaved
 //   dword  0 1 | 2 3 | 4 5 | 6  7  | 8    9    | 10     11     | 12    13    | 14 15
@@ -37,11 +39,17 @@ __host__ __device__ __forceinline__ bh_frec frec_get(const bh_frec* pool, long l
   r.first = i[10]; r.meta = i[12]; r.pad = i[14];
   return r;
 }
+// child blocks start at even records, so bit 5 of first << 5 is free as well: 6 bits of count (63 = "63 or more":
+// the walk then redoes the wave with the generic loop, which reads `meta`)
+__host__ __device__ __forceinline__ int frec_link(int first, int meta) {
+  const unsigned c = meta < 0 ? 0u : (meta > 63 ? 63u : (unsigned)meta);
+  return (int)(((unsigned)first << 5) | c);
+}
 __host__ __device__ __forceinline__ void frec_put(bh_frec* pool, long long e, const bh_frec& r) {
   float* f = reinterpret_cast<float*>(pool) + (size_t)(e >> 1) * 16 + (e & 1);
   int* i = reinterpret_cast<int*>(f);
   f[0] = r.x; f[2] = r.y; f[4] = r.z; f[6] = r.gm; f[8] = r.thr2;
-  i[10] = r.first; i[12] = r.meta; i[14] = r.pad;
+  i[10] = r.first; i[12] = r.meta; i[14] = frec_link(r.first, r.meta);
 }
 __host__ __device__ __forceinline__ bh_frec frec_null() {
   bh_frec z;

@@ -1125,13 +1125,14 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
   q.gm = __shfl_xor(fr.gm, 1, 64); q.thr2 = __shfl_xor(fr.thr2, 1, 64);
   q.first = __shfl_xor(fr.first, 1, 64); q.meta = __shfl_xor(fr.meta, 1, 64);
   if (e >= E) return;
+  const int lk = frec_link(fr.first, fr.meta), lq = frec_link(q.first, q.meta);  // (bh_internal.h: the walk's stack word)
   float4* pair = reinterpret_cast<float4*>(frec) + (size_t)(e >> 1) * 4;
   if ((e & 1) == 0) {  // slot 0 writes x0 x1 y0 y1 | z0 z1 gm0 gm1
     pair[0] = make_float4(fr.x, q.x, fr.y, q.y);
     pair[1] = make_float4(fr.z, q.z, fr.gm, q.gm);
-  } else {             // slot 1 writes thr0 thr1 first0 first1 | meta0 meta1 pad pad
+  } else {             // slot 1 writes thr0 thr1 first0 first1 | meta0 meta1 link0 link1
     pair[2] = make_float4(q.thr2, fr.thr2, __int_as_float(q.first), __int_as_float(fr.first));
-    pair[3] = make_float4(__int_as_float(q.meta), __int_as_float(fr.meta), 0.0f, 0.0f);
+    pair[3] = make_float4(__int_as_float(q.meta), __int_as_float(fr.meta), __int_as_float(lq), __int_as_float(lk));
   }
 }
 
