@@ -80,22 +80,24 @@ def issue_roofline(ws, simds, launch_ms):
     """VALU-issue floor of one force launch from the walk's own event counters (bh_force_walk_stats, counted in
     THIS run) priced with the per-form issue costs above.  Instruction counts follow csrc/bh_force.hip:
     a pair = 3 v_pk_add + 3 v_pk_fma + 2 v_cmp + 2 v_rsq + 3 v_pk_mul + 3 v_pk_fma (+ 2 v_cndmask if a record was
-    opened) and 2 scalar (s_or + branch); a block = 4 v_readlane + 2-4 s_load + ~11 scalar / branch; a push =
-    4 v_writelane + ~7 scalar.  The BOUND is the VALU-only figure (no configuration can beat it); the estimate
+    opened) and 2 scalar (s_or + branch); a block = 2-4 s_load + ~13 scalar / branch; a push = ~9 scalar; a stack
+    entry that is not its block's last push goes through the lanes: 3 v_writelane + 3 v_readlane (counted:
+    lane_spills; the last push of a block stays in scalar registers).  The BOUND is the VALU-only figure (no configuration can beat it); the estimate
     with scalar issue at its measured in-context cost is reported beside it and is an estimate, not a floor."""
     c = ISSUE_CYCLES
     pairs, blocks, masked, waves = float(ws.pairs), float(ws.blocks), float(ws.masked_pairs), float(ws.waves)
     pushes = blocks - waves
     pair_cycles = 3 * c["pk_add_sgpr"] + 6 * c["pk_fma"] + 2 * c["cmp_e64"] + 2 * c["rsq"] + 3 * c["pk_mul"]
-    valu_insts = 16 * pairs + 2 * masked + 4 * blocks + 4 * pushes
-    valu_cycles = pair_cycles * pairs + 2 * c["cndmask_e64"] * masked + c["lane_rw"] * (4 * blocks + 4 * pushes)
-    scalar_insts = 2 * pairs + 13 * blocks + 7 * pushes
+    spills = float(getattr(ws, "lane_spills", 0))
+    valu_insts = 16 * pairs + 2 * masked + 6 * spills
+    valu_cycles = pair_cycles * pairs + 2 * c["cndmask_e64"] * masked + c["lane_rw"] * 6 * spills
+    scalar_insts = 2 * pairs + 13 * blocks + 9 * pushes
     clock_hz = ws.clock_ghz * 1e9
     floor_valu_ms = valu_cycles / simds / clock_hz * 1e3
     est_ms = (valu_cycles + c["scalar_in_context"] * scalar_insts) / simds / clock_hz * 1e3
     return {
         "counted_this_run": {"waves": int(waves), "record_pairs": int(pairs), "blocks": int(blocks),
-                             "pairs_with_opened_record": int(masked)},
+                             "pairs_with_opened_record": int(masked), "stack_entries_through_lanes": int(spills)},
         "valu_insts_per_launch": valu_insts, "scalar_insts_per_launch": scalar_insts,
         "cycles_per_pair_valu": pair_cycles, "issue_cycles_per_form": c, "issue_cycles_provenance": ISSUE_PROVENANCE,
         "clock_ghz_in_kernel": ws.clock_ghz, "simds": simds,

@@ -186,7 +186,9 @@ typedef struct bh_walk_stats {
   uint64_t masked_pairs; /* pairs with an opened record (force half runs with the take masks)          */
   double clock_ghz;      /* median over the waves of shader cycles / constant-clock time               */
   double wave_cycles_max, wave_cycles_mean; /* wave lifetime, shader cycles                            */
-  uint64_t reserved[4];
+  uint64_t lane_spills;  /* stack entries that went through the cross-lane stack (3 v_writelane + 3 v_readlane
+                            each); the others stayed in scalar registers from push to pop                 */
+  uint64_t reserved[3];
 } bh_walk_stats;
 int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out);
 

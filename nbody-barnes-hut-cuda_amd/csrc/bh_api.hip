@@ -396,6 +396,7 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
     out->pairs += r[0];
     out->blocks += r[1];
     out->masked_pairs += r[2];
+    out->lane_spills += r[3];
     if (r[5]) ghz.push_back((double)r[4] / ((double)r[5] * 10.0));  // 100 MHz ticks -> ns
     cyc_max = r[4] > cyc_max ? (double)r[4] : cyc_max;
     cyc_sum += (double)r[4];

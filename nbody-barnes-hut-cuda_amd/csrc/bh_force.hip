@@ -492,6 +492,8 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   "s_add_u32 s30, s30, 1\n"                                                                               \
   ".if %c[stats] == 0\n"                                                                                  \
   "s_max_u32 s31, s31, s30\n"                                                                             \
+  ".else\n"                                                                                               \
+  "s_add_u32 s25, s25, 1\n"            /* entries spilled to the lanes (each is read back once) */        \
   ".endif\n"                                                                                              \
   "v_writelane_b32 v48, s101, m0\n"                                                                       \
   "v_writelane_b32 v50, s22, m0\n"                                                                        \
@@ -551,13 +553,14 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // BUDGET: at most `budget` child blocks are popped (a malformed pool cannot hang the wave); the walk then
 // stops and limit_hit is set.  `root` must be an even record index.
 // STATS (measurement only, result discarded): s16 / s17 / s31 count pairs evaluated / blocks popped / pairs that
-// took the masked path instead of tracking overflow, and the walk is stamped with s_memtime (shader clock)
-// and s_memrealtime (100 MHz); st[0..5] = pairs, blocks, masked pairs, 0, shader cycles, 10-ns ticks.
+// took the masked path instead of tracking overflow, s25 the stack entries spilled to the lanes, and the walk is
+// stamped with s_memtime (shader clock) and s_memrealtime (100 MHz); st[0..5] = pairs, blocks, masked pairs,
+// spilled entries, shader cycles, 10-ns ticks.
 template <bool BUDGET, bool STATS = false, bool PF = false>
 __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u64 m0, float px, float py,
                                                   float pz, float eps2, float& ax, float& ay, float& az,
                                                   int budget, bool& limit_hit, u32* st = nullptr) {
-  int maxsp, maxc, left;
+  int maxsp, maxc, left, spills;
   u64 t0 = 0, r0 = 0;
   if (STATS) {
     t0 = __builtin_amdgcn_s_memtime();
@@ -582,6 +585,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_mov_b32 s33, 1\n"
       "s_mov_b64 s[34:35], %[mask]\n"
       "s_mov_b32 s101, 0\n"              // no top-of-stack entry in scalar registers yet
+      "s_mov_b32 s25, 0\n"
       "s_branch L_block_%=\n"
       "L_take_%=:\n"                     // the entry pushed last is still in scalar registers
       "s_mov_b32 s32, s101\n"
@@ -631,7 +635,9 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_mov_b32 %[maxsp], s31\n"
       "s_mov_b32 %[maxc], s16\n"
       "s_mov_b32 %[left], s17\n"
-      : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left)
+      "s_mov_b32 %[spl], s25\n"
+      : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left),
+        [spl] "=s"(spills)
       : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
         [eps2] "s"(eps2), [budget] "s"(STATS ? 0 : budget), [use_budget] "n"(BUDGET && !STATS ? 1 : 0),
         [stats] "n"(STATS ? 1 : 0), [pf] "n"(PF ? 1 : 0)
@@ -650,7 +656,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
     st[0] = (u32)maxc;   // s16: pairs
     st[1] = (u32)left;   // s17: blocks
     st[2] = (u32)maxsp;  // s31: masked pairs
-    st[3] = 0;
+    st[3] = (u32)spills;  // s25: stack entries that went through the lanes
     st[4] = (u32)(t1 - t0);
     st[5] = (u32)(r1 - r0);
     limit_hit = false;
