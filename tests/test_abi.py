@@ -140,11 +140,11 @@ def test_dd_query_sizes_are_host_side_and_consistent():
     bhpkg.load()
     from nbody_barnes_hut_cuda_amd._lib import lib, BhDdSizes, BH_DD_PIECE_CAP
     sz = BhDdSizes()
-    n_cap, world, mig_cap, let_cap = 1_304_096, 8, 652_048, 2 + BH_DD_PIECE_CAP + 1_304_096
+    n_cap, world, mig_cap, let_cap = 1_304_096, 8, 652_048, 4 + BH_DD_PIECE_CAP + 1_304_096
     assert lib.bh_dd_query(n_cap, world, mig_cap, let_cap, C.byref(sz)) == 0
     assert sz.x2_bytes == 32 + 32 * mig_cap and sz.x3_bytes == 80 * (1 + BH_DD_PIECE_CAP)
     assert sz.x1_bytes == 4 * (8 + 4 * (2048 // world))  # 2048 position samples in the whole system
-    assert sz.let_min == 2 + BH_DD_PIECE_CAP and sz.let_cap == let_cap
+    assert sz.let_min == 4 + BH_DD_PIECE_CAP and sz.let_cap == let_cap  # header + 3 needs-row records + piece slots
     # pool = local tree + body digests | two top trees | world LET segments (+ read-ahead padding)
     assert sz.top_base >= 3 * n_cap and sz.seg_base > sz.top_base
     assert sz.pool_records >= sz.seg_base + world * let_cap
