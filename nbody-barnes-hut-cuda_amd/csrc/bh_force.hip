@@ -17,7 +17,8 @@
 //     masked off below it.  The set of lanes that still need a cell opened is the (EXEC-restricted) result of
 //     the compare; if it is non-empty the (child block, lane mask) pair is pushed on the wave's stack.  Per-lane
 //     results therefore equal the per-body recurrence of the CPU oracle (same interactions, fixed order);
-//   * the wave's stack lives in registers ACROSS LANES: entry j is held by lane j of four VGPRs
+//   * the wave's stack lives in registers ACROSS LANES: entry j is held by lane j of three VGPRs (block link, lane
+//     mask), the top entry in scalar registers
 //     (v_writelane / v_readlane) — no scratch, no LDS, no memory latency on push/pop.  64 entries cover every
 //     tree seen in practice; a wave that needs more redoes its walk with the generic loop's 192 entries
 //     (>= the 7*21+1 bound for 63-bit keys);
@@ -391,28 +392,34 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 //     chain (x - px, ... with the record in SGPRs) is all slow forms: 58 cycles per record.  Evaluating the
 //     two records of a digest pair (bh_internal.h: fields interleaved, so each field pair is an aligned SGPR
 //     pair) with packed instructions costs 37 cycles per record;
-//   * the entry's lane mask is loaded into EXEC once per child block, so inactive lanes need no take-mask and
-//     `s_andn2_b64 open, exec, accept` yields the open mask AND, in SCC, whether it is empty;
-//   * lanes that open a record must not take its monopole: only the path that pushed (16 % of the records)
+//   * the entry's lane mask is loaded into EXEC once per child block, so inactive lanes need no take-mask and the
+//     compare `v_cmp_ge thr2, d2` under that EXEC IS the open mask of the record; one `s_or_b64` + branch per
+//     pair tests both records (scalar instructions cost ~1.25 cycles beside other waves' vector issue);
+//   * lanes that open a record must not take its monopole: only the path that pushed (20 % of the pairs)
 //     runs the variant of the force half with the two v_cndmask;
 //   * a child block is fetched as up to 4 pairs (s_load_dwordx16 each, 64-byte aligned: blocks start at even
-//     records) BEFORE anything else, two loads if it has <= 4 children, and evaluated LAST PAIR FIRST by a
-//     computed jump (entry offsets in the lanes of a VGPR, indexed by the child count): no per-record count
-//     test, no loop counter.  A block of an odd number of children ends in a null record (gm 0, thr2 -1);
+//     records) BEFORE anything else, two loads if it has <= 4 children, and evaluated LAST PAIR FIRST from the
+//     entry a two-level branch tree on the child count selects: no per-record count test, no loop counter.  A
+//     block of an odd number of children ends in a null record (gm 0, thr2 -1: it can never open);
+//   * v_readlane / v_writelane cost ~5 cycles each in this loop: a stack entry is three dwords (the block LINK =
+//     byte offset | child count, written into the digest by the COM stage, and the 64-bit lane mask), and the top
+//     entry stays in scalar registers (BH_PUSH1);
 //   * stack overflow and "child count > 8" are recorded with one s_max each and judged once, after the walk
 //     (the caller then redoes the wave with the generic loop).
 //   * the pair chain is software-pipelined: the force half of pair p (8 VALU) is interleaved, instruction by
 //     instruction, with the MAC half of pair p-1 (10 VALU), so consecutive instructions of a wave are
 //     independent (a wave's DEPENDENT VALU instructions issue only every ~4+ cycles whatever the occupancy).
-// Per pair: 16 VALU + 2 x (s_andn2 + s_cbranch).  Per block: 5 v_readlane, <= 4 s_load, 11 SALU/branch.
-// Per push: 4 v_writelane + 5 SALU/branch.  v_readlane/v_writelane ignore EXEC.
-// Code:  PRO(q) = MAC(q)              entry of a block of 2q+1 or 2q+2 children (computed jump)
-//        SEG(q) = FORCE(q) || MAC(q-1)   q = 3..1;  SEG(0) = FORCE(0);  SEGm(q) = the same with the take masks
+// Per pair: 16 VALU + s_or_b64 + s_cbranch.  Per block: <= 4 s_load, ~13 SALU/branch, 3 v_readlane unless the
+// entry was still in scalar registers.  Per push: ~9 SALU/branch, 3 v_writelane for the entry it displaces from
+// the scalar registers.  v_readlane/v_writelane ignore EXEC.
+// Code:  PRO(q) = MAC(q)              entry of a block of 2q+1 or 2q+2 children
+//        SEG(q) = FORCE(q) || MAC(q-1)   q = 3..1;  SEG(0) = FORCE(0);  SEGm(q) = the same with the open masks
 //        ARMS(q)= pushes of pair q, then SEGm(q)
-// Fixed registers inside the block: s[36:99] record window (pair p at s[36+16p..]), s10-s35 state;
+// Fixed registers inside the block: s[36:99] record window (pair p at s[36+16p..]), s10-s35, s100, s101 state;
 // v[16:17] = (px,py), v[18:19] = (pz,-), v[20:21] = (eps2,eps2); pair sets (even / odd pairs) d = v[22:27] /
-// v[30:35], rinv = v[28:29] / v[36:37], accept masks s[18:19],s[14:15] / s[12:13],s[10:11]; v[38:39] d2,
-// v[40:41] f, v[42:47] six partial accumulators, v48-v51 cross-lane stack, v52 jump table.
+// v[30:35], rinv = v[28:29] / v[36:37], open masks s[18:19],s[14:15] / s[12:13],s[10:11]; v[38:39] d2,
+// v[40:41] f, v[42:47] six partial accumulators, v48 / v50 / v51 cross-lane stack (link, mask lo, mask hi),
+// s101 / s[22:23] its top entry.
 #define BH_S0 "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v28", "v29", "s[18:19]", "s[14:15]"
 #define BH_S1 "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v36", "v37", "s[12:13]", "s[10:11]"
 // MAC of the pair (X, Y, Z, THR0, THR1) into set (DX, DY, DZ, R, R0, R1, MA, MB)
