@@ -106,6 +106,8 @@ struct bh_dd_state {
   int* dstd;       // [world][n_cap] per destination: block offset of every exporting cell inside that segment
   int* dtot;       // [64] per destination: records of its blocks
   int* csum;       // [world][n_cap / 8192 + 1] chunk sums of the per-destination scan
+  int* mark_cnt;   // [2][rec_cap / 1024 + 3] exporting cells per dd_mark_kernel block, then their exclusive bases
+  u32* mark_done;  // bh_last_block counters of dd_mark_kernel
   u32* cls_done;   // bh_last_block counters of dd_classify_kernel
   u32* abs_done;   // ... of dd_absorb_flag_kernel
   int* arrive;     // [64] immigrants per rank of the current round (left at zero by the kernel)
@@ -654,17 +656,21 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
                                                       const float4* __restrict__ boxes,
                                                       const float4* __restrict__ rbox, int world,
                                                       const int* __restrict__ ddi, float eps2,
-                                                      int* __restrict__ w, unsigned* __restrict__ wmask) {
+                                                      int* __restrict__ w, unsigned* __restrict__ wmask,
+                                                      int* __restrict__ lpos, int* __restrict__ bcnt,
+                                                      int* __restrict__ bbase, u32* __restrict__ done) {
   __shared__ float4 sb[kMarkBoxes];
   __shared__ float4 srb[128];
   __shared__ float4 cxyz[kMarkChunk];  // candidate: com, threshold
   __shared__ int cidx[kMarkChunk];     // candidate: record index
   __shared__ int ccnt[kMarkChunk];     // candidate: child count
+  __shared__ unsigned char oflag[kMarkChunk];  // per-destination mode: record of this block exports its children
   __shared__ int ncand;
   const int E = min(info->n_entries, rec_cap);
   const int NB = ddi[1];
   const int e0 = blockIdx.x * kMarkChunk;
   if (threadIdx.x == 0) ncand = 0;
+  for (int i = threadIdx.x; i < kMarkChunk; i += 256) oflag[i] = 0;
   for (int i = threadIdx.x; i < 2 * world; i += 256) srb[i] = rbox[i];
   for (int i = threadIdx.x; i < min(NB, kMarkBoxes); i += 256) sb[i] = boxes[i];
   __syncthreads();
@@ -716,8 +722,68 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
       }
     }
     w[cidx[c]] = open ? ccnt[c] : 0;
-    if (wmask) wmask[cidx[c]] = mask;
+    if (wmask) {
+      wmask[cidx[c]] = mask;
+      if (open && ccnt[c] > 0) oflag[cidx[c] - e0] = 1;
+    }
   }
+  if (!wmask) return;
+  // per-destination mode: the exporting cells are compacted here (record order inside the block, blocks in order:
+  // deterministic) instead of by a separate flag scan over the whole record pool.  lpos[e] = position inside the
+  // block; the block that finishes last turns the block counts into bases (bbase, bbase[blocks] = list length);
+  // dd_let_list_kernel adds them up.
+  __syncthreads();
+  __shared__ int wsum2[4];
+  __shared__ int s_last;
+  {
+    const int t4 = 4 * (int)threadIdx.x;
+    const int f0 = oflag[t4], f1 = oflag[t4 + 1], f2 = oflag[t4 + 2], f3 = oflag[t4 + 3];
+    const int s4 = f0 + f1 + f2 + f3;
+    int inc = s4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int u = __shfl_up(inc, dd, 64);
+      if (lane >= dd) inc += u;
+    }
+    if (lane == 63) wsum2[wv] = inc;
+    __syncthreads();
+    int pre = inc - s4;
+    for (int k = 0; k < wv; k++) pre += wsum2[k];
+    if (f0) lpos[e0 + t4] = pre;
+    if (f1) lpos[e0 + t4 + 1] = pre + f0;
+    if (f2) lpos[e0 + t4 + 2] = pre + f0 + f1;
+    if (f3) lpos[e0 + t4 + 3] = pre + f0 + f1 + f2;
+  }
+  if (threadIdx.x == 0) {
+    bh_publish_i32(bcnt + blockIdx.x, wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3]);
+    bh_published();
+    s_last = bh_last_block(done, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __shared__ int carry2;
+  int* part = cidx;  // (the candidate arrays are free now) 256 entries
+  if (threadIdx.x == 0) carry2 = 0;
+  __syncthreads();
+  const int nb = (int)gridDim.x;
+  for (int c0 = 0; c0 < nb; c0 += 256) {
+    const int b = c0 + (int)threadIdx.x;
+    const int v = b < nb ? bh_collect_i32(bcnt + b) : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int dd = 1; dd < 256; dd <<= 1) {
+      const int u = (int)threadIdx.x >= dd ? part[threadIdx.x - dd] : 0;
+      __syncthreads();
+      part[threadIdx.x] += u;
+      __syncthreads();
+    }
+    if (b < nb) bbase[b] = carry2 + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry2 += part[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bbase[nb] = carry2;
 }
 
 __device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restrict__ w,
@@ -791,12 +857,15 @@ __global__ __launch_bounds__(256) void dd_export_kernel(const bh_frec* __restric
 // all-gather put it, so the top tree, the validation and the walk are unchanged.
 __global__ __launch_bounds__(256) void dd_let_list_kernel(const int* __restrict__ w,
                                                           const unsigned* __restrict__ wmask,
-                                                          const int* __restrict__ lpos, int rec_cap, int lcap,
+                                                          int* __restrict__ lpos, const int* __restrict__ bbase,
+                                                          int nblocks, int rec_cap, int lcap,
                                                           int* __restrict__ list_e, int* __restrict__ list_w,
                                                           unsigned* __restrict__ list_m) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) lpos[rec_cap] = bbase[nblocks];  // list length (read by the kernels that follow)
   if (e >= rec_cap || w[e] <= 0) return;
-  const int i = lpos[e];
+  const int i = bbase[e / kMarkChunk] + lpos[e];  // block base + position inside dd_mark_kernel's block
+  lpos[e] = i;                                    // from here on: the cell's position in the list
   if (i >= lcap) return;
   list_e[i] = e;
   list_w[i] = (w[e] + 1) & ~1;  // blocks start at even records
@@ -1377,7 +1446,7 @@ void bh_dd_free(bh_ctx* c) {
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
                   d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2,
                   d->cls_done, d->abs_done, d->arrive, c->dd_minmax, d->wmask, d->list_e, d->list_w, d->list_m, d->dstd,
-                  d->dtot, d->csum};
+                  d->dtot, d->csum, d->mark_cnt, d->mark_done};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (d->host) (void)hipHostFree(d->host);
@@ -1484,6 +1553,12 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->dstd, ((size_t)world * n_cap + 64) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->dtot, 64 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->csum, ((size_t)world * (n_cap / 8192 + 2) + 64) * 4) == hipSuccess;
+  {
+    const size_t mb = (size_t)c->rec_cap / kMarkChunk + 3;
+    ok = ok && hipMalloc((void**)&d->mark_cnt, 2 * mb * 4 + 256) == hipSuccess;
+    ok = ok && hipMalloc((void**)&d->mark_done, (mb / 32 + 8) * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMemset(d->mark_done, 0, (mb / 32 + 8) * sizeof(u32)) == hipSuccess;
+  }
   d->let_mode = 0;
   ok = ok && hipMalloc((void**)&c->dd_minmax, 8 * sizeof(float)) == hipSuccess;
   c->dd_minmax_ok = false;
@@ -1686,15 +1761,16 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
   dd_boxes_kernel<<<d->world, 256, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, c->bounds,
                                                    d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;
-  dd_mark_kernel<<<(c->rec_cap + kMarkChunk) / kMarkChunk, 256, 0, c->stream>>>(
+  const int mark_blocks = (c->rec_cap + kMarkChunk) / kMarkChunk;
+  dd_mark_kernel<<<mark_blocks, 256, 0, c->stream>>>(
       c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w,
-      d->let_mode == 1 ? d->wmask : nullptr);
+      d->let_mode == 1 ? d->wmask : nullptr, d->dst, d->mark_cnt, d->mark_cnt + mark_blocks + 1, d->mark_done);
   BH_HIP(c, hipGetLastError());
   if (d->let_mode == 1) {  // `send_x4` holds world segments of `stride` records, exchanged with an all-to-all
     const int n_cap = (c->rec_cap - 8) / 3;
-    BH_HIP(c, bhk_scan_i32_flag(c, d->w, d->dst, c->rec_cap));  // dst = lpos: list position of every exporting cell
-    dd_let_list_kernel<<<blocks, 256, 0, c->stream>>>(d->w, d->wmask, d->dst, c->rec_cap, n_cap, d->list_e, d->list_w,
-                                                      d->list_m);
+    // dst = lpos: list position of every exporting cell (dd_mark_kernel compacted them block by block)
+    dd_let_list_kernel<<<blocks, 256, 0, c->stream>>>(d->w, d->wmask, d->dst, d->mark_cnt + mark_blocks + 1, mark_blocks,
+                                                      c->rec_cap, n_cap, d->list_e, d->list_w, d->list_m);
     {
       const int nch = (n_cap + kLetChunk - 1) / kLetChunk;
       const dim3 grid((unsigned)nch, (unsigned)d->world);
