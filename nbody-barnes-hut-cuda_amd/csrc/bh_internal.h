@@ -307,7 +307,6 @@ void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 // device-wide scans (bh_scan.hip)
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);
 hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out /* n+1 */, int n);  // of (in[i]+1)&~1
-hipError_t bhk_scan_i32_flag(bh_ctx* c, const int* in, int* out /* n+1 */, int n);  // of in[i] > 0
 hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n, bool side);
 hipError_t bhk_com_records(bh_ctx* c, bool canonical);  // second half of bhk_com: records from the prefix sums
 size_t bhk_scan_tmp_bytes(int n);

@@ -64,10 +64,6 @@ struct LoadI32Even {  // child counts rounded up to even: child blocks start on 
   const int* p;
   __device__ __forceinline__ int operator()(int i) const { return (p[i] + 1) & ~1; }
 };
-struct LoadI32Flag {  // 1 where the entry is positive (compaction of the exporting cells, bh_dd.hip)
-  const int* p;
-  __device__ __forceinline__ int operator()(int i) const { return p[i] > 0 ? 1 : 0; }
-};
 struct LoadPM {  // body i -> (m, m x, m y, m z) in fp64; the products of two fp32 are exact in fp64
   const float4* posm;
   __device__ __forceinline__ bh_d4 operator()(int i) const {
@@ -222,10 +218,6 @@ hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out, int n, const int* n_
 
 hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out, int n) {
   return run_scan<OpI32>(c->stream, c->scan_tmp, c->scan_cnt_off, LoadI32Even{in}, out, n, nullptr);
-}
-
-hipError_t bhk_scan_i32_flag(bh_ctx* c, const int* in, int* out, int n) {
-  return run_scan<OpI32>(c->stream, c->scan_tmp, c->scan_cnt_off, LoadI32Flag{in}, out, n, nullptr);
 }
 
 // side = true: run on the context's side stream with its own scratch (bh_step overlaps this scan,
