@@ -475,14 +475,28 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
       keys[i] = k[r];
     }
   }
-  // splitter t+1 = key of the body stored at position (t+1) n / nb; unused slots sort to the end
-  u64 sk = ~0ull;
-  if (tid < nb - 1) {
-    const float4 q = posm[(int)(((u64)(tid + 1) * (u64)n) / (u64)nb)];
-    sk = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
-  }
+  // splitter t+1 = the MEDIAN of the keys of the three bodies stored around position (t+1) n / nb; unused slots
+  // sort to the end.  (One body per splitter: a sample body that crossed a high-level cell plane last step — about
+  // one in seventy does — takes its bucket boundary far away with it, and the two buckets beside it came out at
+  // 0.25x and 2x the average: 938 / 3906 / 7791 keys at 1M, and the largest bucket is local_sort_kernel's length.)
+  __shared__ u64 raw3[3][256];
   __shared__ u32 rnk[256];
+  if (tid < 768) {
+    const int t = tid & 255, j = tid >> 8;
+    u64 sk3 = ~0ull;
+    if (t < nb - 1) {
+      const int pos = (int)(((u64)(t + 1) * (u64)n) / (u64)nb) + j - 1;  // n / nb >= 2: inside [0, n)
+      const float4 q = posm[min(max(pos, 0), n - 1)];
+      sk3 = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
+    }
+    raw3[j][t] = sk3;
+  }
+  __syncthreads();
+  u64 sk = ~0ull;
   if (tid < 256) {
+    const u64 a = raw3[0][tid], b = raw3[1][tid], c = raw3[2][tid];
+    const u64 lo = a < b ? a : b, hi = a < b ? b : a;
+    sk = c < lo ? lo : (c > hi ? hi : c);
     raw[tid] = sk;
     cnt[tid] = 0;
     rnk[tid] = 0;

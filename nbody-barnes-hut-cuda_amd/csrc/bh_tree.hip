@@ -350,11 +350,18 @@ __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int
 // 8 lanes per cell (key_lower_bound above).
 #ifdef BH_TREE_TRACE
 // design-study instrumentation (tools/tree_trace.py): 100 MHz wall-clock stamps per block
-__device__ unsigned long long g_tree_trace[2][8192][8];
+__device__ unsigned long long g_tree_trace[2][8192][12];
 #define TT_STAMP(kern, k) \
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_tree_trace[kern][blockIdx.x][k] = wall_clock64();
+// after everything this thread has loaded so far has arrived
+#define TT_STAMPW(kern, k)                                                    \
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {                                \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
+    g_tree_trace[kern][blockIdx.x][k] = wall_clock64();                       \
+  }
 #else
 #define TT_STAMP(kern, k)
+#define TT_STAMPW(kern, k)
 #endif
 constexpr int kPairTile = 1024;            // pairs per block (template parameter TILE: 1024, or 256 for small n)
 constexpr int kHalo = 1024;                // window positions either side of the tile = the largest "narrow" cell
@@ -599,6 +606,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       for (int s = threadIdx.x; s < ns; s += 256) s_samp[s] = ksamp[s];
     }
     __syncthreads();
+    TT_STAMP(0, 8)
     for (int idx = threadIdx.x >> 4; idx < nw; idx += 16) {
       const int p = wide[idx];
       const int j = base + p;
@@ -606,13 +614,18 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       const int sh = 3 * (B - L), dsh = 3 * (B - 1 - L);
       const u64 pj = key_prefix(k[j], sh);
       const u64 kjm = k[j - 1];
+      TT_STAMPW(0, 9)
       const int l = (sub <= 8) ? key_lower_bound(k, n, s_samp, ns, ss, dsh, (pj << 3) + (u64)sub) : 0;
+      TT_STAMPW(0, 10)
       const int a = __shfl(l, 0, 16), b = __shfl(l, 8, 16);
       const int nxt = __shfl_down(l, 1, 16);
       const u64 bal = __ballot(sub < 8 && nxt > l);
       int nc = 0;
-      // j is the cell's FIRST child boundary iff key j-1 lies in the cell's first non-empty octant
-      if (((kjm >> dsh) & 7ull) == ((k[a] >> dsh) & 7ull) && b - a > cap)
+      // j is the cell's FIRST child boundary iff key j-1 lies in the cell's first non-empty octant, i.e. iff no key
+      // of the cell has a smaller digit than key j-1's g: lower bound of (pj, g) == a (lane g's result; reading
+      // k[a] instead put one more dependent global round trip, ~2.5 us, on the slowest blocks' chain)
+      const int lg = __shfl(l, (int)((kjm >> dsh) & 7ull), 16);
+      if (lg == a && b - a > cap)
         nc = __popcll((bal >> (lane & ~15)) & 0xffull);
       if (sub == 0) {
         pn[j] = nc;
@@ -871,20 +884,33 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   constexpr int kR = TILE / 256;
   int nc_[kR], e_[kR], a_[kR], b_[kR], jp_[kR], ord_[kR];
   int jl_[kR], ordl_[kR], cntl_[kR];  // the leaf starting at body j: parent's pair, ordinal, bodies
+  {
+    // all loads first, unconditionally (clamped index), then the arithmetic: with the loads inside `if (j < n)` and
+    // the sum BH_CB right behind them the compiler waited for each pair's loads before issuing the next pair's —
+    // four dependent round trips, 11 of this kernel's 34 us per block
+    int tb_[kR], cb_[kR];
 #pragma unroll
-  for (int r = 0; r < kR; r++) {
-    const int j = t0 + r * 256 + (int)threadIdx.x;
-    nc_[r] = 0;
-    e_[r] = a_[r] = b_[r] = 0;
-    jp_[r] = jl_[r] = -1;
-    ord_[r] = ordl_[r] = cntl_[r] = 0;
-    if (j > 0 && j < n) {
-      nc_[r] = pn[j];
-      e_[r] = BH_BLOCK0 + BH_CB(j);
-      a_[r] = pa[j];  // (defined only where nc > 0; unused otherwise)
-      b_[r] = pb[j];
+    for (int r = 0; r < kR; r++) {
+      const int jc = min(t0 + r * 256 + (int)threadIdx.x, n - 1);
+      nc_[r] = pn[jc];
+      cb_[r] = cb[jc];
+      tb_[r] = tpre[jc >> tshift];
+      a_[r] = pa[jc];  // (defined only where nc > 0; unused otherwise)
+      b_[r] = pb[jc];
+    }
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+      const int j = t0 + r * 256 + (int)threadIdx.x;
+      const bool in = j > 0 && j < n;
+      nc_[r] = in ? nc_[r] : 0;
+      e_[r] = in ? BH_BLOCK0 + tb_[r] + cb_[r] : 0;
+      a_[r] = in ? a_[r] : 0;
+      b_[r] = in ? b_[r] : 0;
+      jp_[r] = jl_[r] = -1;
+      ord_[r] = ordl_[r] = cntl_[r] = 0;
     }
   }
+  TT_STAMPW(1, 8)
 #pragma unroll
   for (int r = 0; r < kR; r++) {
     const int p = kHalo + r * 256 + (int)threadIdx.x;
@@ -963,12 +989,25 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       }
     }
   }
+  TT_STAMPW(1, 9)
   int ep_[kR], el_[kR];
+  {
+    int pb_[kR], pc_[kR], lb_[kR], lc_[kR];  // (loads first, see above)
 #pragma unroll
-  for (int r = 0; r < kR; r++) {
-    ep_[r] = (jp_[r] >= 0) ? BH_BLOCK0 + BH_CB(jp_[r]) + ord_[r] : rec_cap;
-    el_[r] = (jl_[r] >= 0) ? BH_BLOCK0 + BH_CB(jl_[r]) + ordl_[r] : rec_cap;
+    for (int r = 0; r < kR; r++) {
+      const int jp = max(jp_[r], 0), jl = max(jl_[r], 0);
+      pb_[r] = tpre[jp >> tshift];
+      pc_[r] = cb[jp];
+      lb_[r] = tpre[jl >> tshift];
+      lc_[r] = cb[jl];
+    }
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+      ep_[r] = (jp_[r] >= 0) ? BH_BLOCK0 + pb_[r] + pc_[r] + ord_[r] : rec_cap;
+      el_[r] = (jl_[r] >= 0) ? BH_BLOCK0 + lb_[r] + lc_[r] + ordl_[r] : rec_cap;
+    }
   }
+  TT_STAMPW(1, 10)
 #pragma unroll
   for (int r = 0; r < kR; r++) {
     const int p = kHalo + r * 256 + (int)threadIdx.x;
@@ -1015,8 +1054,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
       const int L = dl[p];
       const int a = pa[j], b = pb[j];
       const int dsh = 3 * (B - 1 - L);
-      // lower bound of digit >= sub inside the cell = first key with (L+1)-digit prefix >= pj*8+sub
-      const u64 pj8 = (k[a] >> dsh) & ~7ull;
+      // lower bound of digit >= sub inside the cell = first key with (L+1)-digit prefix >= pj*8+sub.  The cell's
+      // L-digit prefix is read off key j (a key of the cell whose address does not wait for pa[j])
+      const u64 pj8 = (k[j] >> dsh) & ~7ull;
       const int l = (sub == 0) ? a : key_lower_bound(k, n, s_samp, ns, ss, dsh, pj8 | (u64)sub);
       int nxt = __shfl_down(l, 1, 8);
       if (sub == 7) nxt = b;
