@@ -56,9 +56,16 @@ __device__ unsigned long long g_os_trace[8][4096][8];
 __device__ unsigned long long g_ls_trace[256][16];
 #define LS_STAMP(k, v) \
   if (threadIdx.x == 0) g_ls_trace[blockIdx.x][k] = (v);
+__device__ unsigned long long g_ks_trace[1024][8];  // keys_split_kernel (tools/ks_trace.py)
+#define KS_STAMP(k)                                             \
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    g_ks_trace[blockIdx.x][k] = wall_clock64();                 \
+  }
 #else
 #define OS_STAMP(k)
 #define LS_STAMP(k, v)
+#define KS_STAMP(k)
 #endif
 
 __device__ __forceinline__ u64 pack_granule(u32 tag, u32 state, u32 value) {
@@ -462,6 +469,7 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
   const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
   const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
   const int tid = threadIdx.x, lane = tid & 63;
+  KS_STAMP(0)
   // the tile's own keys first (their loads overlap the splitter work)
   const int base = blockIdx.x * TILE;
   u64 k[TILE / kKsThreads];
@@ -475,6 +483,7 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
       keys[i] = k[r];
     }
   }
+  KS_STAMP(1)
   // splitter t+1 = the MEDIAN of the keys of the three bodies stored around position (t+1) n / nb; unused slots
   // sort to the end.  (One body per splitter: a sample body that crossed a high-level cell plane last step — about
   // one in seventy does — takes its bucket boundary far away with it, and the two buckets beside it came out at
@@ -502,6 +511,7 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
     rnk[tid] = 0;
   }
   __syncthreads();
+  KS_STAMP(2)
   {  // rank sort of the <= 255 splitters, four threads per splitter (64 comparisons each: this serial loop is
      // most of the kernel at small n, where the grid is a handful of blocks)
     const int t = tid & 255, q = tid >> 8;
@@ -517,6 +527,7 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
   if (tid < 256) sp[rnk[tid]] = sk;
   __syncthreads();
   if (blockIdx.x == 0 && tid < 256) splitters[tid] = sp[tid];
+  KS_STAMP(3)
 #pragma unroll
   for (int r = 0; r < TILE / kKsThreads; r++) {
     const int i = base + r * kKsThreads + tid;
@@ -533,7 +544,9 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
     }
   }
   __syncthreads();
+  KS_STAMP(4)
   if (tid < 256 && cnt[tid]) atomicAdd(&bcount[tid], cnt[tid]);
+  KS_STAMP(5)
 }
 
 // exclusive scan of one value per thread over the first 256 threads of the block (4 waves); all threads call
@@ -818,6 +831,9 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
 #ifdef BH_OS_TRACE
 extern "C" int bh_debug_os_trace(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_trace), sizeof(g_os_trace));
+}
+extern "C" int bh_debug_ks_trace(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ks_trace), sizeof(g_ks_trace));
 }
 extern "C" int bh_debug_ls_trace(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_trace), sizeof(g_ls_trace));
