@@ -440,8 +440,10 @@ __global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ pe
 //      positions of the (nearly sorted) body array, so the buckets come out nearly equal — and counts the
 //      bucket sizes;
 //   2. ONE partition pass (onesweep_pass_kernel<true>) moves every key to its bucket, stably;
-//   3. local_sort_kernel: one workgroup per bucket sorts it entirely in LDS (stable LSD radix over the digit
-//      positions that actually vary inside the bucket), writes the sorted keys and gathers the bodies.
+//   3. local_sort_kernel: one workgroup per bucket sorts it entirely in LDS (stable LSD radix passes over the top
+//      32 of the bit positions that vary inside the bucket, runs of keys that agree on those ordered by neighbour
+//      exchanges, the full set of passes if that does not finish: ls_sort_in_lds), writes the sorted keys and
+//      gathers the bodies.
 // Three kernels instead of eleven; result bit-identical to the radix sort (both are stable).  A bucket that does
 // not fit LDS (order drifted a lot, or forced on random input) is sorted by its workgroup through global
 // memory: slow, correct.  Not used for the first sort after an upload (no order to exploit).
@@ -451,6 +453,9 @@ constexpr int kLsWaves = kLsThreads / 64;
 #define BH_LS_CAP 12288  // 144 KB of the 160 KB LDS for keys + values
 #endif
 constexpr int kLsCap = BH_LS_CAP;  // keys per bucket sorted in LDS
+#ifndef BH_LS_WINDOW
+#define BH_LS_WINDOW 32  // key bits (below the highest one that varies in the bucket) sorted by radix passes
+#endif
 constexpr int kLsItems = kLsCap / kLsThreads;
 
 constexpr int kKsThreads = 1024;  // x 4 keys: 4 waves per SIMD hide the LDS round trips of the bucket lookups
@@ -611,16 +616,78 @@ __device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __re
     LS_STAMP(1, wall_clock64())
     LS_STAMP(5, diff)
 
+    // Which passes.  The keys of a bucket differ in ~55 bit positions (seven 8-bit passes), but ~4000 keys are
+    // almost always told apart by the TOP 32 of them (24 for ~512 keys): first four passes over that window only, then one look at
+    // the neighbours — if no two adjacent keys agree on the window, the order is final (the lower bits cannot
+    // matter), else (coincident or extremely close bodies) the full set of passes runs from the lowest varying
+    // byte, which is correct from any starting arrangement and keeps equal keys in their original order because
+    // every pass is stable.  11.4 us less per sort at 1M (3 passes of 3.8 us).
+    const int hb = (diff == 0ull) ? -1 : 63 - __clzll((long long)diff);  // highest varying bit
+    const int window = (size <= 1024) ? BH_LS_WINDOW - 8 : BH_LS_WINDOW;  // measured: 24 bits for the ~512-key buckets of small systems
+    const int lowbit = (hb > window - 1) ? hb - (window - 1) : 0;
+    int phase = (lowbit > 0) ? 0 : 1;  // 0: the window [lowbit, hb]; 1: every varying byte from bit 0
+    int shift = lowbit;
+    [[maybe_unused]] int npass = 0;
 #pragma unroll 1
-    for (int p = 0; p < 8; p++) {
-      const int shift = 8 * p;
-      if (((diff >> shift) & 255ull) == 0ull) continue;  // block-uniform
+    for (;;) {
+      if (phase == 1)
+        while (shift <= hb && ((diff >> shift) & 255ull) == 0ull) shift += 8;  // block-uniform
+      if (shift > hb) {
+        if (phase == 1) break;
+        int tie = 0;  // skey / key[] hold the bucket ordered by the window
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+          if (r < nit) {
+            const int idx = wbase + r * 64 + lane;
+            if (idx > 0 && idx < size) tie |= (((key[r] ^ skey[idx - 1]) >> lowbit) == 0ull) ? 1 : 0;
+          }
+        }
+        if (!__syncthreads_or(tie)) break;
+        // Some neighbours agree on the whole window (a bucket that straddles a high-level cell plane has a high
+        // top bit, and 32 bits below it do not reach the leaves of a dense region).  Their runs are short: order
+        // each run by the full key with odd-even exchanges of neighbours inside a run (strict >: equal keys keep
+        // their order).  A run longer than the round limit allows falls through to the full set of passes.
+        bool done = false;
+#pragma unroll 1
+        for (int round = 0; round < 24 && !done; round++) {
+          int swapped = 0;
+#pragma unroll 1
+          for (int par = 0; par < 2; par++) {
+            for (int i = 2 * tid + par; i + 1 < size; i += 2 * kLsThreads) {
+              const u64 ka = skey[i], kb = skey[i + 1];
+              if (((ka ^ kb) >> lowbit) == 0ull && ka > kb) {
+                const u32 va = sval[i], vb = sval[i + 1];
+                skey[i] = kb; skey[i + 1] = ka;
+                sval[i] = vb; sval[i + 1] = va;
+                swapped = 1;
+              }
+            }
+            __syncthreads();
+          }
+          done = !__syncthreads_or(swapped);
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+          if (r < nit) {
+            const int idx = wbase + r * 64 + lane;
+            if (idx < size) {
+              key[r] = skey[idx];
+              val[r] = sval[idx];
+            }
+          }
+        }
+        if (done) break;
+        phase = 1;
+        shift = 0;
+        continue;
+      }
 #ifdef BH_OS_TRACE
-      const bool tr = (p == 1);
+      const bool tr = (npass == 1);
 #define LS_PSTAMP(k) if (tr) { LS_STAMP(k, wall_clock64()) }
 #else
 #define LS_PSTAMP(k)
 #endif
+      npass++;
       LS_PSTAMP(8)
       for (int q = tid; q < kLsWaves * 256; q += kLsThreads) (&wcnt[0][0])[q] = 0;
       __syncthreads();
@@ -675,8 +742,10 @@ __device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __re
       }
       LS_PSTAMP(13)
       // (the barrier at the top of the next pass, or none needed after the last, orders these reads)
+      shift += 8;
     }
     LS_STAMP(2, wall_clock64())
+    LS_STAMP(6, (unsigned long long)npass)
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
       if (r < nit) {

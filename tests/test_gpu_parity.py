@@ -114,6 +114,51 @@ def test_splitter_sort_bucket_paths(pkg, orc, n, shuffle):
     e.close()
 
 
+@pytest.mark.parametrize("n,presorted", [(30000, False), (30000, True), (400000, True)])
+def test_splitter_sort_close_clusters(pkg, orc, n, presorted):
+    """the in-LDS bucket sort runs its radix passes over the TOP 32 (24) varying key bits only and orders the runs
+    of keys that agree on them by neighbour exchanges; a run too long for that takes the full set of passes.
+    Input made for all three paths: scattered bodies (no run), 300 pairs and 40 clumps of 5-30 bodies 1e-5 apart
+    (short runs), four clumps of 700 bodies 1e-4 ... 0.5 wide (runs of hundreds in random order: fall through), exact
+    duplicates (equal keys keep their original order).  == the oracle's stable sort, exact permutation."""
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-1000.0, 1000.0, (n, 3))
+    k = 1000
+    for _ in range(300):  # pairs
+        x[k + 1] = x[k] + rng.normal(0, 1e-5, 3)
+        k += 2
+    for _ in range(40):   # small clumps
+        m = int(rng.integers(5, 31))
+        x[k:k + m] = x[k] + rng.normal(0, 1e-5, (m, 3))
+        k += m
+    for wdt in (0.5, 0.1, 0.02, 1e-4):  # big clumps, wider than a finest cell: hundreds of distinct keys per run
+        x[k:k + 700] = x[k] + rng.uniform(-wdt, wdt, (700, 3))
+        k += 700
+    x[k:k + 50] = x[k]  # coincident bodies
+    x = x.astype(np.float32)
+    z = np.zeros(n, np.float32)
+    ic = (x[:, 0].copy(), x[:, 1].copy(), x[:, 2].copy(), z, z.copy(), z.copy(), np.ones(n, np.float32))
+    b = orc.bbox(*ic[:3])
+    kc = key_curve_of(pkg.default_params())
+    keys = orc.keys(*ic[:3], b, 63, kc)
+    if presorted:  # bodies in key order except for a sprinkling of swaps, as a step leaves them
+        _, p0 = orc.sort(keys)
+        sw = rng.integers(0, n - 40, 200)
+        p0[sw], p0[sw + 37] = p0[sw + 37].copy(), p0[sw].copy()
+        ic = tuple(a[p0] for a in ic)
+        keys = orc.keys(*ic[:3], b, 63, kc)
+    e = _engine(pkg, ic, sort_variant=3)
+    e.bbox(); e.morton(); e.sort()
+    sk, perm = orc.sort(keys)
+    assert np.array_equal(e.download_keys(), sk)
+    assert np.array_equal(e.download_order(), perm)
+    st = e.stats()
+    assert st.status_flags == 0
+    if presorted:
+        assert st.sort_slow_buckets == 0  # every bucket took the in-LDS path under test
+    e.close()
+
+
 def test_splitter_sort_gives_way_when_buckets_overflow(pkg, orc):
     """many identical keys (120,000 coincident bodies among 200,000) land in ONE bucket of the splitter sort, far
     beyond the 8,192 keys its workgroup sorts in LDS: that bucket goes through the slow global-memory path (still

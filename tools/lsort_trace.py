@@ -14,7 +14,7 @@ buf = np.zeros((256, 16), dtype=np.uint64)
 assert lib.bh_debug_ls_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 t = buf[:, :4].astype(np.int64)
 size = buf[:, 4].astype(np.int64)
-npass = np.array([sum(1 for p in range(8) if (int(d) >> (8 * p)) & 255) for d in buf[:, 5]])
+npass = buf[:, 6].astype(np.int64)  # passes run (4 over the top window; + the full set after a tie)
 ok = size > 0
 t0 = t[ok, 0].min()
 us = (t[ok] - t0) / 100.0
