@@ -14,6 +14,8 @@ if mode == "compare":
     n, steps = int(sys.argv[2]), int(sys.argv[3])
     every = int(sys.argv[4]) if len(sys.argv) > 4 else 50
     ic = pkg.plummer(n, seed=23)
+    if os.environ.get("BH_SOAK_IC") == "cold":  # the same bodies at rest: they fall into a dense core (close pairs,
+        ic = ic[:3] + tuple(np.zeros_like(v) for v in ic[3:6]) + ic[6:]  # equal keys, deep trees, big cube changes)
     a = pkg.Engine(n)
     b = pkg.Engine(n, sort_variant=2)
     a.upload(*ic); b.upload(*ic)
