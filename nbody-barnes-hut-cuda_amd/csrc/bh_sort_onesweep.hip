@@ -617,21 +617,59 @@ __device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __re
     LS_STAMP(5, diff)
 
     // Which passes.  The keys of a bucket differ in ~55 bit positions (seven 8-bit passes), but ~4000 keys are
-    // almost always told apart by the TOP 32 of them (24 for ~512 keys): first four passes over that window only, then one look at
-    // the neighbours — if no two adjacent keys agree on the window, the order is final (the lower bits cannot
-    // matter), else (coincident or extremely close bodies) the full set of passes runs from the lowest varying
-    // byte, which is correct from any starting arrangement and keeps equal keys in their original order because
-    // every pass is stable.  11.4 us less per sort at 1M (3 passes of 3.8 us).
+    // almost always told apart by a WINDOW of the top 32 of them: passes over the window only (4 instead of 7), then
+    // one look at the neighbours — if no two adjacent keys agree on the window the order is final (the lower bits
+    // cannot matter); runs of keys that do agree are ordered by neighbour exchanges; if those do not finish, the full
+    // set of passes runs from the lowest varying byte, which is correct from any starting arrangement and keeps equal
+    // keys in their original order because every pass is stable.  10 us less per sort at 1M.
     const int hb = (diff == 0ull) ? -1 : 63 - __clzll((long long)diff);  // highest varying bit
-    const int window = (size <= 1024) ? BH_LS_WINDOW - 8 : BH_LS_WINDOW;  // measured: 24 bits for the ~512-key buckets of small systems
-    const int lowbit = (hb > window - 1) ? hb - (window - 1) : 0;
+    // How wide the window has to be is read off the INPUT: the bucket arrives in the previous step's order, so its
+    // adjacent keys are (nearly) the adjacent keys of the result, and a pair ties on a window exactly if its two keys
+    // first differ below it.  Count, for three window widths, the adjacent input pairs that would tie; take the
+    // narrowest window that leaves at most one pair in 128 tied (a few short runs for the exchanges below), none if
+    // even the widest leaves more (a thin disc after some hundred steps, many coincident bodies): then the full
+    // set of passes runs at once and no window pass is wasted.
+    const int w0 = (size <= 1024) ? BH_LS_WINDOW - 8 : BH_LS_WINDOW;  // measured: 24 bits do for ~512-key buckets
+    int lowbit = 0;
+    if (hb >= w0) {  // block-uniform
+      int c[3] = {0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < ITEMS; r++) {
+        if (r < nit) {
+          const int idx = wbase + r * 64 + lane;
+          const u64 nx = __shfl_down(key[r], 1, 64);
+          const bool pair = lane < 63 && idx + 1 < size;
+          const u64 x = key[r] ^ nx;
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            const int lb = hb - (w0 + 8 * t) + 1;
+            c[t] += __popcll(__ballot(pair && lb > 0 && (x >> max(lb, 0)) == 0ull));
+          }
+        }
+      }
+      if (tid < 3) toff[tid] = 0;
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+          if (c[t]) atomicAdd(&toff[t], (u32)c[t]);
+      }
+      __syncthreads();
+      const u32 few = (u32)(size >> 7);
+#pragma unroll
+      for (int t = 2; t >= 0; t--) {
+        const int lb = hb - (w0 + 8 * t) + 1;
+        if (lb >= 8 && toff[t] <= few) lowbit = lb;  // the narrowest acceptable window wins (t = 0 last)
+      }
+      __syncthreads();  // toff is a scratch of the passes
+    }
     int phase = (lowbit > 0) ? 0 : 1;  // 0: the window [lowbit, hb]; 1: every varying byte from bit 0
+    LS_STAMP(7, 0ull)
     int shift = lowbit;
     [[maybe_unused]] int npass = 0;
 #pragma unroll 1
     for (;;) {
-      if (phase == 1)
-        while (shift <= hb && ((diff >> shift) & 255ull) == 0ull) shift += 8;  // block-uniform
+      while (shift <= hb && ((diff >> shift) & 255ull) == 0ull) shift += 8;  // a digit nobody differs in: block-uniform
       if (shift > hb) {
         if (phase == 1) break;
         int tie = 0;  // skey / key[] hold the bucket ordered by the window
@@ -642,7 +680,10 @@ __device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __re
             if (idx > 0 && idx < size) tie |= (((key[r] ^ skey[idx - 1]) >> lowbit) == 0ull) ? 1 : 0;
           }
         }
-        if (!__syncthreads_or(tie)) break;
+        if (!__syncthreads_or(tie)) {
+          LS_STAMP(7, 1ull)
+          break;
+        }
         // Some neighbours agree on the whole window (a bucket that straddles a high-level cell plane has a high
         // top bit, and 32 bits below it do not reach the leaves of a dense region).  Their runs are short: order
         // each run by the full key with odd-even exchanges of neighbours inside a run (strict >: equal keys keep
@@ -676,6 +717,7 @@ __device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __re
             }
           }
         }
+        LS_STAMP(7, done ? 2ull : 3ull)
         if (done) break;
         phase = 1;
         shift = 0;

@@ -116,11 +116,13 @@ def test_splitter_sort_bucket_paths(pkg, orc, n, shuffle):
 
 @pytest.mark.parametrize("n,presorted", [(30000, False), (30000, True), (400000, True)])
 def test_splitter_sort_close_clusters(pkg, orc, n, presorted):
-    """the in-LDS bucket sort runs its radix passes over the TOP 32 (24) varying key bits only and orders the runs
-    of keys that agree on them by neighbour exchanges; a run too long for that takes the full set of passes.
-    Input made for all three paths: scattered bodies (no run), 300 pairs and 40 clumps of 5-30 bodies 1e-5 apart
-    (short runs), four clumps of 700 bodies 1e-4 ... 0.5 wide (runs of hundreds in random order: fall through), exact
-    duplicates (equal keys keep their original order).  == the oracle's stable sort, exact permutation."""
+    """the in-LDS bucket sort (ls_sort_in_lds) has four paths: the full set of radix passes at once (the input's
+    adjacent keys say a window would leave many ties), passes over a window of the top 24-48 bits only, the same
+    followed by neighbour exchanges inside the runs of keys that agree on the window, and — exchanges not finished —
+    the full set after all.  Input made for all of them (tools/lsort_paths.py shows which bucket took which):
+    scattered bodies, 300 pairs and 40 clumps of 5-30 bodies 1e-5 apart, clumps of 700 bodies 1e-4 ... 0.5 wide,
+    exact duplicates (equal keys keep their original order), 64 clumps dealt round-robin into the input (no tie
+    between adjacent INPUT bodies, runs of 150 in the result).  == the oracle's stable sort, exact permutation."""
     rng = np.random.default_rng(17)
     x = rng.uniform(-1000.0, 1000.0, (n, 3))
     k = 1000
@@ -135,6 +137,13 @@ def test_splitter_sort_close_clusters(pkg, orc, n, presorted):
         x[k:k + 700] = x[k] + rng.uniform(-wdt, wdt, (700, 3))
         k += 700
     x[k:k + 50] = x[k]  # coincident bodies
+    k += 50
+    # 64 clumps of 150 bodies, each 2e-3 wide, dealt ROUND-ROBIN into the input: adjacent input bodies always
+    # belong to different clumps (the window estimate sees no ties), the sorted buckets hold runs of 150 keys in
+    # random order, more than the neighbour exchanges finish: the window passes are followed by the full set
+    cc = rng.uniform(-900.0, 900.0, (64, 3))
+    rr = cc[np.arange(9600) % 64] + rng.uniform(-1e-3, 1e-3, (9600, 3))
+    x[k:k + 9600] = rr
     x = x.astype(np.float32)
     z = np.zeros(n, np.float32)
     ic = (x[:, 0].copy(), x[:, 1].copy(), x[:, 2].copy(), z, z.copy(), z.copy(), np.ones(n, np.float32))

@@ -15,7 +15,9 @@ for _ in range(40):
     m = int(rng.integers(5, 31)); x[k:k + m] = x[k] + rng.normal(0, 1e-5, (m, 3)); k += m
 for wdt in (0.5, 0.1, 0.02, 1e-4):
     x[k:k + 700] = x[k] + rng.uniform(-wdt, wdt, (700, 3)); k += 700
-x[k:k + 50] = x[k]
+x[k:k + 50] = x[k]; k += 50
+cc = rng.uniform(-900.0, 900.0, (64, 3))
+x[k:k + 9600] = cc[np.arange(9600) % 64] + rng.uniform(-1e-3, 1e-3, (9600, 3))
 x = x.astype(np.float32)
 z = np.zeros(n, np.float32)
 e = pkg.Engine(n, sort_variant=3)
@@ -27,4 +29,7 @@ buf = np.zeros((256, 16), dtype=np.uint64)
 assert lib.bh_debug_ls_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 size, npass = buf[:, 4].astype(np.int64), buf[:, 6].astype(np.int64)
 ok = size > 0
+path = buf[:, 7].astype(np.int64)
+names = {0: "full set of passes at once", 1: "window only", 2: "window + neighbour exchanges", 3: "window, exchanges not finished, full set"}
+print("paths", {names[int(k)]: int(v) for k, v in zip(*np.unique(path[ok], return_counts=True))})
 print("buckets", ok.sum(), "passes histogram", dict(zip(*np.unique(npass[ok], return_counts=True))), "slow", e.stats().sort_slow_buckets)

@@ -6,7 +6,7 @@ import bhpkg
 pkg = bhpkg.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 e = pkg.Engine(n)
-e.upload(*pkg.plummer(n, seed=42))
+e.upload(*(pkg.disc(n, seed=42) if os.environ.get("BH_TRACE_IC") == "disc" else pkg.plummer(n, seed=42)))
 e.step(6)
 e.sync()
 lib = ctypes.CDLL(os.environ["BH_LIB_PATH"])
