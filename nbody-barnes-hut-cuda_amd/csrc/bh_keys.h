@@ -54,18 +54,43 @@ __device__ __forceinline__ u64 morton_key(float px, float py, float pz, float mi
 // (the cells are the same cubes, their numbering inside the parent changes), so sort, tree build, COM and the
 // walk are untouched; consecutive bodies are always spatial neighbours (no Z-curve jumps), which makes the
 // 64-body groups of the force walk more compact: -5 % force time at 1M bodies.
+// Branch-free: written with `if (X1 & Q) ... else ...` (Skilling's text) the compiler built two divergent regions
+// per level (EXEC save / restore, 40 v_cmp + 22 VCC-form v_cndmask per key — the slowest instruction form there
+// is on gfx950); as masks every step is a couple of three-input boolean operations (v_bitop3_b32).
+// bit_mask: bit Q of x spread over the word (0 or ~0) — inline asm so that the optimiser cannot see a select in it:
+// given `0 - ((x >> q) & 1)` it rebuilds v_cmp + v_cndmask (79 VCC-form selects per key).
+template <int Q>
+__device__ __forceinline__ u32 bit_mask(u32 x) {
+  u32 m;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(x), "n"(Q));
+  return m;
+}
+template <int Q>
+__device__ __forceinline__ void hilbert_level(u32& X0, u32& X1, u32& X2) {
+  constexpr u32 P = (1u << Q) - 1u;
+  const u32 m0 = bit_mask<Q>(X0);  // all ones where the level's bit is set
+  X0 ^= P & m0;
+  const u32 m1 = bit_mask<Q>(X1);
+  const u32 t1 = (X0 ^ X1) & P & ~m1;  // bit clear: exchange the low bits of X0 and X1; set: invert X0's
+  X0 ^= (P & m1) ^ t1;
+  X1 ^= t1;
+  const u32 m2 = bit_mask<Q>(X2);
+  const u32 t2 = (X0 ^ X2) & P & ~m2;
+  X0 ^= (P & m2) ^ t2;
+  X2 ^= t2;
+  if constexpr (Q > 1) hilbert_level<Q - 1>(X0, X1, X2);
+}
 __device__ __forceinline__ void hilbert_axes_to_transpose(u32& X0, u32& X1, u32& X2) {
-  for (u32 Q = 1u << 20; Q > 1u; Q >>= 1) {
-    const u32 P = Q - 1u;
-    if (X0 & Q) X0 ^= P;
-    if (X1 & Q) X0 ^= P; else { const u32 t = (X0 ^ X1) & P; X0 ^= t; X1 ^= t; }
-    if (X2 & Q) X0 ^= P; else { const u32 t = (X0 ^ X2) & P; X0 ^= t; X2 ^= t; }
-  }
+  hilbert_level<20>(X0, X1, X2);  // levels Q = 2^20 .. 2
   X1 ^= X0;
   X2 ^= X1;
-  u32 t = 0;
-  for (u32 Q = 1u << 20; Q > 1u; Q >>= 1)
-    if (X2 & Q) t ^= Q - 1u;
+  // Gray encode: bit b of t = parity of the bits of X2 above b (the loop `if (X2 & Q) t ^= Q - 1` over Q = 2^20 .. 2)
+  u32 t = X2 >> 1;
+  t ^= t >> 1;
+  t ^= t >> 2;
+  t ^= t >> 4;
+  t ^= t >> 8;
+  t ^= t >> 16;
   X0 ^= t; X1 ^= t; X2 ^= t;
 }
 // inverse ("TransposeToAxes"): transposed index -> cell coordinates
