@@ -214,7 +214,8 @@ int bh_get_stats(bh_ctx* c, bh_stats* s);
 /* on = 1: an event after every stage of bh_step (bh_stats.ms_*, bh_timing_history); on = 2: only the pair around
    the force launch (ms_force; the other times read 0) — each event record costs the stream several microseconds,
    eight of them ~60 us per 1M-body step; on = 3: that pair on every 4th step only (bh_timing_history then holds one
-   entry per sampled step); 0 = off */
+   entry per sampled step); 0 = off.  In modes 0, 2 and 3 the force launch of bh_step also integrates the bodies
+   (same arithmetic, same results; ms_force of modes 2 / 3 = force + integrate); mode 1 times separate kernels */
 int bh_set_timing(bh_ctx* c, int on);
 /* waits for the context's stream; BH_ERR_DEVICE_FLAG if a sticky device flag is set (the step loop's check:
    stack / pool overflow, sort time-out, traversal limit — see BH_FLAG_*) */

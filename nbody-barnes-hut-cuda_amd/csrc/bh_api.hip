@@ -85,7 +85,7 @@ static void free_all(bh_ctx* c) {
   void* ptrs[] = {c->posm[0], c->posm[1], c->velid[0], c->velid[1], c->acc_own, c->stage_buf,
                   c->keys[0], c->keys[1], c->vals[0], c->vals[1], c->hist, c->sw_hist, c->sw_status,
                   c->sw_ticket, c->sp_keys, c->sp_count, c->bbox_partial, c->bounds_next, c->ibox_rows,
-                  c->bounds, c->d8, c->ksamp, c->pa, c->pb, c->pn,
+                  c->bounds, c->d8, c->ksamp, c->fuse_rows, c->fuse_cnt, c->pa, c->pb, c->pn,
                   c->cb, c->ttot, c->blk_done, c->rec, c->frec, c->er_lo, c->er_hi, c->P, c->info, c->scan_tmp,
                   c->cV, c->cO, c->cP};
   for (void* p : ptrs)
@@ -187,6 +187,11 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->ibox_rows, (N / 1024 + 2) * 6) == hipSuccess;  // one row per integrate block (>= 1024 bodies)
   ok = ok && dalloc(&c->d8, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->ksamp, (size_t)2048 + 8) == hipSuccess;
+  // waves of a force launch over all bodies: 64 bodies per wave, 32 up to 81,920 bodies, 16 up to 24,576 (force_group)
+  c->fuse_waves = (int)std::max<size_t>(N / 64 + 2, std::min<size_t>(N / 16 + 2, 2600));
+  ok = ok && dalloc(&c->fuse_rows, ((size_t)c->fuse_waves + c->fuse_waves / 32 + 2) * 6) == hipSuccess;
+  ok = ok && dalloc(&c->fuse_cnt, (size_t)c->fuse_waves / 32 + 3) == hipSuccess;
+  ok = ok && hipMemset(c->fuse_cnt, 0, ((size_t)c->fuse_waves / 32 + 3) * sizeof(u32)) == hipSuccess;
   ok = ok && dalloc(&c->pa, N) == hipSuccess && dalloc(&c->pb, N) == hipSuccess;
   ok = ok && dalloc(&c->pn, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->cb, N + 4) == hipSuccess;
@@ -480,10 +485,13 @@ static int step_launch(bh_ctx* c) {
   // digests only unless something reads the canonical records after this step (strict / literal kernels)
   BH_HIP(c, bhk_com_records(c, c->p.strict_fp || c->p.literal_force || c->dd));  // ref:279-280
   BH_MARK(5);
-  BH_HIP(c, bhk_force(c, 0, c->n, false));     // ref:281
-  BH_MARK(6);
+  // Outside per-stage timing the force launch also integrates (ref:282) and folds the next step's cube (ref:259):
+  // force_fast_kernel FUSE.  The timed pair (5, 6) then brackets force + integrate.
   const bool fuse_bbox = !c->dd && c->p.step_graph != 1;
-  BH_HIP(c, bhk_integrate(c, fuse_bbox));      // ref:282 (+ ref:259 of the next step)
+  bool fused = false;
+  BH_HIP(c, bhk_force(c, 0, c->n, false, fuse_bbox && !all, &fused));     // ref:281
+  BH_MARK(6);
+  if (!fused) BH_HIP(c, bhk_integrate(c, fuse_bbox));      // ref:282 (+ ref:259 of the next step)
   c->bounds_next_ok = fuse_bbox;
   BH_MARK(7);
 #undef BH_MARK

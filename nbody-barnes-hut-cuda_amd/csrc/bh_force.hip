@@ -676,13 +676,43 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
 // VARIANT 0: hand-scheduled walk (fast_traverse_asm); 1: the compiler-scheduled walk (A/B, bh_params.force_variant).
 // BUDGET: bound the number of child blocks a wave may pop (domain-decomposed entry: the pool holds records
 // written by other ranks, and a malformed pool must end in BH_FLAG_TRAVERSAL_LIMIT, not in a hang).
-template <int VARIANT, bool BUDGET, bool PF = false>
+// What a wave of the fused launch needs to integrate its own bodies and fold the next step's cube (FUSE below).
+struct bh_fuse_args {
+  float4* posm;     // the bodies, updated in place (each by the one wave that owns it)
+  float4* velid;
+  float dt, max_speed;
+  float* rows;      // [waves][6] min / max of every wave's new positions
+  float* grows;     // [waves / 32 + 1][6] the same per group of 32 waves
+  u32* cnt;         // [1 + groups] counters of the two-level "last wave" hand-off (left at zero)
+  float* bounds_next;
+  int waves;        // waves of this launch that own bodies
+};
+
+__device__ __forceinline__ float fuse_wave_min(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float fuse_wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+// FUSE (bh_step of the default engine): the wave also integrates its bodies (ref:227-249, the arithmetic of
+// integrate_kernel in bh_tree.hip, bit for bit) — nobody else reads a body's position during the launch: the walk
+// reads the digests — and the launch folds the min / max of the new positions into the next step's cube the way
+// integrate_kernel<true> does, two levels deep because a launch has up to 15,625 waves: the last wave of every
+// group of 32 folds the group's rows, the last of those folds the groups (bh_internal.h: fence-free hand-off).
+// One launch and 32 bytes per body less than force + integrate; the integrate kernel's 19 us (9 at 65,536 bodies)
+// become a few hundred instructions at the end of waves that finish at different times anyway.
+template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false>
 __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict__ frec_g,
                                                          const float4* __restrict__ posm,
                                                          float4* __restrict__ acc, int lo, int hi, float G,
                                                          float eps2, int xcd_mode,
                                                          bh_devinfo* __restrict__ info, int root, int budget,
-                                                         int group) {
+                                                         int group, bh_fuse_args fz = bh_fuse_args{}) {
   cfloat_t* frec = (cfloat_t*)frec_g;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
@@ -693,14 +723,14 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   // a SIMD — half the bodies walk a smaller union of records and two waves per SIMD hide each other's latency
   const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * group + lane;
   const bool valid = lane < group && i < hi;
-  float px, py, pz;
+  float px, py, pz, pm;
   {
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
-    px = p.x; py = p.y; pz = p.z;
+    px = p.x; py = p.y; pz = p.z; pm = p.w;
   }
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
   const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
-  if (m0 == 0) return;
+  if (m0 == 0) return;  // (a wave without bodies: not one of fz.waves)
   // 64 stack entries (one VGPR set, no set-select branches) cover every tree seen in practice; the
   // rare wave that needs more redoes its walk with the 192-entry stack (>= the 7*21+1 bound)
   bool ok, limit = false;
@@ -717,6 +747,98 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   }
   if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
+  if (!FUSE) return;
+
+  float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
+  float mx[3] = {-1e10f, -1e10f, -1e10f};
+  if (valid) {  // ref:227-249, source text, no contraction: v += a dt; clamp |v| to max_speed; p += v dt
+    float4 v = fz.velid[i];
+    const float DT = fz.dt, MAX_SPEED = fz.max_speed;
+    float vx = v.x + ax * DT;
+    float vy = v.y + ay * DT;
+    float vz = v.z + az * DT;
+    const float speedSq = vx * vx + vy * vy + vz * vz;
+    if (speedSq > MAX_SPEED * MAX_SPEED) {
+      const float scale = MAX_SPEED / sqrtf(speedSq);
+      vx *= scale;
+      vy *= scale;
+      vz *= scale;
+    }
+    v.x = vx; v.y = vy; v.z = vz;
+    px += vx * DT;
+    py += vy * DT;
+    pz += vz * DT;
+    fz.posm[i] = make_float4(px, py, pz, pm);
+    fz.velid[i] = v;
+    mn[0] = mx[0] = px; mn[1] = mx[1] = py; mn[2] = mx[2] = pz;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    mn[q] = fuse_wave_min(mn[q]);
+    mx[q] = fuse_wave_max(mx[q]);
+  }
+  const int w = chunk * (int)(blockDim.x >> 6) + wib;  // < fz.waves: the wave owns bodies
+  const int g = w >> 5, gsize = min(32, fz.waves - (g << 5)), ngroups = (fz.waves + 31) >> 5;
+  int last = 0;
+  if (lane == 0) {
+    float* o = fz.rows + (size_t)w * 6;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      bh_publish_f32(o + q, mn[q]);
+      bh_publish_f32(o + 3 + q, mx[q]);
+    }
+    bh_published();
+    if (__hip_atomic_fetch_add(fz.cnt + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u32)(gsize - 1)) {
+      __hip_atomic_store(fz.cnt + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = 1;
+    }
+  }
+  if (!__shfl(last, 0, 64)) return;
+  {  // the group's rows (this wave's own among them)
+    const float* o = fz.rows + ((size_t)(g << 5) + (size_t)min(lane, gsize - 1)) * 6;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      mn[q] = fuse_wave_min(lane < gsize ? bh_collect_f32(o + q) : 1e10f);
+      mx[q] = fuse_wave_max(lane < gsize ? bh_collect_f32(o + 3 + q) : -1e10f);
+    }
+  }
+  last = 0;
+  if (lane == 0) {
+    float* o = fz.grows + (size_t)g * 6;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      bh_publish_f32(o + q, mn[q]);
+      bh_publish_f32(o + 3 + q, mx[q]);
+    }
+    bh_published();
+    if (__hip_atomic_fetch_add(fz.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u32)(ngroups - 1)) {
+      __hip_atomic_store(fz.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = 1;
+    }
+  }
+  if (!__shfl(last, 0, 64)) return;
+  float fn[3] = {1e10f, 1e10f, 1e10f}, fx[3] = {-1e10f, -1e10f, -1e10f};
+  for (int r = lane; r < ngroups; r += 64) {
+    const float* o = fz.grows + (size_t)r * 6;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      fn[q] = fminf(fn[q], bh_collect_f32(o + q));
+      fx[q] = fmaxf(fx[q], bh_collect_f32(o + 3 + q));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    fn[q] = fuse_wave_min(fn[q]);
+    fx[q] = fuse_wave_max(fx[q]);
+  }
+  if (lane == 0) {  // the cube of ref:148-154 (write_cube, bh_tree.hip)
+    float* b = fz.bounds_next;
+    const float size = fmaxf(fx[0] - fn[0], fmaxf(fx[1] - fn[1], fx[2] - fn[2]));  // ref:148
+    b[0] = fn[0]; b[1] = fn[1]; b[2] = fn[2];
+    b[3] = fn[0] + size; b[4] = fn[1] + size; b[5] = fn[2] + size;  // ref:152-154: anchored at the min corner
+    b[6] = fmaxf(b[3] - b[0], 1.0f);  // root edge s0, ref:55
+    b[7] = 0.0f;
+  }
 }
 
 // measurement only (bh_force_walk_stats): the hand-scheduled walk with its event counters and clock stamps,
@@ -859,7 +981,10 @@ static int resolve_xcd_mode(const bh_ctx* c, int bodies, int group) {
   return waves > (long long)c->num_cus * 32 ? 2 : 0;
 }
 
-hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
+// fuse_integrate (bh_step): the launch may also integrate the bodies and fold the next step's cube into
+// c->bounds_next (force_fast_kernel FUSE); *fused tells whether it did (only the hand-scheduled walk over all bodies)
+hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate, bool* fused) {
+  if (fused) *fused = false;
   if (hi <= lo) return hipSuccess;
   const int blocks = (hi - lo + 255) / 256;
   const bh_node* rec = c->rec;
@@ -899,6 +1024,20 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count) {
       constexpr bool debug_budget = false;
       constexpr int lds_pad = 0;
 #endif
+      const int waves = (hi - lo + group - 1) / group;
+      if (fuse_integrate && fused && !debug_budget && c->p.force_variant == 0 && lo == 0 && hi == c->n &&
+          waves <= c->fuse_waves) {
+        const bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
+                              c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->bounds_next, waves};
+        if (hi - lo <= kPrefetchMaxBodies)
+          force_fast_kernel<0, false, true, true><<<g2, tpb, 0, c->stream>>>(
+              (const float*)c->frec, posm, c->acc, lo, hi, G, e2, mode, c->info, 0, 0, group, fz);
+        else
+          force_fast_kernel<0, false, false, true><<<g2, tpb, 0, c->stream>>>(
+              (const float*)c->frec, posm, c->acc, lo, hi, G, e2, mode, c->info, 0, 0, group, fz);
+        *fused = true;
+        return hipGetLastError();
+      }
       if (debug_budget)
         force_fast_kernel<0, true><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, posm, c->acc, lo, hi, G, e2,
                                                               mode, c->info, 0, kTraversalBudget, group);

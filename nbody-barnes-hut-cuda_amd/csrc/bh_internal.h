@@ -177,6 +177,10 @@ struct bh_ctx {
   // domain-decomposed stepping (bh_dd.hip); null until bh_dd_init
   struct bh_dd_state* dd;
   bh_frec* frec_own;  // the context's own record pool while frec points into a caller pool
+  // force + integrate in one launch (bh_step, force_fast_kernel FUSE): per-wave and per-group min / max rows, counters
+  float* fuse_rows;   // [fuse_waves + fuse_waves / 32 + 2][6]
+  u32* fuse_cnt;      // [fuse_waves / 32 + 3], zero between launches
+  int fuse_waves;
   float* dd_minmax;   // [8] dd mode: this rank's min / max of the positions the last integrate wrote (X1 payload)
   bool dd_minmax_ok;  // set by bh_integrate in dd mode, cleared by anything else that writes positions
 
@@ -297,7 +301,7 @@ hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather);
 hipError_t bhk_gather_bodies(bh_ctx* c, hipStream_t stream);  // no-op unless a gather is pending
 hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
-hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count);
+hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate = false, bool* fused = nullptr);
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream,
                           float4* acc);  // fast kernel from pool record `root`
 hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows);  // measurement: per-wave event counters of the fast walk

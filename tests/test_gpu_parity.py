@@ -603,7 +603,7 @@ def test_timing_modes(pkg):
     """bh_set_timing: 1 = an event after every stage (every ms_* of bh_stats filled, the history carries force and
     step times), 2 = only the pair around the force launch (what bench.py's timed region uses: ms_force and the
     force history only), 3 = that pair on every 4th step (steps 0 and 4 of these 5), 0 = off; the physics does not
-    depend on it"""
+    depend on it — mode 1 steps with separate force and integrate kernels, the others with the fused launch"""
     n = 40000
     ic = pkg.plummer(n, seed=12)
     states = []
@@ -627,9 +627,11 @@ def test_timing_modes(pkg):
     assert states[0] == states[1] == states[2] == states[3]
 
 
-def test_step_cube_from_integrate_is_the_bbox_cube(pkg, orc):
-    """the cube a step takes from the previous step's integrate kernel == bh_bbox of the same positions"""
-    ic = pkg.plummer(70001, seed=9)
+@pytest.mark.parametrize("n", [5000, 70001, 300000])
+def test_step_cube_from_integrate_is_the_bbox_cube(pkg, orc, n):
+    """the cube a step takes from the previous step — folded by the force launch that also integrates (16 / 32 / 64
+    bodies per wave at these sizes: 313 / 2,188 / 4,688 waves, two-level hand-off) — == bh_bbox of the same positions"""
+    ic = pkg.plummer(n, seed=9)
     e = _engine(pkg, ic)
     for _ in range(3):
         e.step(1)
