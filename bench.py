@@ -390,7 +390,8 @@ def main():
                 "bound": "valu", "achieved": useful_tflops, "peak": FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": useful_tflops / FP32_VECTOR_TFLOPS,
                 "traffic": traffic, "traffic_provenance": traffic_src,
-                "kernel": "force_fast_kernel<0,false> (csrc/bh_force.hip, hand-scheduled walk)",
+                "kernel": "force_fast_kernel<0,false,...,FUSE> (csrc/bh_force.hip, hand-scheduled walk; in bh_step the "
+                          "launch also integrates its bodies and folds the next cube, ~3 us of the launch time)",
                 "avg_launch_ms": avg_force_ms,
                 "launches_timed": int(len(f_ms)),
                 "why_valu": "the walk is bound by VALU instruction ISSUE: every record field arrives in SGPRs, and "
