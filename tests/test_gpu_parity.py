@@ -537,6 +537,23 @@ def _state(e):
     return np.stack(e.download(), 1).tobytes(), e.download_order().tobytes()
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 1000, 24577, 81921, 250000])
+def test_fused_force_integrate_step_matches_separate_kernels(pkg, n):
+    """bh_step's force launch also integrates and folds the next cube (modes other than per-stage timing); under
+    bh_set_timing(1) the same step runs force and integrate as separate kernels.  Same states, same order and the
+    same cube after 4 steps, for one wave, the 16 / 32 / 64 bodies-per-wave launches and both walk instances"""
+    ic = pkg.plummer(n, seed=31)
+    out = []
+    for timing in (0, 1):
+        e = _engine(pkg, ic)
+        e.set_timing(timing)
+        e.step(4)
+        assert e.stats().status_flags == 0
+        out.append((_state(e), e.download_bounds().tobytes()))
+        e.close()
+    assert out[0] == out[1]
+
+
 def test_step_shortcuts_survive_uploads_and_stage_calls(pkg):
     """bh_step takes two shortcuts from the previous step — the bounding cube folded by its integrate kernel and
     the splitter sort that relies on the stored key order — and both must be dropped whenever something else
