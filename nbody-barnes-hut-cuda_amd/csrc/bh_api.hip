@@ -465,7 +465,9 @@ static int step_launch(bh_ctx* c) {
   BH_HIP(c, bhk_keys(c));                      // ref:260
   c->key_buf = 0;
   BH_MARK(2);
-  BH_HIP(c, bhk_sort(c, true));                // ref:262-264 (the body gather may be left pending)
+  // (the body gather is left pending for the second stream — where there is one: below BH_FORK_MIN_N bodies the
+  // bucket sort gathers the bodies itself, one launch less on the only stream)
+  BH_HIP(c, bhk_sort(c, c->n >= BH_FORK_MIN_N));  // ref:262-264
   BH_MARK(3);
   // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan on the side
   // stream while the main stream builds the tree (both are small, latency-bound grids).  Each event hand-over
