@@ -83,7 +83,7 @@ typedef struct bh_params {
                             graph, one per ping-pong parity of the body arrays (measured slower on ROCm 7.2:
                             DESIGN.md)                                                                  */
   int32_t force_group;   /* bodies per wave of the default force kernel: 64, 32 or 16 (upper lanes idle), or
-                            0 = by launch size: 16 up to 24,576 bodies, 32 up to 81,920, else 64;
+                            0 = by launch size: 16 up to 20,480 bodies, 32 up to 57,344, else 64;
                             speed only                                                               */
   int32_t key_curve;     /* numbering of the 2^21-per-axis cell grid behind the 63-bit keys: 0 = Morton / Z order
                             (the reference's, ref:42-63), 1 = Hilbert order (default).  Same cells, same tree up

@@ -187,7 +187,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->ibox_rows, (N / 1024 + 2) * 6) == hipSuccess;  // one row per integrate block (>= 1024 bodies)
   ok = ok && dalloc(&c->d8, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->ksamp, (size_t)2048 + 8) == hipSuccess;
-  // waves of a force launch over all bodies: 64 bodies per wave, 32 up to 81,920 bodies, 16 up to 24,576 (force_group)
+  // waves of a force launch over all bodies: 64 bodies per wave, 32 up to 57,344 bodies, 16 up to 20,480 (force_group)
   c->fuse_waves = (int)std::max<size_t>(N / 64 + 2, std::min<size_t>(N / 16 + 2, 2600));
   ok = ok && dalloc(&c->fuse_rows, ((size_t)c->fuse_waves + c->fuse_waves / 32 + 2) * 6) == hipSuccess;
   ok = ok && dalloc(&c->fuse_cnt, (size_t)c->fuse_waves / 32 + 3) == hipSuccess;

@@ -136,7 +136,10 @@ __device__ __forceinline__ void ws_pop(const WaveStack& s, int sp, int& first, i
 }
 
 constexpr int kStackCap = 192;
-constexpr int kPrefetchMaxBodies = 200000;  // launches up to this size run the walk with its scalar-cache prefetch
+#ifndef BH_PF_MAX
+#define BH_PF_MAX 200000
+#endif
+constexpr int kPrefetchMaxBodies = BH_PF_MAX;  // launches up to this size run the walk with its scalar-cache prefetch
 constexpr int kTraversalBudget = 1 << 22;  // child blocks one wave may pop in the domain-decomposed entry
 
 struct Lane {
@@ -463,15 +466,26 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // Scalar-cache prefetch (template parameter PF of fast_traverse_asm): the walk is a chain pop -> fetch ->
 // evaluate, and with few waves per SIMD the fetch latency (scalar loads served by the L2) is exposed.  A one-dword
 // scalar load brings a 64-byte line into the scalar data cache without needing a register window: the first two
-// lines of a child block are touched when the block is PUSHED (the last block pushed is the next one popped);
+// lines of a child block (round 3, later: all four) are touched when the block is PUSHED (the last block pushed is the next one popped);
 // s100 is a dummy target.  Measured (force ms without / with): 16,384 bodies 0.150 / 0.145, 65,536 0.219 / 0.214,
 // 125,000 0.272 / 0.263, 250,000 0.442 / 0.441, 1M 1.217 / 1.226 — on for launches of <= kPrefetchMaxBodies.
 // (Also touching the new stack top at every pop measured slower at every size: +0.4 % at 16k ... +5 % at 1M.)
+// All four lines of the block are touched (a block of 5-8 children is fetched as four pairs; touching only the first
+// two left half of the blocks waiting for the L2 at the pop): force ms, two lines / four: 16,384 bodies 0.143 /
+// 0.135, 65,536 0.213 / 0.207, 125,000 0.261 / 0.250, 200,000 0.366 / 0.361; above the threshold it loses like
+// the two-line form (300,000 +3 %, 1M +9 % against the walk without prefetch).  -DBH_PF2: the two-line form.
+// (Touching the first line of EVERY child's block as soon as a block's records arrive: +8 ... +14 % at these sizes.)
+#ifndef BH_PF2
+#define BH_PF_MORE "s_load_dword s100, s[20:21], s24 offset:128\n s_load_dword s100, s[20:21], s24 offset:192\n"
+#else
+#define BH_PF_MORE ""
+#endif
 #define BH_PF_PUSH(LINK)                                                                                 \
   ".if %c[pf]\n"                                                                                          \
   "s_andn2_b32 s24, " LINK ", 63\n"                                                                        \
   "s_load_dword s100, s[20:21], s24 offset:0\n"                                                           \
   "s_load_dword s100, s[20:21], s24 offset:64\n"                                                          \
+  BH_PF_MORE                                                                                              \
   ".endif\n"
 // a stack entry = (link, lane mask): link = byte offset of the child block | its child count (bh_internal.h).
 // The TOP of the stack is kept in scalar registers (s101 link — 0: none —, s[22:23] mask): a push first spills the
@@ -965,11 +979,13 @@ __global__ __launch_bounds__(256) void unpack_u32x3_kernel(const u32* __restrict
 
 // bodies per wave of the fast walk: fewer than 64 (upper lanes idle) when 64 would leave the 1024 SIMDs with one
 // or two waves each — smaller groups walk smaller unions of records and more waves hide each other's scalar-load
-// latency.  Measured force ms (16 / 32 / 64 bodies per wave): 16,384 bodies 0.153 / 0.170 / 0.191; 32,768:
-// 0.185 / 0.187 / 0.216; 65,536: 0.286 / 0.223 / 0.233; 98,304: 0.391 / 0.274 / 0.268; 131,072: 0.514 / 0.337 / 0.276
+// latency.  Measured force ms with the four-line prefetch (16 / 32 / 64 bodies per wave): 8,192 bodies 0.150 /
+// 0.144 / 0.146; 16,384: 0.136 / 0.146 / 0.160; 24,576: 0.170 / 0.160 / 0.176; 32,768: 0.172 / 0.166 / 0.184;
+// 49,152: 0.221 / 0.201 / 0.198; 65,536: 0.268 / 0.204 / 0.203; 81,920: 0.319 / 0.248 / 0.240; 131,072: 0.486 /
+// 0.317 / 0.251.  Results do not depend on the group size.
 static int force_group(const bh_ctx* c, int bodies) {
   if (c->p.force_group == 16 || c->p.force_group == 32 || c->p.force_group == 64) return c->p.force_group;
-  return bodies <= 24 * 1024 ? 16 : (bodies <= 80 * 1024 ? 32 : 64);
+  return bodies <= 20 * 1024 ? 16 : (bodies <= 56 * 1024 ? 32 : 64);
 }
 
 // bh_params.xcd_mode 3 (default): interleaved runs when the launch has more waves than the GPU holds at once
