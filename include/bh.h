@@ -188,7 +188,8 @@ typedef struct bh_walk_stats {
   double wave_cycles_max, wave_cycles_mean; /* wave lifetime, shader cycles                            */
   uint64_t lane_spills;  /* stack entries that went through the cross-lane stack (3 v_writelane + 3 v_readlane
                             each); the others stayed in scalar registers from push to pop                 */
-  uint64_t reserved[3];
+  uint64_t no_taker_pairs; /* of the masked pairs: those in which every active lane opens both records */
+  uint64_t reserved[2];
 } bh_walk_stats;
 int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out);
 

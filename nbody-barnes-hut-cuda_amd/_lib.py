@@ -49,7 +49,7 @@ class BhWalkStats(C.Structure):
     """struct bh_walk_stats: event counters of one launch of the default force walk (measurement)."""
     _fields_ = [("waves", C.c_uint64), ("pairs", C.c_uint64), ("blocks", C.c_uint64), ("masked_pairs", C.c_uint64),
                 ("clock_ghz", C.c_double), ("wave_cycles_max", C.c_double), ("wave_cycles_mean", C.c_double),
-                ("lane_spills", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("lane_spills", C.c_uint64), ("no_taker_pairs", C.c_uint64), ("reserved", C.c_uint64 * 2)]
 
 
 class BhDdSizes(C.Structure):

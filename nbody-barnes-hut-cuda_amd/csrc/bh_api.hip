@@ -8,6 +8,7 @@
 // 4-byte D2H of nodeCounter every step, :277-278), per-stage hipEvent timers.
 // There is NO CPU fallback anywhere in this library: without a HIP device bh_create fails.
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -205,7 +206,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && dalloc(&c->er_hi, (size_t)c->rec_cap) == hipSuccess;
   ok = ok && dalloc(&c->P, N + 1) == hipSuccess;
   ok = ok && dalloc(&c->info, 1) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&c->host_flags, sizeof(int)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->host_flags, 4 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc(&c->scan_tmp, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipMalloc(&c->scan_tmp2, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipMemset(c->scan_tmp, 0, c->scan_tmp_bytes) == hipSuccess;
@@ -250,15 +251,34 @@ static int sync_raw(bh_ctx* c) {
   return BH_OK;
 }
 
+// The splitter sort met buckets beyond its LDS capacity.  An isolated one is normal (two neighbouring splitter
+// bodies that both crossed a high-level cell plane: about once in 60 steps of the 1M Plummer run, a 0.18 ms
+// sort); when more than every fourth sort since the last look had one, the input defeats the splitters (many
+// equal keys) and the context goes back to the radix passes until the next upload.  Looked at wherever the host
+// reads the device info block anyway: bh_sync (every frame of a step loop) and bh_get_stats.
+static void note_slow_buckets(bh_ctx* c, int slow_buckets) {
+  const int d_slow = slow_buckets - c->slow_seen;
+  const long d_sorts = (long)c->sort_calls - (long)c->slow_seen_sorts;
+  if (d_slow > 0 && d_sorts > 0 && 4L * d_slow > d_sorts) c->splitter_off = true;
+  c->slow_seen = slow_buckets;
+  c->slow_seen_sorts = c->sort_calls;
+}
+
 int bh_sync(bh_ctx* c) {
   if (!c) return BH_ERR_BAD_ARG;
-  // the sticky flags ride on the same synchronisation: 4 bytes into pinned memory, then one wait
+  // the sticky flags (and the slow-bucket count of the splitter sort) ride on the same synchronisation: 12 bytes
+  // of the device info block — flags, redo_waves, slow_buckets — into pinned memory, then one wait
+  static_assert(offsetof(bh_devinfo, slow_buckets) == offsetof(bh_devinfo, flags) + 8, "bh_devinfo layout");
   if (c->host_flags) {
-    *c->host_flags = 0;
-    BH_HIP(c, hipMemcpyAsync(c->host_flags, &c->info->flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->host_flags[0] = 0;
+    c->host_flags[2] = c->slow_seen;
+    BH_HIP(c, hipMemcpyAsync(c->host_flags, &c->info->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   BH_HIP(c, hipStreamSynchronize(c->stream));
-  if (c->host_flags && *c->host_flags) return BH_ERR_DEVICE_FLAG;
+  if (c->host_flags) {
+    note_slow_buckets(c, c->host_flags[2]);
+    if (c->host_flags[0]) return BH_ERR_DEVICE_FLAG;
+  }
   return BH_OK;
 }
 
@@ -332,6 +352,10 @@ int bh_morton(bh_ctx* c) {
 int bh_sort(bh_ctx* c) {
   BH_NEED(c, BH_ST_MORTON);
   if (c->stage & BH_ST_SORT) return BH_ERR_ORDER;  // sorting twice would permute twice
+  // the tree of an earlier digest-only step stays downloadable: make its records canonical before the bodies
+  // they refer to are reordered (stage calls only; bh_step rebuilds the tree anyway)
+  if ((c->ever & BH_ST_BUILD) && c->rec_proto && c->com_digests) BH_HIP(c, bhk_canonical_records(c));
+  c->com_digests = false;
   BH_HIP(c, bhk_sort(c));
   c->stage |= BH_ST_SORT;
   c->ever |= BH_ST_SORT;
@@ -378,7 +402,7 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
   BH_NEED(c, BH_ST_COM);
   if (c->p.strict_fp || c->p.literal_force || c->dd) return BH_ERR_BAD_ARG;  // the default walk only
   memset(out, 0, sizeof(*out));
-  const size_t W = ((size_t)c->n + 63) / 64;
+  const size_t W = (size_t)bhk_force_walk_rows(c);
   u32* rows = nullptr;
   BH_HIP(c, hipMalloc((void**)&rows, W * 8 * sizeof(u32)));
   std::vector<u32> h(W * 8);
@@ -402,6 +426,7 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
     out->blocks += r[1];
     out->masked_pairs += r[2];
     out->lane_spills += r[3];
+    out->no_taker_pairs += r[7];
     if (r[5]) ghz.push_back((double)r[4] / ((double)r[5] * 10.0));  // 100 MHz ticks -> ns
     cyc_max = r[4] > cyc_max ? (double)r[4] : cyc_max;
     cyc_sum += (double)r[4];
@@ -673,9 +698,13 @@ static int fetch_info(bh_ctx* c, bh_devinfo* h) {
 
 int bh_download_tree(bh_ctx* c, bh_node* out, int capacity, int* n_entries) {
   BH_NEED_EVER(c, BH_ST_BUILD);
-  // bh_step of the default engine writes only the force kernel's digests; the canonical records exist after the
-  // stage calls (bh_build + bh_com) or after a step of a strict_fp / literal_force context
-  if (out && c->rec_proto) return BH_ERR_ORDER;
+  // bh_step of the default engine writes only the force kernel's digests: the canonical records are then made on
+  // demand, here (the step's prefix sums and digests are still in place).  After bh_build alone there is no
+  // centre of mass to serve yet.
+  if (out && c->rec_proto) {
+    if (!c->com_digests) return BH_ERR_ORDER;
+    BH_HIP(c, bhk_canonical_records(c));
+  }
   bh_devinfo hi;
   int s = fetch_info(c, &hi);
   if (s) return s;
@@ -712,17 +741,7 @@ int bh_get_stats(bh_ctx* c, bh_stats* st) {
   }
   st->force_redo_waves = hi.redo_waves;
   st->sort_slow_buckets = hi.slow_buckets;
-  // The splitter sort met buckets beyond its LDS capacity.  An isolated one is normal (two neighbouring splitter
-  // bodies that both crossed a high-level cell plane: about once in 60 steps of the 1M Plummer run, a 0.18 ms
-  // sort); when more than every fourth sort since the last look had one, the input defeats the splitters (many
-  // equal keys) and the context goes back to the radix passes until the next upload.
-  {
-    const int d_slow = hi.slow_buckets - c->slow_seen;
-    const long d_sorts = (long)c->sort_calls - (long)c->slow_seen_sorts;
-    if (d_slow > 0 && d_sorts > 0 && 4L * d_slow > d_sorts) c->splitter_off = true;
-    c->slow_seen = hi.slow_buckets;
-    c->slow_seen_sorts = c->sort_calls;
-  }
+  note_slow_buckets(c, hi.slow_buckets);
   st->count_V = c->tV;
   st->count_O = c->tO;
   st->count_P = c->tP;

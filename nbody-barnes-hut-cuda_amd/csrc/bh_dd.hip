@@ -1089,8 +1089,9 @@ __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ 
   if (used > stride ? k >= kSegBlocks0 : k >= used) return;
   const long long e = (long long)seg_base + t;
   const bh_frec r = frec_get(pool, e);
-  if (r.thr2 < 0.0f) return;  // closed (always accepted).  A NaN threshold is never accepted by the walk's
-                              // `d2 > thr2`, i.e. always opened: it falls through to the range check
+  if (r.thr2 < 0.0f) return;  // closed (always accepted).  A NaN threshold fails this test and falls through to the
+                              // range check: both fast walks open on `thr2 >= d2` (false for NaN: such a record is
+                              // taken as a monopole, never opened), but the check does not rely on that
   const long long lo = seg0 + kSegBlocks0, hi = seg0 + stride;
   const bool ok = r.meta >= 1 && r.meta <= 8 && (r.first & 1) == 0 && (long long)r.first >= lo &&
                   (long long)r.first + r.meta <= hi && r.pad == frec_link(r.first, r.meta);  // (the walk follows the link)

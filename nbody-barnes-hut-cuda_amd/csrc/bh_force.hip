@@ -326,8 +326,9 @@ __device__ __forceinline__ void load_frec2(cfloat_t* base, int e, FRec& a, FRec&
   {                                                                                      \
     const float dx = (R).x - px, dy = (R).y - py, dz = (R).z - pz;                       \
     const float d2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));                     \
-    const u64 accm = __builtin_amdgcn_ballot_w64(d2 > (R).thr2);                         \
-    const u64 takem = mask & accm, openm = mask & ~accm;                                 \
+    /* open test in the sense of the hand-scheduled walk (BH_M7): false for a NaN on either side */ \
+    const u64 opnm = __builtin_amdgcn_ballot_w64((R).thr2 >= d2);                        \
+    const u64 takem = mask & ~opnm, openm = mask & opnm;                                 \
     const float rinv = __builtin_amdgcn_rsqf(d2);                                        \
     const float f = ((R).gm * rinv) * (rinv * rinv);                                     \
     const float fm = __builtin_amdgcn_inverse_ballot_w64(takem) ? f : 0.0f;              \
@@ -447,7 +448,12 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_F2(R) "v_pk_mul_f32 " R ", " R ", " R "\n"
 #define BH_F3(R) "v_pk_mul_f32 v[40:41], v[40:41], " R "\n"
 #define BH_FA(D, A) "v_pk_fma_f32 " A ", v[40:41], " D ", " A "\n"
-#define BH_FM(MA, MB) "v_cndmask_b32_e64 v40, v40, 0, " MA "\n v_cndmask_b32_e64 v41, v41, 0, " MB "\n"
+// (STATS: vcc_lo counts the masked pairs in which every active lane opens BOTH records — their force half is issued
+// for nothing)
+#define BH_FM(MA, MB)                                                                                    \
+  ".if %c[stats]\n s_and_b64 s[26:27], " MA ", " MB "\n s_xor_b64 s[26:27], s[26:27], exec\n"              \
+  "s_cmp_eq_u64 s[26:27], 0\n s_cselect_b32 s24, 1, 0\n s_add_u32 vcc_lo, vcc_lo, s24\n .endif\n"          \
+  "v_cndmask_b32_e64 v40, v40, 0, " MA "\n v_cndmask_b32_e64 v41, v41, 0, " MB "\n"
 #define BH_SEG_(LBL, MASK, qm, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1) \
   LBL ":\n"                                                                                               \
   BH_M1(DX, X) BH_F1(GM, FR) BH_M2(DY, Y) BH_F2(FR) BH_M3(DZ, Z) BH_F3(FR) BH_M4(DX) MASK(FMA, FMB)       \
@@ -502,7 +508,11 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   ".if %c[pf]\n"      /* small launches: straight into the lanes (see BH_POP_TAIL) */                      \
   "s_mov_b32 m0, s30\n"                                                                                   \
   "s_add_u32 s30, s30, 1\n"                                                                               \
+  ".if %c[stats] == 0\n"                                                                                  \
   "s_max_u32 s31, s31, s30\n"                                                                             \
+  ".else\n"                                                                                               \
+  "s_add_u32 s25, s25, 1\n"            /* every entry goes through the lanes in this form */               \
+  ".endif\n"                                                                                              \
   "v_writelane_b32 v48, " LINK ", m0\n"                                                                   \
   "v_writelane_b32 v50, " MLO ", m0\n"                                                                    \
   "v_writelane_b32 v51, " MHI ", m0\n"                                                                    \
@@ -576,12 +586,12 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // STATS (measurement only, result discarded): s16 / s17 / s31 count pairs evaluated / blocks popped / pairs that
 // took the masked path instead of tracking overflow, s25 the stack entries spilled to the lanes, and the walk is
 // stamped with s_memtime (shader clock) and s_memrealtime (100 MHz); st[0..5] = pairs, blocks, masked pairs,
-// spilled entries, shader cycles, 10-ns ticks.
+// spilled entries, shader cycles, 10-ns ticks, masked pairs in which no active lane takes either record.
 template <bool BUDGET, bool STATS = false, bool PF = false>
 __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u64 m0, float px, float py,
                                                   float pz, float eps2, float& ax, float& ay, float& az,
                                                   int budget, bool& limit_hit, u32* st = nullptr) {
-  int maxsp, maxc, left, spills;
+  int maxsp, maxc, left, spills, notake = 0;
   u64 t0 = 0, r0 = 0;
   if (STATS) {
     t0 = __builtin_amdgcn_s_memtime();
@@ -607,6 +617,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_mov_b64 s[34:35], %[mask]\n"
       "s_mov_b32 s101, 0\n"              // no top-of-stack entry in scalar registers yet
       "s_mov_b32 s25, 0\n"
+      ".if %c[stats]\n s_mov_b32 vcc_lo, 0\n .endif\n"
       "s_branch L_block_%=\n"
       "L_take_%=:\n"                     // the entry pushed last is still in scalar registers
       "s_mov_b32 s32, s101\n"
@@ -657,8 +668,9 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_mov_b32 %[maxc], s16\n"
       "s_mov_b32 %[left], s17\n"
       "s_mov_b32 %[spl], s25\n"
+      ".if %c[stats]\n s_mov_b32 %[ntk], vcc_lo\n .endif\n"
       : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left),
-        [spl] "=s"(spills)
+        [spl] "=s"(spills), [ntk] "=s"(notake)
       : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
         [eps2] "s"(eps2), [budget] "s"(STATS ? 0 : budget), [use_budget] "n"(BUDGET && !STATS ? 1 : 0),
         [stats] "n"(STATS ? 1 : 0), [pf] "n"(PF ? 1 : 0)
@@ -680,6 +692,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
     st[3] = (u32)spills;  // s25: stack entries that went through the lanes
     st[4] = (u32)(t1 - t0);
     st[5] = (u32)(r1 - r0);
+    st[6] = (u32)notake;  // vcc_lo: masked pairs without a taker
     limit_hit = false;
     return true;
   }
@@ -720,9 +733,14 @@ __device__ __forceinline__ float fuse_wave_max(float v) {
 // group of 32 folds the group's rows, the last of those folds the groups (bh_internal.h: fence-free hand-off).
 // One launch and 32 bytes per body less than force + integrate; the integrate kernel's 19 us (9 at 65,536 bodies)
 // become a few hundred instructions at the end of waves that finish at different times anyway.
+#ifdef BH_FORCE_TRACE  // tools/force_trace.py: per-wave start / end of walk on the 100 MHz clock, HW_ID, XCC_ID
+constexpr int kForceTraceRows = 1 << 18;
+__device__ u32 g_force_trace[kForceTraceRows * 4];
+#endif
+
 template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false>
 __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict__ frec_g,
-                                                         const float4* __restrict__ posm,
+                                                         const float4* posm,  // (FUSE: fz.posm is the same buffer)
                                                          float4* __restrict__ acc, int lo, int hi, float G,
                                                          float eps2, int xcd_mode,
                                                          bh_devinfo* __restrict__ info, int root, int budget,
@@ -737,6 +755,9 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   // a SIMD — half the bodies walk a smaller union of records and two waves per SIMD hide each other's latency
   const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * group + lane;
   const bool valid = lane < group && i < hi;
+#ifdef BH_FORCE_TRACE
+  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
+#endif
   float px, py, pz, pm;
   {
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
@@ -761,6 +782,17 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   }
   if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
+#ifdef BH_FORCE_TRACE
+  {
+    const int wv = chunk * (int)(blockDim.x >> 6) + wib;
+    if (lane == 0 && wv < kForceTraceRows) {
+      g_force_trace[wv * 4 + 0] = tr0;
+      g_force_trace[wv * 4 + 1] = (u32)__builtin_amdgcn_s_memrealtime();
+      g_force_trace[wv * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+      g_force_trace[wv * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+  }
+#endif
   if (!FUSE) return;
 
   float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
@@ -857,15 +889,16 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
 
 // measurement only (bh_force_walk_stats): the hand-scheduled walk with its event counters and clock stamps,
 // one row of 8 words per wave; accelerations are not stored
+template <bool PF>
 __global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __restrict__ frec_g,
                                                                const float4* __restrict__ posm, int n, float eps2,
-                                                               int xcd_mode, u32* __restrict__ rows) {
+                                                               int xcd_mode, int group, u32* __restrict__ rows) {
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int chunk = block_chunk(xcd_mode);
   const int wave = chunk * (int)(blockDim.x >> 6) + wib;
-  const int i = wave * 64 + lane;
-  const bool valid = i < n;
+  const int i = wave * group + lane;
+  const bool valid = lane < group && i < n;
   float px, py, pz;
   {
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -875,14 +908,15 @@ __global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __re
   const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
   if (m0 == 0) return;
   bool limit;
-  u32 st[6];
-  (void)fast_traverse_asm<false, true>(frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit, st);
-  if (lane == 0) {
+  u32 st[7];
+  (void)fast_traverse_asm<false, true, PF>(frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit, st);
+  const bool odd = __float_as_uint(ax + ay + az) == 0x7fc12345u;  // never: keeps the walk's arithmetic alive
+  if (lane == 0 || odd) {
     u32* r = rows + (size_t)wave * 8;
 #pragma unroll
     for (int k = 0; k < 6; k++) r[k] = st[k];
     r[6] = (u32)__popcll(m0);
-    r[7] = __float_as_uint(ax + ay + az);  // keeps the walk's arithmetic alive
+    r[7] = st[6];
   }
 }
 
@@ -1071,12 +1105,26 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
   return hipGetLastError();
 }
 
-hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [ceil(n/64)][8], device */) {
+// the instruction stream of the launch bhk_force would make: the same bodies per wave (force_group) and the same
+// instance of the walk — with the scalar-cache prefetch and every stack entry in the lanes up to kPrefetchMaxBodies
+// bodies, with the stack top in scalar registers above (round-3 review: the small configurations were counted with
+// the other instance)
+int bhk_force_walk_rows(const bh_ctx* c) {
+  const int group = force_group(c, c->n);
+  return (c->n + group - 1) / group;
+}
+hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][8], device */) {
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
   const int mode = (c->p.xcd_mode == 1) ? 1 : 0;  // one row per wave in launch order: no grid padding here
-  const int g2 = (c->n + tpb - 1) / tpb;
-  force_walk_stats_kernel<<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->n, c->p.eps2, mode, rows);
+  const int group = force_group(c, c->n);
+  const int g2 = (bhk_force_walk_rows(c) * 64 + tpb - 1) / tpb;
+  if (c->n <= kPrefetchMaxBodies)
+    force_walk_stats_kernel<true><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->n, c->p.eps2,
+                                                             mode, group, rows);
+  else
+    force_walk_stats_kernel<false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->n, c->p.eps2,
+                                                              mode, group, rows);
   return hipGetLastError();
 }
 
@@ -1104,6 +1152,13 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
                                                        c->p.eps2, mode, c->info, root, budget, group);
   return hipGetLastError();
 }
+
+#ifdef BH_FORCE_TRACE
+extern "C" int bh_debug_force_trace(void* out, int rows) {
+  if (rows > kForceTraceRows) rows = kForceTraceRows;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_force_trace), (size_t)rows * 16);
+}
+#endif
 
 hipError_t bhk_pack(bh_ctx* c) {
   const int n = c->n;

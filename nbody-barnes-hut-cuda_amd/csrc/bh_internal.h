@@ -160,6 +160,8 @@ struct bh_ctx {
   int* er_lo;     // [rec_cap] body range of each record (written by the canonical COM stage)
   int* er_hi;
   bool rec_proto; // rec / er_lo / er_hi were NOT made canonical by the last COM stage (bh_step of the default engine)
+  bool com_digests;  // a COM stage has run on the current tree: digests and prefix sums P belong to rec (what
+                     // bhk_canonical_records needs to make proto records canonical after the fact)
   int rec_cap;
   bh_d4* P;       // [n+1] fp64 exclusive prefix of (m, m x, m y, m z) over sorted bodies
   bh_devinfo* info;
@@ -305,6 +307,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate 
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream,
                           float4* acc);  // fast kernel from pool record `root`
 hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows);  // measurement: per-wave event counters of the fast walk
+int bhk_force_walk_rows(const bh_ctx* c);               // waves (rows) of that launch
 hipError_t bhk_integrate(bh_ctx* c, bool with_bbox);
 void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 
@@ -313,5 +316,6 @@ hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, con
 hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out /* n+1 */, int n);  // of (in[i]+1)&~1
 hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n, bool side);
 hipError_t bhk_com_records(bh_ctx* c, bool canonical);  // second half of bhk_com: records from the prefix sums
+hipError_t bhk_canonical_records(bh_ctx* c);  // proto records -> canonical, after a digest-only COM stage
 size_t bhk_scan_tmp_bytes(int n);
 size_t bhk_scan_cnt_offset(int n);

@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
                                                   int* __restrict__ er_hi,
                                                   const bh_devinfo* __restrict__ info, int rec_cap,
                                                   const float4* __restrict__ posm,
-                                                  const bh_d4* __restrict__ P) {
+                                                  const bh_d4* __restrict__ P, int proto) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int E = min(info->n_entries, rec_cap);  // even: root + padding + blocks of even length
   if ((e & ~63) >= E) return;                   // whole wave beyond the tree
@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
   bh_frec fr = frec_null();
   if (e < E) {
     const bh_node r = rec[e];
-    const int lo = __float_as_int(r.x), hi = __float_as_int(r.y);  // put_rec: the body range
+    // the body range: in the bit patterns of x / y as the build left it (put_rec), or — a repeated bh_com on records
+    // an earlier canonical pass already overwrote with the centre of mass — in er_lo / er_hi
+    const int lo = proto ? __float_as_int(r.x) : er_lo[e], hi = proto ? __float_as_int(r.y) : er_hi[e];
     if (CANON) {
       er_lo[e] = lo;
       er_hi[e] = hi;
@@ -1174,6 +1176,45 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
     pair[2] = make_float4(q.thr2, fr.thr2, __int_as_float(q.first), __int_as_float(fr.first));
     pair[3] = make_float4(__int_as_float(q.meta), __int_as_float(fr.meta), __int_as_float(lq), __int_as_float(lk));
   }
+}
+
+// The canonical records of a tree whose COM stage wrote only the digests (bh_step of the default engine), produced
+// when somebody asks for them (bh_download_tree): the prefix sums P of that step are still there; a BODY record's
+// position comes from its digest — the fused force launch has moved posm since — and its mass from posm (masses
+// never change).  Writes exactly what com_kernel<true> would have written; touches no digest.
+__global__ __launch_bounds__(256) void canon_kernel(bh_node* __restrict__ rec, const bh_frec* __restrict__ frec,
+                                                    int* __restrict__ er_lo, int* __restrict__ er_hi,
+                                                    const bh_devinfo* __restrict__ info, int rec_cap,
+                                                    const float4* __restrict__ posm,
+                                                    const bh_d4* __restrict__ P) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int E = min(info->n_entries, rec_cap);
+  if (e >= E) return;
+  const bh_node r = rec[e];
+  const int lo = __float_as_int(r.x), hi = __float_as_int(r.y);
+  er_lo[e] = lo;
+  er_hi[e] = hi;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r.kind == BH_KIND_BODY) {
+    const bh_frec d = frec_get(frec, e);
+    o = make_float4(d.x, d.y, d.z, posm[lo].w);
+  } else if (r.kind != BH_KIND_PAD) {
+    const bh_d4 p1 = P[hi], p0 = P[lo];
+    const double M = p1.m - p0.m;
+    const double sx = p1.x - p0.x, sy = p1.y - p0.y, sz = p1.z - p0.z;
+    const float mass = (float)M;
+    o.w = mass;
+    if (mass > 1e-6f) {  // ref:180
+      o.x = (float)(sx / M);
+      o.y = (float)(sy / M);
+      o.z = (float)(sz / M);
+    } else {
+      o.x = (float)sx;
+      o.y = (float)sy;
+      o.z = (float)sz;
+    }
+  }
+  *reinterpret_cast<float4*>(&rec[e]) = o;
 }
 
 }  // namespace
@@ -1251,6 +1292,7 @@ extern "C" int bh_debug_tree_trace(void* out) {
 hipError_t bhk_build(bh_ctx* c) {
   const int n = c->n;
   c->rec_proto = true;  // records carry their body range in x / y until the (canonical) COM stage has run
+  c->com_digests = false;
   const u64* k = c->keys[c->key_buf];
   // every 2^ss-th key, at most kSampMax of them: bisection seeds of the wide-cell searches
   int ss = 12;
@@ -1290,12 +1332,24 @@ hipError_t bhk_com(bh_ctx* c) {
 // build's form (body range in x / y) until a stage call (bh_com) or a canonical step rewrites them
 hipError_t bhk_com_records(bh_ctx* c, bool canonical) {
   const int blocks = (c->rec_cap + 255) / 256;
+  // (a digest-only pass on records that are already canonical cannot happen: every caller builds first)
+  const int proto = c->rec_proto ? 1 : 0;
   if (canonical)
     com_kernel<true><<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info,
-                                                    c->rec_cap, c->posm[c->cur], c->P);
+                                                    c->rec_cap, c->posm[c->cur], c->P, proto);
   else
     com_kernel<false><<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info,
-                                                     c->rec_cap, c->posm[c->cur], c->P);
-  c->rec_proto = !canonical;
+                                                     c->rec_cap, c->posm[c->cur], c->P, proto);
+  if (canonical) c->rec_proto = false;
+  c->com_digests = true;
+  return hipGetLastError();
+}
+
+// bh_download_tree after a digest-only step: make the records canonical now (canon_kernel)
+hipError_t bhk_canonical_records(bh_ctx* c) {
+  if (!c->rec_proto) return hipSuccess;
+  canon_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->frec, c->er_lo, c->er_hi, c->info,
+                                                                c->rec_cap, c->posm[c->cur], c->P);
+  c->rec_proto = false;
   return hipGetLastError();
 }

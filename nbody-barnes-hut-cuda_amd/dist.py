@@ -172,10 +172,9 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
         return e.download_order()
 
 
-import os as _os
 # X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
-# (BH_DD_LET_MODE=0 selects round 2's all-gather of the union for A/B)
-LET_MODE_DEFAULT = int(_os.environ.get("BH_DD_LET_MODE", "1"))
+# (DomainStepper(..., let_mode=0) selects round 2's all-gather of the union; tools/dd_debug.py --let-mode 0 for A/B)
+LET_MODE_DEFAULT = 1
 
 
 class DomainLeft(RuntimeError):

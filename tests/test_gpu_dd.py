@@ -229,16 +229,30 @@ def test_dd_rank_failure_is_collective():
     assert "left the domain-decomposed step" in str(ei.value) or "overflow" in str(ei.value)
 
 
-def test_dd_config4_full_size_8_ranks_x_1M():
+def test_dd_config4_full_size_8_ranks_x_1M(orc):
     """BASELINE config 4 (8,000,000 bodies on 8 GPUs) rehearsed on this one GPU: 8 ranks x 1M bodies in
-    one process against a single 8M-body context, 2 steps.  Same canonical octree, so the forces agree to
-    summation order (the two-pass force adds the own and the remote part separately)."""
+    one process, 2 steps, against (a) the CPU oracle's step loop on the 8M bodies (ref:255-283 stage order; the
+    bounds of test_fullsize_k_steps_vs_oracle's 8M case: |dx| max <= 4.9e-4, |dv| p99.99 <= 6.1e-5, max <= 4.3e-4)
+    and (b) a single 8M-body context: same canonical octree, so the forces agree to summation order (the two-pass
+    force adds the own and the remote part separately)."""
     pkg = bhpkg.load()
     n = 8_000_000
     ic = pkg.plummer(n, seed=42)
     p1, v1, a1 = single(ic, 2)
     out = run_ranks(8, ic, 2)
     p, v, a = merge(out, n)
+    o = orc.Oracle(n)
+    o.upload(*ic)
+    o.step(2, order=orc.ORDER_BATCHED)
+    w = np.stack(o.download(), 1)
+    o.close()
+    dx = np.abs(p.astype(np.float64) - w[:, :3]).max(axis=1)
+    dv = np.abs(v.astype(np.float64) - w[:, 3:]).max(axis=1)
+    print(f"8 ranks x 1M vs oracle, K=2: |dx| p50 {np.median(dx):.3e} p99.99 {np.percentile(dx, 99.99):.3e} "
+          f"max {dx.max():.3e}; |dv| p50 {np.median(dv):.3e} p99.99 {np.percentile(dv, 99.99):.3e} max {dv.max():.3e}")
+    assert np.median(dx) <= 3.1e-5 and np.percentile(dx, 99.99) <= 1.3e-4 and dx.max() <= 4.9e-4
+    assert np.median(dv) <= 1e-6 and np.percentile(dv, 99.99) <= 6.1e-5 and dv.max() <= 4.3e-4
+    del w, dx, dv
     assert sum(o[-1] for o in out) == n
     e = rel(a, a1)
     assert np.median(e) < 2e-6, np.median(e)

@@ -194,6 +194,22 @@ def test_splitter_sort_gives_way_when_buckets_overflow(pkg, orc):
     r.close()
 
 
+def test_splitter_sort_gives_way_in_a_plain_step_loop(pkg):
+    """the same input in the loop INTEGRATION.md shows — bh_step + bh_sync per frame, bh_get_stats never polled in
+    between (round-3 review: the fall-back was only evaluated inside bh_get_stats): bh_sync reads the slow-bucket
+    count with the sticky flags, so the overfull bucket is met once, not in every step"""
+    n = 200000
+    x, y, z, vx, vy, vz, m = [a.copy() for a in pkg.plummer(n, seed=23)]
+    x[:120000] = 1.5; y[:120000] = -2.5; z[:120000] = 3.25
+    vx[:120000] = vy[:120000] = vz[:120000] = 0.0
+    e = _engine(pkg, (x, y, z, vx, vy, vz, m))
+    for _ in range(6):
+        e.step(); e.sync()
+    st = e.stats()
+    assert st.status_flags == 0 and 1 <= st.sort_slow_buckets <= 2   # step 2 (and at most the step in flight)
+    e.close()
+
+
 def test_splitter_sort_in_steps(pkg, orc):
     """automatic choice: the first sort after an upload is the radix sort, later steps use the splitter sort;
     the body order after 6 steps equals that of a context pinned to the radix sort, bit for bit"""
@@ -685,36 +701,79 @@ def test_stage_order_errors(pkg):
         pkg.Engine(10, key_bits=48)
 
 
-def test_canonical_tree_records_exist_when_asked_for(pkg, orc):
+@pytest.mark.parametrize("leaf_cap", [1, 4])
+def test_canonical_tree_records_exist_when_asked_for(pkg, orc, leaf_cap):
     """bh_step of the default engine writes only the force kernel's digests (the COM stage skips the canonical
-    x/y/z/m and body-range arrays: 24 B less traffic per record); bh_download_tree then refuses (BH_ERR_ORDER) until
-    the stage calls have built a canonical tree.  A strict_fp step keeps them (its kernel reads them), and the
-    canonical tree after stage calls that follow steps equals the oracle's."""
+    x/y/z/m and body-range arrays: 24 B less traffic per record).  The reference's d_nodes is readable after every
+    simulationStep (ref:266-281), so bh_download_tree produces the canonical records on demand (canon_kernel: the
+    step's prefix sums and digests are still there; the bodies have moved since, so a BODY record's position comes
+    from its digest).  Checked against (a) a second engine that reaches the same tree through the stage calls —
+    bit for bit, every field — and (b) the oracle's tree of that state.  After bh_build alone (no centre of mass
+    yet) the download still refuses."""
     n = 3000
     ic = pkg.plummer(n, seed=17)
-    e = _engine(pkg, ic)
+    e = _engine(pkg, ic, leaf_cap=leaf_cap)
     e.step(2)
-    with pytest.raises(pkg.BhError):
-        e.download_tree()
-    e.bbox(); e.morton(); e.sort(); e.build()
-    with pytest.raises(pkg.BhError):
-        e.download_tree()          # centres of mass not set yet
-    e.com()
-    rec = e.download_tree()
-    bodies = e.download_sorted_bodies()
-    p = oparams(orc, e.params)
-    state = [np.ascontiguousarray(a) for a in e.download()]
-    o = oracle_pipeline(orc, tuple(state) + (e.download_mass(),), p)
-    for f in ("kind", "first", "count"):
-        assert np.array_equal(rec[f], o["rec"][f]), f
-    assert np.array_equal(bodies[:, 0], o["xyzm"][:, 0])
+    rec_a = e.download_tree()       # tree of step 2, made canonical now
+    rec_a2 = e.download_tree()      # asking twice changes nothing
+    assert rec_a.tobytes() == rec_a2.tobytes()
     assert e.stats().status_flags == 0
-    e.close()
+    b = _engine(pkg, ic, leaf_cap=leaf_cap)
+    b.step(1)
+    state = [np.ascontiguousarray(a) for a in b.download()]
+    mass = b.download_mass()
+    b.bbox(); b.morton(); b.sort(); b.build()
+    with pytest.raises(pkg.BhError):
+        b.download_tree()           # centres of mass not set yet
+    b.com()
+    rec_b = b.download_tree()
+    assert len(rec_a) == len(rec_b)
+    for f in rec_b.dtype.names:
+        assert rec_a[f].tobytes() == rec_b[f].tobytes(), f
+    p = oparams(orc, b.params)
+    o = oracle_pipeline(orc, tuple(state) + (mass,), p)
+    for f in ("kind", "first", "count"):
+        assert np.array_equal(rec_a[f], o["rec"][f]), f
+    live = rec_a["kind"] != 3
+    scale = float(np.abs(o["rec"]["x"][live]).max())
+    for f in ("x", "y", "z"):
+        assert np.abs(rec_a[f][live] - o["rec"][f][live]).max() <= 4 * np.spacing(np.float32(scale)), f
+    assert np.allclose(rec_a["m"][live], o["rec"]["m"][live], rtol=1e-6)
+    # the step after an on-demand download is unaffected by it
+    e.step(1); b.force(); b.integrate(); b.step(1)
+    assert all(np.array_equal(u, v) for u, v in zip(e.download(), b.download()))
+    # the tree of a step survives the stage calls of the next one up to the sort (records made canonical in time)
+    e.bbox(); e.morton(); e.sort()
+    rec_c = e.download_tree()
+    assert (rec_c["kind"] == 1).sum() > 0 and np.isfinite(rec_c["x"]).all()
+    assert e.stats().status_flags == 0 and b.stats().status_flags == 0
+    e.close(); b.close()
     s = _engine(pkg, ic, strict_fp=1)
     s.step(2)
     rec2 = s.download_tree()       # a strict step reads the canonical records, so it writes them
     assert (rec2["kind"] == 1).sum() > 0 and np.isfinite(rec2["x"]).all()
     s.close()
+
+
+@pytest.mark.parametrize("leaf_cap", [1, 4])
+def test_com_stage_is_reentrant(pkg, leaf_cap):
+    """bh_com twice on one tree (round-3 review: the second call took a record's body range from the bit patterns of
+    x / y, which the first call had replaced by the centre of mass): same records, same accelerations, no flags."""
+    n = 5000
+    ic = pkg.plummer(n, seed=23)
+    e = _engine(pkg, ic, leaf_cap=leaf_cap)
+    e.tree_stages()
+    rec1 = e.download_tree()
+    e.force()
+    a1 = e.download_acc()
+    e.com(); e.com()
+    rec2 = e.download_tree()
+    e.force()
+    a2 = e.download_acc()
+    assert rec1.tobytes() == rec2.tobytes()
+    assert all(np.array_equal(u, v) for u, v in zip(a1, a2))
+    assert e.stats().status_flags == 0
+    e.close()
 
 
 @pytest.mark.parametrize("variant", [0])
