@@ -97,7 +97,8 @@ def issue_roofline(ws, simds, launch_ms):
     est_ms = (valu_cycles + c["scalar_in_context"] * scalar_insts) / simds / clock_hz * 1e3
     return {
         "counted_this_run": {"waves": int(waves), "record_pairs": int(pairs), "blocks": int(blocks),
-                             "pairs_with_opened_record": int(masked), "stack_entries_through_lanes": int(spills)},
+                             "pairs_with_opened_record": int(masked), "stack_entries_through_lanes": int(spills),
+                             "masked_pairs_nobody_takes": int(getattr(ws, "no_taker_pairs", 0))},
         "valu_insts_per_launch": valu_insts, "scalar_insts_per_launch": scalar_insts,
         "cycles_per_pair_valu": pair_cycles, "issue_cycles_per_form": c, "issue_cycles_provenance": ISSUE_PROVENANCE,
         "clock_ghz_in_kernel": ws.clock_ghz, "simds": simds,

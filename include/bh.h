@@ -90,7 +90,10 @@ typedef struct bh_params {
                             to the order of the children inside a block and of the bodies in memory; the
                             64-body groups of the force walk are more compact (-5 % force time).  30-bit keys
                             are always Morton (reference-literal code)                                */
-  int32_t reserved_;     /* 0 */
+  int32_t force_coop;    /* waves that share the walk of one group of bodies (round 4): 0 = by context size
+                            (as many, up to 8, as keep the launch within ~6 waves per SIMD: 2+ up to ~196,000 bodies),
+                            1 = one wave per group (the depth-first walk), 2..8.  Results are reproducible bit for
+                            bit for a given value; different values differ in the association of the fp32 sums   */
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:
@@ -189,7 +192,9 @@ typedef struct bh_walk_stats {
   uint64_t lane_spills;  /* stack entries that went through the cross-lane stack (3 v_writelane + 3 v_readlane
                             each); the others stayed in scalar registers from push to pop                 */
   uint64_t no_taker_pairs; /* of the masked pairs: those in which every active lane opens both records */
-  uint64_t reserved[2];
+  uint64_t fetch_wait_cycles; /* small-launch instance only: shader cycles, summed over waves and blocks, between the
+                                 issue of a child block's scalar loads and the arrival of its records       */
+  uint64_t reserved[1];
 } bh_walk_stats;
 int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out);
 

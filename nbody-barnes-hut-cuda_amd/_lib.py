@@ -21,7 +21,7 @@ class BhParams(C.Structure):
         ("strict_fp", C.c_int32), ("force_variant", C.c_int32), ("xcd_mode", C.c_int32),
         ("sort_variant", C.c_int32), ("literal_force", C.c_int32), ("force_block", C.c_int32),
         ("step_graph", C.c_int32), ("force_group", C.c_int32), ("key_curve", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("force_coop", C.c_int32),
     ]
 
 
@@ -49,7 +49,8 @@ class BhWalkStats(C.Structure):
     """struct bh_walk_stats: event counters of one launch of the default force walk (measurement)."""
     _fields_ = [("waves", C.c_uint64), ("pairs", C.c_uint64), ("blocks", C.c_uint64), ("masked_pairs", C.c_uint64),
                 ("clock_ghz", C.c_double), ("wave_cycles_max", C.c_double), ("wave_cycles_mean", C.c_double),
-                ("lane_spills", C.c_uint64), ("no_taker_pairs", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+                ("lane_spills", C.c_uint64), ("no_taker_pairs", C.c_uint64), ("fetch_wait_cycles", C.c_uint64),
+                ("reserved", C.c_uint64 * 1)]
 
 
 class BhDdSizes(C.Structure):

@@ -115,7 +115,7 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   if (p.key_bits != 63 && p.key_bits != 30) return BH_ERR_BAD_ARG;
   if (!(p.eps2 > 0.0f) || !(p.theta >= 0.0f) || p.leaf_cap < 1 || p.leaf_cap > 64 || p.max_depth < 0 ||
       p.force_variant < 0 || p.force_variant > 1 || p.sort_variant < 0 || p.sort_variant > 3 ||
-      p.key_curve < 0 || p.key_curve > 1 || p.xcd_mode < 0 || p.xcd_mode > 3)
+      p.key_curve < 0 || p.key_curve > 1 || p.xcd_mode < 0 || p.xcd_mode > 3 || p.force_coop < 0 || p.force_coop > 8)
     return BH_ERR_BAD_ARG;
   if (p.key_bits == 30) p.key_curve = 0;  // the reference-literal 30-bit code is a Morton code
 
@@ -404,11 +404,11 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
   memset(out, 0, sizeof(*out));
   const size_t W = (size_t)bhk_force_walk_rows(c);
   u32* rows = nullptr;
-  BH_HIP(c, hipMalloc((void**)&rows, W * 8 * sizeof(u32)));
-  std::vector<u32> h(W * 8);
-  hipError_t e = hipMemsetAsync(rows, 0, W * 8 * sizeof(u32), c->stream);
+  BH_HIP(c, hipMalloc((void**)&rows, W * BH_WALK_ROW * sizeof(u32)));
+  std::vector<u32> h(W * BH_WALK_ROW);
+  hipError_t e = hipMemsetAsync(rows, 0, W * BH_WALK_ROW * sizeof(u32), c->stream);
   if (e == hipSuccess) e = bhk_force_walk_stats(c, rows);
-  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), rows, W * 8 * sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), rows, W * BH_WALK_ROW * sizeof(u32), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(rows);
   if (e != hipSuccess) {
@@ -419,7 +419,7 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
   ghz.reserve(W);
   double cyc_max = 0, cyc_sum = 0;
   for (size_t w = 0; w < W; w++) {
-    const u32* r = &h[w * 8];
+    const u32* r = &h[w * BH_WALK_ROW];
     if (r[6] == 0) continue;
     out->waves++;
     out->pairs += r[0];
@@ -427,6 +427,7 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
     out->masked_pairs += r[2];
     out->lane_spills += r[3];
     out->no_taker_pairs += r[7];
+    out->fetch_wait_cycles += r[8];
     if (r[5]) ghz.push_back((double)r[4] / ((double)r[5] * 10.0));  // 100 MHz ticks -> ns
     cyc_max = r[4] > cyc_max ? (double)r[4] : cyc_max;
     cyc_sum += (double)r[4];

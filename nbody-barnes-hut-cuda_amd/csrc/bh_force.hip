@@ -66,14 +66,14 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 #define BH_XCD_RUN 64  // 16..64 measure alike at 1M bodies, 256 is 6 % slower, 2 is 2 % slower
 #endif
 constexpr int kXcdRun = BH_XCD_RUN;
-__device__ __forceinline__ int block_chunk(int mode) {
-  const int nb = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ int block_chunk_of(int mode, int b, int nb) {
   if (mode == 1) return b;
   const int xcd = b & 7, p = b >> 3;
   if (mode == 2) return ((p / kXcdRun) * 8 + xcd) * kXcdRun + (p % kXcdRun);
   const int q = nb >> 3, r = nb & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + p;
 }
+__device__ __forceinline__ int block_chunk(int mode) { return block_chunk_of(mode, blockIdx.x, gridDim.x); }
 
 struct WaveStack {  // entry j lives in lane (j & 63) of set (j >> 6)
   int f0, f1, f2;   // first child record
@@ -505,7 +505,17 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   ".if %c[stats] == 0\n"                                                                                  \
   "s_max_u32 s16, s16, " META "\n"                                                                        \
   ".endif\n"                                                                                              \
-  ".if %c[pf]\n"      /* small launches: straight into the lanes (see BH_POP_TAIL) */                      \
+  ".if %c[coop]\n"    /* cooperative walk: append to this wave's list of the next level (LDS, 16-byte entries) */ \
+  "v_mov_b32 v52, " LINK "\n"                                                                             \
+  "v_mov_b32 v53, " MLO "\n"                                                                              \
+  "v_mov_b32 v54, " MHI "\n"                                                                              \
+  "v_mov_b32 v56, s22\n"                                                                                  \
+  "s_cmp_lt_u32 s22, s23\n"                                                                               \
+  "s_cbranch_scc0 2f\n"              /* list full: counted, not written (the group is redone) */          \
+  "ds_write_b96 v56, v[52:54]\n"                                                                          \
+  "2:\n"                                                                                                  \
+  "s_add_u32 s22, s22, 16\n"                                                                              \
+  ".elseif %c[pf]\n"  /* small launches: straight into the lanes (see BH_POP_TAIL) */                      \
   "s_mov_b32 m0, s30\n"                                                                                   \
   "s_add_u32 s30, s30, 1\n"                                                                               \
   ".if %c[stats] == 0\n"                                                                                  \
@@ -566,18 +576,61 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   BH_ARMS(1, BH_MK1, "s66", "s64", "s67", "s65") BH_ARMS(0, BH_MK0, "s50", "s48", "s51", "s49")
 // end of a block: pop the next one (the test of L_pop folded into the loop-back branch)
 #define BH_POP_TAIL                                                                                      \
+  ".if %c[coop]\n s_branch L_centry_%=\n .else\n"                                                         \
   ".if %c[pf] == 0\n s_cmp_lg_u32 s101, 0\n s_cbranch_scc1 L_take_%=\n .endif\n"                          \
-  "s_sub_u32 s30, s30, 1\n s_cbranch_scc0 L_popb_%=\n s_branch L_done_%=\n"
+  "s_sub_u32 s30, s30, 1\n s_cbranch_scc0 L_popb_%=\n s_branch L_done_%=\n .endif\n"
 // Dispatch on the child count c (s33) by a two-level branch tree — no jump table, no computed jump:
 //   c <= 4: two cache lines are fetched (always fetching four measured +1 %), entry PRO1 (c = 3, 4) or PRO0;
 //   c >= 5: four lines, entry PRO3 (c >= 7; c > 8 also trips the "more than 8 children" redo) or PRO2.
 // The second compare sits between the EXEC write and the wait for the loads.  A block of 0 children is never
 // built, and no record of such a block can be opened: the open test `thr2 >= d2` is false for a null record
 // (thr2 = -1) whatever d2 is, NaN included.
+#define BH_STAT_WAIT                                                                                     \
+  ".if %c[stats] && %c[pf]\n s_waitcnt lgkmcnt(0)\n s_memtime s[100:101]\n s_waitcnt lgkmcnt(0)\n"          \
+  "s_sub_u32 s24, s100, s22\n s_add_u32 vcc_hi, vcc_hi, s24\n .endif\n"
 #define BH_DISPATCH_SMALL                                                                                \
+  BH_STAT_WAIT                                                                                           \
   "s_mov_b64 exec, s[34:35]\n s_cmp_gt_u32 s33, 2\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro1_%=\n"
 #define BH_DISPATCH_BIG                                                                                  \
+  BH_STAT_WAIT                                                                                           \
   "s_mov_b64 exec, s[34:35]\n s_cmp_gt_u32 s33, 6\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro3_%=\n"
+
+// One child block, from the stack entry in s32 (link) / s[34:35] (lane mask) to the jump back for the next entry:
+// shared by the depth-first walk (fast_traverse_asm) and the cooperative level-by-level walk (coop_traverse_asm).
+#define BH_WALK_BODY                                                                                     \
+      "L_decode_%=:\n"                                                                                   \
+      "s_and_b32 s33, s32, 63\n"         /* child count */                                               \
+      "s_andn2_b32 s32, s32, 63\n"       /* byte offset of the block */                                  \
+      "L_block_%=:\n"                                                                                    \
+      ".if %c[stats] && %c[pf]\n"  /* measurement: shader clock from the fetch of a block to its arrival */ \
+      "s_memtime s[22:23]\n"                                                                             \
+      ".endif\n"                                                                                         \
+      ".if %c[use_budget]\n"                                                                             \
+      "s_sub_u32 s17, s17, 1\n"                                                                          \
+      "s_cbranch_scc1 L_done_%=\n"                                                                       \
+      ".endif\n"                                                                                         \
+      "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"                                               \
+      "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"                                              \
+      ".if %c[stats]\n"                                                                                  \
+      "s_add_u32 s17, s17, 1\n"   /* blocks popped */                                                    \
+      "s_add_u32 s24, s33, 1\n"                                                                          \
+      "s_lshr_b32 s24, s24, 1\n"                                                                         \
+      "s_min_u32 s24, s24, 4\n"                                                                          \
+      "s_add_u32 s16, s16, s24\n"  /* pairs evaluated */                                                 \
+      ".endif\n"                                                                                         \
+      "s_cmp_gt_u32 s33, 4\n"                                                                            \
+      "s_cbranch_scc1 L_big_%=\n"                                                                        \
+      BH_DISPATCH_SMALL                                                                                  \
+      BH_PRO_SMALL                                                                                       \
+      "L_big_%=:\n"                                                                                      \
+      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"                                             \
+      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"                                             \
+      BH_DISPATCH_BIG                                                                                    \
+      BH_PRO_BIG                                                                                         \
+      BH_SEG_ALL                                                                                         \
+      BH_POP_TAIL                                                                                        \
+      BH_SEGM_ALL                                                                                        \
+      BH_ARMS_ALL
 
 // Returns false if the 64-entry cross-lane stack overflowed or a block with more than 8 children was met
 // (unsplit cell of > 8 bodies); ax..az are then invalid and the caller redoes the wave.
@@ -591,7 +644,7 @@ template <bool BUDGET, bool STATS = false, bool PF = false>
 __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u64 m0, float px, float py,
                                                   float pz, float eps2, float& ax, float& ay, float& az,
                                                   int budget, bool& limit_hit, u32* st = nullptr) {
-  int maxsp, maxc, left, spills, notake = 0;
+  int maxsp, maxc, left, spills, notake = 0, waitcy = 0;
   u64 t0 = 0, r0 = 0;
   if (STATS) {
     t0 = __builtin_amdgcn_s_memtime();
@@ -617,7 +670,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_mov_b64 s[34:35], %[mask]\n"
       "s_mov_b32 s101, 0\n"              // no top-of-stack entry in scalar registers yet
       "s_mov_b32 s25, 0\n"
-      ".if %c[stats]\n s_mov_b32 vcc_lo, 0\n .endif\n"
+      ".if %c[stats]\n s_mov_b32 vcc_lo, 0\n s_mov_b32 vcc_hi, 0\n .endif\n"
       "s_branch L_block_%=\n"
       "L_take_%=:\n"                     // the entry pushed last is still in scalar registers
       "s_mov_b32 s32, s101\n"
@@ -628,36 +681,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "v_readlane_b32 s32, v48, s30\n"   // link
       "v_readlane_b32 s34, v50, s30\n"
       "v_readlane_b32 s35, v51, s30\n"
-      "L_decode_%=:\n"
-      "s_and_b32 s33, s32, 63\n"         // child count
-      "s_andn2_b32 s32, s32, 63\n"       // byte offset of the block
-      "L_block_%=:\n"
-      ".if %c[use_budget]\n"
-      "s_sub_u32 s17, s17, 1\n"
-      "s_cbranch_scc1 L_done_%=\n"
-      ".endif\n"
-      "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"
-      "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"
-      ".if %c[stats]\n"
-      "s_add_u32 s17, s17, 1\n"   // blocks popped
-      "s_add_u32 s24, s33, 1\n"
-      "s_lshr_b32 s24, s24, 1\n"
-      "s_min_u32 s24, s24, 4\n"
-      "s_add_u32 s16, s16, s24\n"  // pairs evaluated
-      ".endif\n"
-      "s_cmp_gt_u32 s33, 4\n"
-      "s_cbranch_scc1 L_big_%=\n"
-      BH_DISPATCH_SMALL
-      BH_PRO_SMALL
-      "L_big_%=:\n"
-      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"
-      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"
-      BH_DISPATCH_BIG
-      BH_PRO_BIG
-      BH_SEG_ALL
-      BH_POP_TAIL
-      BH_SEGM_ALL
-      BH_ARMS_ALL
+      BH_WALK_BODY
       "L_done_%=:\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_mov_b64 exec, s[28:29]\n"
@@ -668,12 +692,12 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "s_mov_b32 %[maxc], s16\n"
       "s_mov_b32 %[left], s17\n"
       "s_mov_b32 %[spl], s25\n"
-      ".if %c[stats]\n s_mov_b32 %[ntk], vcc_lo\n .endif\n"
+      ".if %c[stats]\n s_mov_b32 %[ntk], vcc_lo\n s_mov_b32 %[wcy], vcc_hi\n .endif\n"
       : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left),
-        [spl] "=s"(spills), [ntk] "=s"(notake)
+        [spl] "=s"(spills), [ntk] "=s"(notake), [wcy] "=s"(waitcy)
       : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
         [eps2] "s"(eps2), [budget] "s"(STATS ? 0 : budget), [use_budget] "n"(BUDGET && !STATS ? 1 : 0),
-        [stats] "n"(STATS ? 1 : 0), [pf] "n"(PF ? 1 : 0)
+        [stats] "n"(STATS ? 1 : 0), [pf] "n"(PF ? 1 : 0), [coop] "n"(0)
       : "memory", "vcc", "scc", "m0", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21",
         "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
         "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
@@ -693,6 +717,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
     st[4] = (u32)(t1 - t0);
     st[5] = (u32)(r1 - r0);
     st[6] = (u32)notake;  // vcc_lo: masked pairs without a taker
+    st[7] = (u32)waitcy;  // vcc_hi (PF instance only): shader cycles between the fetch of a block and its arrival
     limit_hit = false;
     return true;
   }
@@ -733,68 +758,12 @@ __device__ __forceinline__ float fuse_wave_max(float v) {
 // group of 32 folds the group's rows, the last of those folds the groups (bh_internal.h: fence-free hand-off).
 // One launch and 32 bytes per body less than force + integrate; the integrate kernel's 19 us (9 at 65,536 bodies)
 // become a few hundred instructions at the end of waves that finish at different times anyway.
-#ifdef BH_FORCE_TRACE  // tools/force_trace.py: per-wave start / end of walk on the 100 MHz clock, HW_ID, XCC_ID
-constexpr int kForceTraceRows = 1 << 18;
-__device__ u32 g_force_trace[kForceTraceRows * 4];
-#endif
-
-template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false>
-__global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict__ frec_g,
-                                                         const float4* posm,  // (FUSE: fz.posm is the same buffer)
-                                                         float4* __restrict__ acc, int lo, int hi, float G,
-                                                         float eps2, int xcd_mode,
-                                                         bh_devinfo* __restrict__ info, int root, int budget,
-                                                         int group, bh_fuse_args fz = bh_fuse_args{}) {
-  cfloat_t* frec = (cfloat_t*)frec_g;
-  const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  const int chunk = block_chunk(xcd_mode);
-  // waves never cooperate, so the workgroup may be 1, 2 or 4 waves (bh_params.force_block): a CU
-  // slot is released when its LAST wave retires, and per-wave work varies by +-30 %.
-  // group = bodies per wave: 64, or 32 (upper lanes idle) when the launch would not even put two waves on
-  // a SIMD — half the bodies walk a smaller union of records and two waves per SIMD hide each other's latency
-  const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * group + lane;
-  const bool valid = lane < group && i < hi;
-#ifdef BH_FORCE_TRACE
-  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
-#endif
-  float px, py, pz, pm;
-  {
-    const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
-    px = p.x; py = p.y; pz = p.z; pm = p.w;
-  }
-  float ax = 0.0f, ay = 0.0f, az = 0.0f;
-  const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
-  if (m0 == 0) return;  // (a wave without bodies: not one of fz.waves)
-  // 64 stack entries (one VGPR set, no set-select branches) cover every tree seen in practice; the
-  // rare wave that needs more redoes its walk with the 192-entry stack (>= the 7*21+1 bound)
-  bool ok, limit = false;
-  if (VARIANT == 0)
-    ok = fast_traverse_asm<BUDGET, false, PF>(frec_g, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit);
-  else
-    ok = fast_traverse<1, BUDGET>(frec, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit);
-  if (!ok && !limit) {
-    ax = ay = az = 0.0f;
-    if (lane == 0) atomicAdd(&info->redo_waves, 1);
-    if (!fast_traverse<3, BUDGET>(frec, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit) && !limit &&
-        lane == 0)
-      atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
-  }
-  if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
-  if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
-#ifdef BH_FORCE_TRACE
-  {
-    const int wv = chunk * (int)(blockDim.x >> 6) + wib;
-    if (lane == 0 && wv < kForceTraceRows) {
-      g_force_trace[wv * 4 + 0] = tr0;
-      g_force_trace[wv * 4 + 1] = (u32)__builtin_amdgcn_s_memrealtime();
-      g_force_trace[wv * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-      g_force_trace[wv * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-    }
-  }
-#endif
-  if (!FUSE) return;
-
+// FUSE epilogue of a force launch (force_fast_kernel, force_coop_kernel): the wave that holds the accelerations of
+// group `w` (one body per lane, `valid` lanes) integrates them (ref:227-249, the arithmetic of integrate_kernel in
+// bh_tree.hip, bit for bit) and the launch folds the min / max of the new positions into the next step's cube.
+__device__ __forceinline__ void fuse_integrate_and_fold(const bh_fuse_args& fz, int w, int i, bool valid, int lane,
+                                                        float px, float py, float pz, float pm, float ax, float ay,
+                                                        float az) {
   float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
   float mx[3] = {-1e10f, -1e10f, -1e10f};
   if (valid) {  // ref:227-249, source text, no contraction: v += a dt; clamp |v| to max_speed; p += v dt
@@ -823,7 +792,6 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
     mn[q] = fuse_wave_min(mn[q]);
     mx[q] = fuse_wave_max(mx[q]);
   }
-  const int w = chunk * (int)(blockDim.x >> 6) + wib;  // < fz.waves: the wave owns bodies
   const int g = w >> 5, gsize = min(32, fz.waves - (g << 5)), ngroups = (fz.waves + 31) >> 5;
   int last = 0;
   if (lane == 0) {
@@ -887,8 +855,337 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
   }
 }
 
+#ifdef BH_FORCE_TRACE  // tools/force_trace.py: per-wave start / end of walk on the 100 MHz clock, HW_ID, XCC_ID
+constexpr int kForceTraceRows = 1 << 18;
+__device__ u32 g_force_trace[kForceTraceRows * 4];
+#endif
+
+template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false>
+__global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict__ frec_g,
+                                                         const float4* posm,  // (FUSE: fz.posm is the same buffer)
+                                                         float4* __restrict__ acc, int lo, int hi, float G,
+                                                         float eps2, int xcd_mode,
+                                                         bh_devinfo* __restrict__ info, int root, int budget,
+                                                         int group, bh_fuse_args fz = bh_fuse_args{}) {
+  cfloat_t* frec = (cfloat_t*)frec_g;
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int chunk = block_chunk(xcd_mode);
+  // waves never cooperate, so the workgroup may be 1, 2 or 4 waves (bh_params.force_block): a CU
+  // slot is released when its LAST wave retires, and per-wave work varies by +-30 %.
+  // group = bodies per wave: 64, or 32 (upper lanes idle) when the launch would not even put two waves on
+  // a SIMD — half the bodies walk a smaller union of records and two waves per SIMD hide each other's latency
+  const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * group + lane;
+  const bool valid = lane < group && i < hi;
+#ifdef BH_FORCE_TRACE
+  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
+#endif
+  float px, py, pz, pm;
+  {
+    const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
+    px = p.x; py = p.y; pz = p.z; pm = p.w;
+  }
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
+  if (m0 == 0) return;  // (a wave without bodies: not one of fz.waves)
+  // 64 stack entries (one VGPR set, no set-select branches) cover every tree seen in practice; the
+  // rare wave that needs more redoes its walk with the 192-entry stack (>= the 7*21+1 bound)
+  bool ok, limit = false;
+  if (VARIANT == 0)
+    ok = fast_traverse_asm<BUDGET, false, PF>(frec_g, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit);
+  else
+    ok = fast_traverse<1, BUDGET>(frec, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit);
+  if (!ok && !limit) {
+    ax = ay = az = 0.0f;
+    if (lane == 0) atomicAdd(&info->redo_waves, 1);
+    if (!fast_traverse<3, BUDGET>(frec, root, m0, px, py, pz, eps2, ax, ay, az, budget, limit) && !limit &&
+        lane == 0)
+      atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
+  }
+  if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
+  if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
+#ifdef BH_FORCE_TRACE
+  {
+    const int wv = chunk * (int)(blockDim.x >> 6) + wib;
+    if (lane == 0 && wv < kForceTraceRows) {
+      g_force_trace[wv * 4 + 0] = tr0;
+      g_force_trace[wv * 4 + 1] = (u32)__builtin_amdgcn_s_memrealtime();
+      g_force_trace[wv * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+      g_force_trace[wv * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+  }
+#endif
+  if (!FUSE) return;
+
+  fuse_integrate_and_fold(fz, chunk * (int)(blockDim.x >> 6) + wib, i, valid, lane, px, py, pz, pm, ax, ay, az);
+}
+
+// ------------------------------------------------------------------ cooperative walk (K waves per group)
+// What bounds a launch that does not fill the GPU (round 4, tools/force_trace.py): a wave's walk is a chain pop ->
+// fetch -> evaluate that runs at its own pace — ~1,500 cycles per child block, three quarters of them waiting for the
+// scalar loads — whether it shares its SIMD with five other waves or with none (waves of a 1M-body launch started
+// into the drain live as long as those started into a full machine); a SIMD saturates at about six waves.  So a
+// launch of 1,024 groups on 1,024 SIMDs (65,536 bodies) runs at a sixth of the machine, and the last wave lifetime
+// of ANY launch is spent with the machine emptying.  Here the K waves of one workgroup share the walk of ONE group
+// of bodies, level by level: the entries (child block, lane mask) of a level sit in K lists in LDS — list w written
+// by wave w while it evaluated the level above —, wave j evaluates entries (j - w) mod K, + K, + 2K ... of list w,
+// accumulates the accepted records into its own partial accelerations and appends the opened children to its list
+// of the next level; one s_barrier per level.  Which wave evaluates which block is a pure function of the tree, the
+// group and K — no atomics, no arrival order —, and the K partial accelerations of a body are added in wave order
+// (coop_kernel), so results are reproducible bit for bit for a given K; against the one-wave walk (K = 1 order) they
+// differ by the association of the fp32 sums only (tests/test_gpu_parity.py::test_force_coop_*).
+// Per block the same code as the depth-first walk (BH_WALK_BODY); a push is 4 v_mov + ds_write_b96 instead of
+// 3 v_writelane, a pop ds_read_b96 + 3 v_readfirstlane instead of 3 v_readlane.
+// LDS per workgroup: 2 levels x K lists x kCoopSub bytes: [count, -, -, -][kCoopCap entries of 16 bytes].
+constexpr int kCoopSub = 2048;                     // bytes per list (power of two: immediate operand of the walk)
+constexpr int kCoopCap = kCoopSub / 16 - 1;        // 127 entries per wave and level; beyond: the group is redone
+constexpr int kCoopMaxK = 8;
+
+// One wave's share of the cooperative walk.  cur / nxt: LDS byte addresses of the two level buffers (cur holds the
+// root entry in list 0, every other count is zero; the caller has synchronised).  Returns false when a list
+// overflowed or a block of more than 8 children was met (ax..az are then partial sums of an incomplete walk).
+__device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u32 nxt, int K, int j, float px,
+                                                  float py, float pz, float eps2, float& ax, float& ay, float& az) {
+  int maxc;
+  asm volatile(
+      "s_mov_b64 s[20:21], %[base]\n"
+      "v_mov_b32 v16, %[px]\n"
+      "v_mov_b32 v17, %[py]\n"
+      "v_mov_b32 v18, %[pz]\n"
+      "v_mov_b32 v19, 0\n"
+      "v_mov_b32 v20, %[eps2]\n"
+      "v_mov_b32 v21, %[eps2]\n"
+      "v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
+      "s_mov_b32 s16, 0\n"
+      "s_mov_b32 s28, %[cur]\n"
+      "s_mov_b32 s29, %[nxt]\n"
+      "L_level_%=:\n"
+      "s_mov_b32 vcc_hi, 0\n"             // entries of this level, all lists
+      "s_mov_b32 s30, 0\n"                // list index w
+      "s_mov_b32 s25, s28\n"              // header of list w
+      "s_mul_i32 s22, %[j], %c[sub]\n"    // this wave's list of the next level: s22 next free entry, s23 its end
+      "s_add_u32 s22, s22, s29\n"
+      "s_add_u32 s22, s22, 16\n"
+      "s_add_u32 s23, s22, %c[capb]\n"
+      "L_sub_%=:\n"
+      "s_cmp_ge_u32 s30, %[K]\n"
+      "s_cbranch_scc1 L_lvlend_%=\n"
+      "v_mov_b32 v56, s25\n"
+      "ds_read_b32 v52, v56\n"
+      "s_sub_i32 s24, %[j], s30\n"        // first entry of list w for wave j: (j - w) mod K
+      "s_cmp_lt_i32 s24, 0\n"
+      "s_cselect_b32 s101, %[K], 0\n"
+      "s_add_u32 s24, s24, s101\n"
+      "s_lshl_b32 s24, s24, 4\n"
+      "s_add_u32 s101, s25, s24\n"
+      "s_add_u32 s101, s101, 16\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_readfirstlane_b32 s100, v52\n"   // entries in list w
+      "s_add_u32 vcc_hi, vcc_hi, s100\n"
+      "s_lshl_b32 s100, s100, 4\n"
+      "s_add_u32 s100, s100, s25\n"
+      "s_add_u32 s100, s100, 16\n"        // end of list w
+      "s_add_u32 s25, s25, %c[sub]\n"
+      "s_add_u32 s30, s30, 1\n"
+      "L_centry_%=:\n"
+      "s_cmp_ge_u32 s101, s100\n"
+      "s_cbranch_scc1 L_sub_%=\n"
+      "v_mov_b32 v56, s101\n"
+      "ds_read_b96 v[52:54], v56\n"
+      "s_lshl_b32 s24, %[K], 4\n"
+      "s_add_u32 s101, s101, s24\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_readfirstlane_b32 s32, v52\n"    // link
+      "v_readfirstlane_b32 s34, v53\n"    // lane mask
+      "v_readfirstlane_b32 s35, v54\n"
+      BH_WALK_BODY
+      "L_lvlend_%=:\n"
+      "s_mov_b64 exec, -1\n"
+      "s_cmp_eq_u32 vcc_hi, 0\n"          // an empty level: nobody pushed anything, every wave leaves here
+      "s_cbranch_scc1 L_done_%=\n"
+      "s_mul_i32 s24, %[j], %c[sub]\n"    // publish this wave's entry count of the next level
+      "s_add_u32 s24, s24, s29\n"
+      "s_sub_u32 s100, s22, s24\n"
+      "s_sub_u32 s100, s100, 16\n"
+      "s_lshr_b32 s100, s100, 4\n"
+      "s_cmp_gt_u32 s100, %c[cap]\n"      // list overflow: entries beyond the capacity were not written
+      "s_cselect_b32 s101, 1024, 0\n"
+      "s_max_u32 s16, s16, s101\n"
+      "s_min_u32 s100, s100, %c[cap]\n"
+      "v_mov_b32 v56, s24\n"
+      "v_mov_b32 v52, s100\n"
+      "ds_write_b32 v56, v52\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_barrier\n"
+      "s_mov_b32 s24, s28\n"              // swap the level buffers
+      "s_mov_b32 s28, s29\n"
+      "s_mov_b32 s29, s24\n"
+      "s_branch L_level_%=\n"
+      "L_done_%=:\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_add_f32 %[ax], v42, v43\n"
+      "v_add_f32 %[ay], v44, v45\n"
+      "v_add_f32 %[az], v46, v47\n"
+      "s_mov_b32 %[maxc], s16\n"
+      : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxc] "=s"(maxc)
+      : [base] "s"(frec), [cur] "s"(cur), [nxt] "s"(nxt), [K] "s"(K), [j] "s"(j), [px] "v"(px), [py] "v"(py),
+        [pz] "v"(pz), [eps2] "s"(eps2), [sub] "n"(kCoopSub), [capb] "n"(kCoopCap * 16), [cap] "n"(kCoopCap),
+        [use_budget] "n"(0), [stats] "n"(0), [pf] "n"(0), [coop] "n"(1)
+      : "memory", "vcc", "scc", "m0", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21",
+        "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
+        "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+        "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "v16", "v17",
+        "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",
+        "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v52", "v53",
+        "v54", "v55", "v56");
+  return maxc <= 8;
+}
+
+// One workgroup of K waves walks one group of `group` bodies (wave j of K; lds: coop_lds_bytes(K)).  Wave 0 adds
+// the K partial accelerations in wave order, stores them and — FUSE — integrates the group
+// (fuse_integrate_and_fold; g = the group's index in the launch).  A group whose walk overflowed a level list (or holds
+// an unsplit cell of more than 8 bodies) is redone by wave 0 with the generic depth-first loop: the same decision on
+// every run, so still reproducible.
+__host__ __device__ constexpr size_t coop_lds_bytes(int K) {
+  return (size_t)K * (2 * kCoopSub + 64 * 3 * sizeof(float) + sizeof(u32));
+}
+template <bool FUSE>
+__device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane, const float* __restrict__ frec_g,
+                                           const float4* posm, float4* __restrict__ acc, int lo, int hi, float eps2,
+                                           bh_devinfo* __restrict__ info, int g, int group, const bh_fuse_args& fz,
+                                           int trace_row) {
+  const int i = lo + g * group + lane;
+  const bool valid = lane < group && i < hi;
+#ifdef BH_FORCE_TRACE
+  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
+#endif
+  float px, py, pz, pm;
+  {
+    const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
+    px = p.x; py = p.y; pz = p.z; pm = p.w;
+  }
+  const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
+  if (m0 == 0) return;  // the whole workgroup: every wave holds the same bodies
+  // level buffers: [2][K][kCoopSub bytes]; then the partial accelerations [K][64][3] and K flags
+  u32* const lvl = coop_lds;
+  float* const part = reinterpret_cast<float*>(coop_lds + 2 * K * (kCoopSub / 4));
+  u32* const bad = coop_lds + 2 * K * (kCoopSub / 4) + K * 192;
+  if (threadIdx.x < (unsigned)K) {
+    lvl[threadIdx.x * (kCoopSub / 4)] = threadIdx.x == 0 ? 1u : 0u;  // level 0: the root in list 0
+    if (threadIdx.x == 0) {
+      lvl[4] = 1u;  // link of record 0: byte offset 0 | one record (root: record 0 of the pool)
+      lvl[5] = (u32)m0;
+      lvl[6] = (u32)(m0 >> 32);
+    }
+  }
+  __syncthreads();
+  const u32 cur = (u32)(size_t)(__attribute__((address_space(3))) u32*)lvl;
+  float ax, ay, az;
+  const bool ok = coop_traverse_asm(frec_g, cur, cur + (u32)K * kCoopSub, K, j, px, py, pz, eps2, ax, ay, az);
+#ifdef BH_FORCE_TRACE
+  if (lane == 0 && trace_row + j < kForceTraceRows) {
+    u32* r = g_force_trace + (size_t)(trace_row + j) * 4;
+    r[0] = tr0;
+    r[1] = (u32)__builtin_amdgcn_s_memrealtime();
+    r[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+  }
+#endif
+  part[(j * 64 + lane) * 3 + 0] = ax;
+  part[(j * 64 + lane) * 3 + 1] = ay;
+  part[(j * 64 + lane) * 3 + 2] = az;
+  if (lane == 0) bad[j] = ok ? 0u : 1u;
+  __syncthreads();
+  if (j != 0) return;
+  bool redo = false;
+  for (int w = 0; w < K; w++) redo = redo || bad[w] != 0u;
+  if (!redo) {
+    for (int w = 1; w < K; w++) {  // fixed order: wave 0 + wave 1 + ...
+      ax += part[(w * 64 + lane) * 3 + 0];
+      ay += part[(w * 64 + lane) * 3 + 1];
+      az += part[(w * 64 + lane) * 3 + 2];
+    }
+  } else {
+    bool limit = false;
+    ax = ay = az = 0.0f;
+    if (lane == 0) atomicAdd(&info->redo_waves, 1);
+    if (!fast_traverse<3, false>((cfloat_t*)frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit) && lane == 0)
+      atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
+  }
+  if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
+  if (FUSE) fuse_integrate_and_fold(fz, g, i, valid, lane, px, py, pz, pm, ax, ay, az);
+}
+
+// every group of the launch by K = blockDim.x / 64 waves (2..8): launches that would not fill the GPU otherwise
+template <bool FUSE>
+__global__ __launch_bounds__(512) void force_coop_kernel(const float* __restrict__ frec_g, const float4* posm,
+                                                         float4* __restrict__ acc, int lo, int hi, float eps2,
+                                                         int xcd_mode, bh_devinfo* __restrict__ info, int group,
+                                                         bh_fuse_args fz) {
+  extern __shared__ __attribute__((aligned(16))) u32 coop_lds[];
+  const int K = (int)(blockDim.x >> 6);
+  const int g = block_chunk(xcd_mode);  // one group per workgroup
+  coop_group<FUSE>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, lo, hi, eps2, info,
+                   g, group, fz, g * K);
+}
+
+// A launch that fills the GPU many times over still ends with one wave lifetime (~0.35 ms at 1M bodies) in which no
+// new wave can start and the machine runs empty: the last wave started lives as long as the first, and a SIMD needs
+// ~6 resident waves to be busy (tools/force_trace.py: the last wave of the 1M launch starts at 0.69 of its span).
+// So the launch is ordered big jobs first: workgroups [0, nbulk) are four independent waves with a 64-body group
+// each (the depth-first walk, groups [0, gb)), workgroups nbulk + t walk group gb + t with their four waves together
+// (coop_group: a quarter of the lifetime) — the hardware dispatches workgroups in index order, so the short jobs fill
+// the slots the long ones leave.  Which groups take which walk depends on the body count only.
+constexpr int kMixedK = 4;
+template <bool FUSE>
+__global__ __launch_bounds__(256) void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
+                                                          float4* __restrict__ acc, int hi, float eps2, int xcd_mode,
+                                                          bh_devinfo* __restrict__ info, int nbulk, int gb,
+                                                          bh_fuse_args fz) {
+  __shared__ __attribute__((aligned(16))) u32 coop_lds[coop_lds_bytes(kMixedK) / 4];
+  const int lane = threadIdx.x & 63;
+  const int wib = rfl((int)(threadIdx.x >> 6));
+  if ((int)blockIdx.x >= nbulk) {
+    const int t = (int)blockIdx.x - nbulk;
+    coop_group<FUSE>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
+                     gb + t * kMixedK);
+    return;
+  }
+  const int w = block_chunk_of(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group
+  if (w >= gb) return;
+  const int i = w * 64 + lane;  // (groups below gb are full: gb * 64 <= hi)
+#ifdef BH_FORCE_TRACE
+  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
+#endif
+  const float4 p = posm[i];  // ref:196
+  float px = p.x, py = p.y, pz = p.z;
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  const u64 m0 = ~0ull;
+  bool limit = false;
+  if (!fast_traverse_asm<false, false, false>(frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit)) {
+    ax = ay = az = 0.0f;
+    if (lane == 0) atomicAdd(&info->redo_waves, 1);
+    if (!fast_traverse<3, false>((cfloat_t*)frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit) && lane == 0)
+      atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
+  }
+  acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
+#ifdef BH_FORCE_TRACE
+  if (lane == 0 && w < kForceTraceRows) {
+    u32* r = g_force_trace + (size_t)w * 4;
+    r[0] = tr0;
+    r[1] = (u32)__builtin_amdgcn_s_memrealtime();
+    r[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+  }
+#endif
+  if (FUSE) fuse_integrate_and_fold(fz, w, i, true, lane, px, py, pz, p.w, ax, ay, az);
+}
+
 // measurement only (bh_force_walk_stats): the hand-scheduled walk with its event counters and clock stamps,
 // one row of 8 words per wave; accelerations are not stored
+constexpr int kWalkRow = BH_WALK_ROW;
 template <bool PF>
 __global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __restrict__ frec_g,
                                                                const float4* __restrict__ posm, int n, float eps2,
@@ -908,15 +1205,16 @@ __global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __re
   const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
   if (m0 == 0) return;
   bool limit;
-  u32 st[7];
+  u32 st[8];
   (void)fast_traverse_asm<false, true, PF>(frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit, st);
   const bool odd = __float_as_uint(ax + ay + az) == 0x7fc12345u;  // never: keeps the walk's arithmetic alive
   if (lane == 0 || odd) {
-    u32* r = rows + (size_t)wave * 8;
+    u32* r = rows + (size_t)wave * kWalkRow;
 #pragma unroll
     for (int k = 0; k < 6; k++) r[k] = st[k];
     r[6] = (u32)__popcll(m0);
     r[7] = st[6];
+    r[8] = st[7];
   }
 }
 
@@ -1019,7 +1317,38 @@ __global__ __launch_bounds__(256) void unpack_u32x3_kernel(const u32* __restrict
 // 0.317 / 0.251.  Results do not depend on the group size.
 static int force_group(const bh_ctx* c, int bodies) {
   if (c->p.force_group == 16 || c->p.force_group == 32 || c->p.force_group == 64) return c->p.force_group;
+  if (!c->dd && c->p.force_variant == 0 && c->p.force_coop != 1) return c->n <= 32 * 1024 ? 32 : 64;  // cooperative walk
   return bodies <= 20 * 1024 ? 16 : (bodies <= 56 * 1024 ? 32 : 64);
+}
+
+// Waves per group (bh_params.force_coop: 0 = by context size, 1 = one wave per group: the depth-first walk, 2..8).
+// Decided from the CONTEXT's body count, never from the range of one launch, so that a slab launch of a sharded step
+// (bh_force_range) gives every body the bits of the full launch.  Automatic: as many waves per 64-body group as keep
+// the launch within the ~6 waves per SIMD the walk saturates at.
+static int force_coop(const bh_ctx* c, int group) {
+  if (c->dd || c->p.force_variant != 0) return 1;
+  if (c->p.force_coop >= 1 && c->p.force_coop <= kCoopMaxK) return c->p.force_coop;
+  const long long groups = ((long long)c->n + group - 1) / group;
+  const long long slots = (long long)c->num_cus * 4 * 6;
+  const long long k = slots / (groups > 0 ? groups : 1);
+  return k >= kCoopMaxK ? kCoopMaxK : (k < 2 ? 1 : (int)k);
+}
+
+// Mixed launches (force_mixed_kernel): the bodies below this bound are walked one wave per 64-body group, the rest
+// four waves per group.  The short jobs have to refill what the long ones free while they drain — about half the
+// resident waves' worth of groups, whatever the launch size (profiles/r04_drain/: T = 3,072 groups on 256 CUs).
+// 0: every group cooperatively (K > 1: the launch does not fill the GPU); n: none (force_coop = 1, other walks).
+static int force_bulk_bodies(const bh_ctx* c, int group, int K) {
+  if (K > 1) return 0;
+  if (c->dd || c->p.force_variant != 0 || c->p.force_coop != 0 || group != 64) return c->n;
+  long long T = (long long)c->num_cus * 4 * 6 / 2;
+#ifdef BH_STUDY
+  static const int env_tail = getenv("BH_FORCE_TAIL") ? atoi(getenv("BH_FORCE_TAIL")) : -1;
+  if (env_tail >= 0) T = env_tail;
+#endif
+  const long long G = ((long long)c->n + 63) / 64;
+  const long long gb = (G - T > 0 ? G - T : 0) & ~3ll;  // whole workgroups of four one-wave groups
+  return T == 0 ? c->n : (int)(gb * 64);
 }
 
 // bh_params.xcd_mode 3 (default): interleaved runs when the launch has more waves than the GPU holds at once
@@ -1075,10 +1404,48 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
       constexpr int lds_pad = 0;
 #endif
       const int waves = (hi - lo + group - 1) / group;
-      if (fuse_integrate && fused && !debug_budget && c->p.force_variant == 0 && lo == 0 && hi == c->n &&
-          waves <= c->fuse_waves) {
-        const bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
-                              c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->bounds_next, waves};
+      // Which walk a group gets depends on the context's body count only (force_coop, force_bulk_bodies): bodies
+      // [0, bulk) in 64-body groups by one wave each, bodies [bulk, n) by K waves per group.
+      const int K = force_coop(c, group);
+      const int bulk = debug_budget ? c->n : force_bulk_bodies(c, group, K);
+      const bool full = lo == 0 && hi == c->n;
+      const bool fuse = fuse_integrate && fused && full && (c->n + group - 1) / group <= c->fuse_waves;
+      const bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
+                            c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->bounds_next, waves};
+      if (bulk > 0 && bulk < c->n && full) {  // big jobs first, short jobs last: force_mixed_kernel
+        const int gb = bulk / 64, tail = (c->n - bulk + 63) / 64;
+        const int mmode = resolve_xcd_mode(c, bulk, 64);
+        int nbulk = gb / 4;
+        if (mmode == 2) nbulk = (nbulk + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+        if (fuse)
+          force_mixed_kernel<true><<<nbulk + tail, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2,
+                                                                       mmode, c->info, nbulk, gb, fz);
+        else
+          force_mixed_kernel<false><<<nbulk + tail, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2,
+                                                                        mmode, c->info, nbulk, gb, bh_fuse_args{});
+        if (fuse) *fused = true;
+        return hipGetLastError();
+      }
+      if (hi > bulk) {  // groups of [max(lo, bulk), hi) by Kc waves each (force_coop_kernel): one workgroup per group
+        const int clo = lo > bulk ? lo : bulk;
+        const int Kc = K > 1 ? K : kMixedK;
+        int gc = (hi - clo + group - 1) / group;
+        const int cmode = resolve_xcd_mode(c, hi - clo, group);
+        if (cmode == 2) gc = (gc + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+        if (fuse && bulk == 0)
+          force_coop_kernel<true><<<gc, Kc * 64, coop_lds_bytes(Kc), c->stream>>>((const float*)c->frec, posm, c->acc,
+                                                                                 clo, hi, e2, cmode, c->info, group, fz);
+        else
+          force_coop_kernel<false><<<gc, Kc * 64, coop_lds_bytes(Kc), c->stream>>>(
+              (const float*)c->frec, posm, c->acc, clo, hi, e2, cmode, c->info, group, bh_fuse_args{});
+        if (fuse && bulk == 0) *fused = true;
+        if (lo >= bulk) return hipGetLastError();
+        hi = bulk;  // the rest by one wave per group, below
+        g2 = ((hi - lo + group - 1) / group * 64 + tpb - 1) / tpb;
+        if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+        fuse_integrate = false;
+      }
+      if (fuse_integrate && fuse && !debug_budget && c->p.force_variant == 0) {
         if (hi - lo <= kPrefetchMaxBodies)
           force_fast_kernel<0, false, true, true><<<g2, tpb, 0, c->stream>>>(
               (const float*)c->frec, posm, c->acc, lo, hi, G, e2, mode, c->info, 0, 0, group, fz);
@@ -1113,7 +1480,7 @@ int bhk_force_walk_rows(const bh_ctx* c) {
   const int group = force_group(c, c->n);
   return (c->n + group - 1) / group;
 }
-hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][8], device */) {
+hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][BH_WALK_ROW], device */) {
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
   const int mode = (c->p.xcd_mode == 1) ? 1 : 0;  // one row per wave in launch order: no grid padding here

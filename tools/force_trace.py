@@ -24,8 +24,18 @@ e = pkg.Engine(n, theta=theta)
 e.upload(*pkg.plummer(n, seed=42))
 e.step(steps)
 e.sync()
-group = 64 if n > 56 * 1024 else (32 if n > 20 * 1024 else 16)
-W = (n + group - 1) // group
+# rows of the launch the default engine makes (csrc/bh_force.hip: force_coop, force_bulk_bodies): one per wave
+G = (n + 63) // 64
+slots = 256 * 4 * 6
+T = int(os.environ.get("BH_FORCE_TAIL", slots // 2))
+if G <= slots // 2:          # every group by K waves
+    K = min(8, slots // G) if n > 32 * 1024 else min(8, slots // ((n + 31) // 32))
+    W = ((n + 63) // 64 if n > 32 * 1024 else (n + 31) // 32) * K
+else:
+    gb = max(G - T, 0) & ~3
+    W = G if (T == 0 or gb == 0) else gb + 4 * (G - gb)
+    if gb == 0 and T > 0:
+        W = 4 * G
 rows = np.zeros((W, 4), np.uint32)
 fn = pkg.lib.bh_debug_force_trace
 fn.restype = C.c_int
