@@ -89,8 +89,10 @@ def issue_roofline(ws, simds, launch_ms):
     pushes = blocks - waves
     pair_cycles = 3 * c["pk_add_sgpr"] + 6 * c["pk_fma"] + 2 * c["cmp_e64"] + 2 * c["rsq"] + 3 * c["pk_mul"]
     spills = float(getattr(ws, "lane_spills", 0))
-    valu_insts = 16 * pairs + 2 * masked + 6 * spills
-    valu_cycles = pair_cycles * pairs + 2 * c["cndmask_e64"] * masked + c["lane_rw"] * 6 * spills
+    skipped = float(getattr(ws, "no_taker_pairs", 0))  # pairs whose force half (3 v_pk_mul + 3 v_pk_fma) is not issued
+    valu_insts = 16 * pairs + 2 * masked + 6 * spills - 6 * skipped
+    valu_cycles = (pair_cycles * pairs + 2 * c["cndmask_e64"] * masked + c["lane_rw"] * 6 * spills
+                   - (3 * c["pk_mul"] + 3 * c["pk_fma"]) * skipped)
     scalar_insts = 2 * pairs + 13 * blocks + 9 * pushes
     clock_hz = ws.clock_ghz * 1e9
     floor_valu_ms = valu_cycles / simds / clock_hz * 1e3
@@ -98,7 +100,7 @@ def issue_roofline(ws, simds, launch_ms):
     return {
         "counted_this_run": {"waves": int(waves), "record_pairs": int(pairs), "blocks": int(blocks),
                              "pairs_with_opened_record": int(masked), "stack_entries_through_lanes": int(spills),
-                             "masked_pairs_nobody_takes": int(getattr(ws, "no_taker_pairs", 0))},
+                             "pairs_nobody_takes_force_half_skipped": int(skipped)},
         "valu_insts_per_launch": valu_insts, "scalar_insts_per_launch": scalar_insts,
         "cycles_per_pair_valu": pair_cycles, "issue_cycles_per_form": c, "issue_cycles_provenance": ISSUE_PROVENANCE,
         "clock_ghz_in_kernel": ws.clock_ghz, "simds": simds,
@@ -211,6 +213,8 @@ def main():
     ap.add_argument("--xcd-mode", type=int, default=3, help="tuning: block->chunk placement (bh_params.xcd_mode, 3 = automatic)")
     ap.add_argument("--leaf-cap", type=int, default=1, help="tuning: bodies per leaf (1 = reference intent)")
     ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
+    ap.add_argument("--force-coop", type=int, default=0,
+                    help="tuning: waves per group of the force walk (bh_params.force_coop; 0 = automatic, 1 = one wave per group)")
     ap.add_argument("--graph", action="store_true",
                     help="time bh_step replayed as a HIP graph (no per-stage event records inside the timed region; "
                          "the force-launch time of the roofline block then comes from 10 extra timed-stage steps)")
@@ -273,7 +277,7 @@ def main():
     def replicated():
         e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
                                         xcd_mode=args.xcd_mode,
-                                        leaf_cap=args.leaf_cap, force_block=args.force_block,
+                                        leaf_cap=args.leaf_cap, force_block=args.force_block, force_coop=args.force_coop,
                                         force_variant=args.force_variant, step_graph=1 if args.graph else 0)
         e.upload(*ic)
         return e, st

@@ -66,10 +66,11 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 #define BH_XCD_RUN 64  // 16..64 measure alike at 1M bodies, 256 is 6 % slower, 2 is 2 % slower
 #endif
 constexpr int kXcdRun = BH_XCD_RUN;
+template <int RUN = kXcdRun>
 __device__ __forceinline__ int block_chunk_of(int mode, int b, int nb) {
   if (mode == 1) return b;
   const int xcd = b & 7, p = b >> 3;
-  if (mode == 2) return ((p / kXcdRun) * 8 + xcd) * kXcdRun + (p % kXcdRun);
+  if (mode == 2) return ((p / RUN) * 8 + xcd) * RUN + (p % RUN);
   const int q = nb >> 3, r = nb & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + p;
 }
@@ -424,8 +425,8 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // v[30:35], rinv = v[28:29] / v[36:37], open masks s[18:19],s[14:15] / s[12:13],s[10:11]; v[38:39] d2,
 // v[40:41] f, v[42:47] six partial accumulators, v48 / v50 / v51 cross-lane stack (link, mask lo, mask hi),
 // s101 / s[22:23] its top entry.
-#define BH_S0 "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v28", "v29", "s[18:19]", "s[14:15]"
-#define BH_S1 "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v36", "v37", "s[12:13]", "s[10:11]"
+#define BH_S0 "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v28", "v29", "s[34:35]", "s[66:67]"
+#define BH_S1 "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v36", "v37", "s[50:51]", "s[82:83]"
 // MAC of the pair (X, Y, Z, THR0, THR1) into set (DX, DY, DZ, R, R0, R1, MA, MB)
 #define BH_M1(DX, X) "v_pk_add_f32 " DX ", " X ", v[16:17] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
 #define BH_M2(DY, Y) "v_pk_add_f32 " DY ", " Y ", v[16:17] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
@@ -435,7 +436,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_M7(MA, T0) "v_cmp_ge_f32_e64 " MA ", " T0 ", v38\n"
 #define BH_M8(MB, T1) "v_cmp_ge_f32_e64 " MB ", " T1 ", v39\n"
 #define BH_M9(R0, R1) "v_rsq_f32 " R0 ", v38\n v_rsq_f32 " R1 ", v39\n"
-#define BH_CHK(q, MA, MB) "s_or_b64 s[26:27], " MA ", " MB "\n s_cbranch_scc1 L_push" #q "_%=\n"
+#define BH_CHK(q, MA, MB) "s_or_b64 s[12:13], " MA ", " MB "\n s_cbranch_scc1 L_push" #q "_%=\n"
 #define BH_MAC_(q, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1)                                       \
   BH_M1(DX, X) BH_M2(DY, Y) BH_M3(DZ, Z) BH_M4(DX) BH_M5(DY) BH_M5(DZ) BH_M7(MA, T0) BH_M8(MB, T1)        \
   BH_M9(R0, R1) BH_CHK(q, MA, MB)
@@ -448,12 +449,8 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_F2(R) "v_pk_mul_f32 " R ", " R ", " R "\n"
 #define BH_F3(R) "v_pk_mul_f32 v[40:41], v[40:41], " R "\n"
 #define BH_FA(D, A) "v_pk_fma_f32 " A ", v[40:41], " D ", " A "\n"
-// (STATS: vcc_lo counts the masked pairs in which every active lane opens BOTH records — their force half is issued
-// for nothing)
-#define BH_FM(MA, MB)                                                                                    \
-  ".if %c[stats]\n s_and_b64 s[26:27], " MA ", " MB "\n s_xor_b64 s[26:27], s[26:27], exec\n"              \
-  "s_cmp_eq_u64 s[26:27], 0\n s_cselect_b32 s24, 1, 0\n s_add_u32 vcc_lo, vcc_lo, s24\n .endif\n"          \
-  "v_cndmask_b32_e64 v40, v40, 0, " MA "\n v_cndmask_b32_e64 v41, v41, 0, " MB "\n"
+// (STATS: vcc_lo counts the pairs in which every active lane opens BOTH records — their force half is skipped, BH_ARMS_)
+#define BH_FM(MA, MB) "v_cndmask_b32_e64 v40, v40, 0, " MA "\n v_cndmask_b32_e64 v41, v41, 0, " MB "\n"
 #define BH_SEG_(LBL, MASK, qm, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1) \
   LBL ":\n"                                                                                               \
   BH_M1(DX, X) BH_F1(GM, FR) BH_M2(DY, Y) BH_F2(FR) BH_M3(DZ, Z) BH_F3(FR) BH_M4(DX) MASK(FMA, FMB)       \
@@ -461,7 +458,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   BH_M8(MB, T1) BH_M9(R0, R1) BH_CHK(qm, MA, MB)
 #define BH_NOMASK(MA, MB) ""
 #define BH_SEG(q, qm, ...) BH_X(BH_SEG_, "L_seg" #q "_%=", BH_NOMASK, qm, __VA_ARGS__)
-#define BH_STAT_MASKED ".if %c[stats]\n s_add_u32 s31, s31, 1\n .endif\n"
+#define BH_STAT_MASKED ".if %c[stats]\n s_add_u32 s15, s15, 1\n .endif\n"
 #define BH_SEGM(q, qm, ...)                                                                              \
   "L_segm" #q "_%=:\n" BH_STAT_MASKED BH_X(BH_SEG_, "L_segmx" #q "_%=", BH_FM, qm, __VA_ARGS__)           \
   "s_branch L_seg" #qm "_%=\n"
@@ -473,7 +470,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // evaluate, and with few waves per SIMD the fetch latency (scalar loads served by the L2) is exposed.  A one-dword
 // scalar load brings a 64-byte line into the scalar data cache without needing a register window: the first two
 // lines of a child block (round 3, later: all four) are touched when the block is PUSHED (the last block pushed is the next one popped);
-// s100 is a dummy target.  Measured (force ms without / with): 16,384 bodies 0.150 / 0.145, 65,536 0.219 / 0.214,
+// s10 is a dummy target.  Measured (force ms without / with): 16,384 bodies 0.150 / 0.145, 65,536 0.219 / 0.214,
 // 125,000 0.272 / 0.263, 250,000 0.442 / 0.441, 1M 1.217 / 1.226 — on for launches of <= kPrefetchMaxBodies.
 // (Also touching the new stack top at every pop measured slower at every size: +0.4 % at 16k ... +5 % at 1M.)
 // All four lines of the block are touched (a block of 5-8 children is fetched as four pairs; touching only the first
@@ -482,20 +479,20 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // the two-line form (300,000 +3 %, 1M +9 % against the walk without prefetch).  -DBH_PF2: the two-line form.
 // (Touching the first line of EVERY child's block as soon as a block's records arrive: +8 ... +14 % at these sizes.)
 #ifndef BH_PF2
-#define BH_PF_MORE "s_load_dword s100, s[20:21], s24 offset:128\n s_load_dword s100, s[20:21], s24 offset:192\n"
+#define BH_PF_MORE "s_load_dword s10, s[20:21], s11 offset:128\n s_load_dword s10, s[20:21], s11 offset:192\n"
 #else
 #define BH_PF_MORE ""
 #endif
 #define BH_PF_PUSH(LINK)                                                                                 \
   ".if %c[pf]\n"                                                                                          \
-  "s_andn2_b32 s24, " LINK ", 63\n"                                                                        \
-  "s_load_dword s100, s[20:21], s24 offset:0\n"                                                           \
-  "s_load_dword s100, s[20:21], s24 offset:64\n"                                                          \
+  "s_andn2_b32 s11, " LINK ", 63\n"                                                                        \
+  "s_load_dword s10, s[20:21], s11 offset:0\n"                                                           \
+  "s_load_dword s10, s[20:21], s11 offset:64\n"                                                          \
   BH_PF_MORE                                                                                              \
   ".endif\n"
 // a stack entry = (link, lane mask): link = byte offset of the child block | its child count (bh_internal.h).
-// The TOP of the stack is kept in scalar registers (s101 link — 0: none —, s[22:23] mask): a push first spills the
-// previous top into lane s30 of v48 / v50 / v51, a pop takes the scalar copy if there is one.  The entry a block
+// The TOP of the stack is kept in scalar registers (s10 link — 0: none —, s[22:23] mask): a push first spills the
+// previous top into lane s14 of v48 / v50 / v51, a pop takes the scalar copy if there is one.  The entry a block
 // pushes last is the next one popped, so it never touches the lanes: v_writelane / v_readlane cost ~5 cycles each in
 // this loop (6 per spilled entry), a scalar move ~1.25.  Same LIFO order, bit-identical results.  Measured (force
 // ms, lanes only / scalar top): 1M 1.175 / 1.164, theta 0.3 3.567 / 3.528, 500,000 0.676 / 0.674, 65,536 0.209 /
@@ -506,101 +503,122 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   "s_max_u32 s16, s16, " META "\n"                                                                        \
   ".endif\n"                                                                                              \
   ".if %c[coop]\n"    /* cooperative walk: append to this wave's list of the next level (LDS, 16-byte entries) */ \
+  "s_cmp_lt_u32 s22, s23\n"                                                                               \
+  "s_cbranch_scc0 2f\n"                                                                                   \
   "v_mov_b32 v52, " LINK "\n"                                                                             \
   "v_mov_b32 v53, " MLO "\n"                                                                              \
   "v_mov_b32 v54, " MHI "\n"                                                                              \
   "v_mov_b32 v56, s22\n"                                                                                  \
-  "s_cmp_lt_u32 s22, s23\n"                                                                               \
-  "s_cbranch_scc0 2f\n"              /* list full: counted, not written (the group is redone) */          \
   "ds_write_b96 v56, v[52:54]\n"                                                                          \
-  "2:\n"                                                                                                  \
   "s_add_u32 s22, s22, 16\n"                                                                              \
+  "s_branch 3f\n"                                                                                         \
+  "2:\n"                /* list full: the entry goes onto this wave's own cross-lane stack and is walked  */ \
+  "s_cmp_lt_u32 s14, 64\n" /* depth-first, children and all, before the wave takes its next list entry     */ \
+  "s_cbranch_scc0 4f\n"                                                                                   \
+  "s_mov_b32 s11, m0\n"                                                                                   \
+  "s_mov_b32 m0, s14\n"                                                                                   \
+  "s_add_u32 s14, s14, 1\n"                                                                               \
+  "v_writelane_b32 v48, " LINK ", m0\n"                                                                   \
+  "v_writelane_b32 v50, " MLO ", m0\n"                                                                    \
+  "v_writelane_b32 v51, " MHI ", m0\n"                                                                    \
+  "s_mov_b32 m0, s11\n"                                                                                   \
+  "s_branch 3f\n"                                                                                         \
+  "4:\n"                                                                                                  \
+  "s_max_u32 s16, s16, 1024\n" /* (64 entries there; beyond: the group is redone) */                       \
+  "3:\n"                                                                                                  \
   ".elseif %c[pf]\n"  /* small launches: straight into the lanes (see BH_POP_TAIL) */                      \
-  "s_mov_b32 m0, s30\n"                                                                                   \
-  "s_add_u32 s30, s30, 1\n"                                                                               \
+  "s_mov_b32 m0, s14\n"                                                                                   \
+  "s_add_u32 s14, s14, 1\n"                                                                               \
   ".if %c[stats] == 0\n"                                                                                  \
-  "s_max_u32 s31, s31, s30\n"                                                                             \
+  "s_max_u32 s15, s15, s14\n"                                                                             \
   ".else\n"                                                                                               \
-  "s_add_u32 s25, s25, 1\n"            /* every entry goes through the lanes in this form */               \
   ".endif\n"                                                                                              \
   "v_writelane_b32 v48, " LINK ", m0\n"                                                                   \
   "v_writelane_b32 v50, " MLO ", m0\n"                                                                    \
   "v_writelane_b32 v51, " MHI ", m0\n"                                                                    \
   ".else\n"                                                                                               \
-  "s_cmp_eq_u32 s101, 0\n"                                                                                \
+  "s_cmp_eq_u32 s10, 0\n"                                                                                \
   "s_cbranch_scc1 1f\n"                                                                                   \
-  "s_mov_b32 m0, s30\n"                                                                                   \
-  "s_add_u32 s30, s30, 1\n"                                                                               \
+  "s_mov_b32 m0, s14\n"                                                                                   \
+  "s_add_u32 s14, s14, 1\n"                                                                               \
   ".if %c[stats] == 0\n"                                                                                  \
-  "s_max_u32 s31, s31, s30\n"                                                                             \
+  "s_max_u32 s15, s15, s14\n"                                                                             \
   ".else\n"                                                                                               \
-  "s_add_u32 s25, s25, 1\n"            /* entries spilled to the lanes (each is read back once) */        \
+  "s_add_u32 vcc_hi, vcc_hi, 1\n"      /* entries spilled to the lanes (each is read back once) */        \
   ".endif\n"                                                                                              \
-  "v_writelane_b32 v48, s101, m0\n"                                                                       \
+  "v_writelane_b32 v48, s10, m0\n"                                                                       \
   "v_writelane_b32 v50, s22, m0\n"                                                                        \
   "v_writelane_b32 v51, s23, m0\n"                                                                        \
   "1:\n"                                                                                                  \
-  "s_mov_b32 s101, " LINK "\n"                                                                            \
+  "s_mov_b32 s10, " LINK "\n"                                                                            \
   "s_mov_b32 s22, " MLO "\n"                                                                              \
   "s_mov_b32 s23, " MHI "\n"                                                                              \
   ".endif\n" BH_PF_PUSH(LINK)
 // a pair with at least one opened record: push the opened one(s), then continue in the masked variant of its
 // force half.  MA / MB are the pair's OPEN masks (v_cmp_nlt under EXEC = the block's lane mask).
-#define BH_ARMS_(q, MA, MALO, MAHI, MB, MBLO, MBHI, F0, M0, F1, M1)                                       \
+// Both records opened: if every active lane opens both (a pair high above the group: 3.7 % of all pairs at 1M
+// bodies, bh_walk_stats.no_taker_pairs), nobody takes a monopole and the pair's force half — 6 packed
+// instructions and the two v_cndmask — is skipped: on to the MAC of the next pair (SKIP = its entry) or to the pop.
+#define BH_ARMS_(q, SKIP, MA, MALO, MAHI, MB, MBLO, MBHI, F0, M0, F1, M1)                                 \
   "L_push" #q "_%=:\n"                                                                                    \
   "s_cmp_eq_u64 " MA ", 0\n"                                                                              \
   "s_cbranch_scc1 L_pushB" #q "_%=\n" BH_PUSH1(F0, M0, MALO, MAHI)                                         \
   "s_cmp_eq_u64 " MB ", 0\n"                                                                              \
+  "s_cbranch_scc1 L_segm" #q "_%=\n" BH_PUSH1(F1, M1, MBLO, MBHI)                                          \
+  "s_and_b64 s[12:13], " MA ", " MB "\n"                                                                  \
+  "s_xor_b64 s[12:13], s[12:13], exec\n"                                                                  \
   "s_cbranch_scc1 L_segm" #q "_%=\n"                                                                      \
+  ".if %c[stats]\n s_add_u32 vcc_lo, vcc_lo, 1\n .endif\n"                                                \
+  "s_branch " SKIP "_%=\n"                                                                                \
   "L_pushB" #q "_%=:\n" BH_PUSH1(F1, M1, MBLO, MBHI)                                                      \
   "s_branch L_segm" #q "_%=\n"
 // pair p of the window: x s[36+16p:37+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11, meta +12/+13, link +14/+15
-#define BH_P0 "s[36:37]", "s[38:39]", "s[40:41]", "s44", "s45"
-#define BH_P1 "s[52:53]", "s[54:55]", "s[56:57]", "s60", "s61"
-#define BH_P2 "s[68:69]", "s[70:71]", "s[72:73]", "s76", "s77"
-#define BH_P3 "s[84:85]", "s[86:87]", "s[88:89]", "s92", "s93"
+#define BH_P0 "s[24:25]", "s[26:27]", "s[28:29]", "s32", "s33"
+#define BH_P1 "s[40:41]", "s[42:43]", "s[44:45]", "s48", "s49"
+#define BH_P2 "s[56:57]", "s[58:59]", "s[60:61]", "s64", "s65"
+#define BH_P3 "s[72:73]", "s[74:75]", "s[76:77]", "s80", "s81"
 #define BH_PRO_SMALL BH_PRO(0, BH_S0, BH_P0) BH_PRO(1, BH_S1, BH_P1)
 #define BH_PRO_BIG BH_PRO(2, BH_S0, BH_P2) "L_pro3_%=:\n" BH_MAC(3, BH_S1, BH_P3)
 #define BH_SEG_ALL                                                                                       \
-  BH_SEG(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEG(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)             \
-  BH_SEG(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0) BH_LAST("L_seg0_%=", BH_NOMASK, BH_S0, "s[42:43]")
+  BH_SEG(3, 2, BH_S1, "s[78:79]", BH_S0, BH_P2) BH_SEG(2, 1, BH_S0, "s[62:63]", BH_S1, BH_P1)             \
+  BH_SEG(1, 0, BH_S1, "s[46:47]", BH_S0, BH_P0) BH_LAST("L_seg0_%=", BH_NOMASK, BH_S0, "s[30:31]")
 #define BH_SEGM_ALL                                                                                      \
-  BH_SEGM(3, 2, BH_S1, "s[90:91]", BH_S0, BH_P2) BH_SEGM(2, 1, BH_S0, "s[74:75]", BH_S1, BH_P1)           \
-  BH_SEGM(1, 0, BH_S1, "s[58:59]", BH_S0, BH_P0)                                                          \
-  "L_segm0_%=:\n" BH_STAT_MASKED BH_LAST("L_segmx0_%=", BH_FM, BH_S0, "s[42:43]") BH_POP_TAIL
-#define BH_MK0 "s[18:19]", "s18", "s19", "s[14:15]", "s14", "s15"  // open masks of set 0 (even pairs)
-#define BH_MK1 "s[12:13]", "s12", "s13", "s[10:11]", "s10", "s11"  // set 1 (odd pairs)
+  BH_SEGM(3, 2, BH_S1, "s[78:79]", BH_S0, BH_P2) BH_SEGM(2, 1, BH_S0, "s[62:63]", BH_S1, BH_P1)           \
+  BH_SEGM(1, 0, BH_S1, "s[46:47]", BH_S0, BH_P0)                                                          \
+  "L_segm0_%=:\n" BH_STAT_MASKED BH_LAST("L_segmx0_%=", BH_FM, BH_S0, "s[30:31]") BH_POP_TAIL
+#define BH_MK0 "s[34:35]", "s34", "s35", "s[66:67]", "s66", "s67"  // open masks of set 0 (even pairs)
+#define BH_MK1 "s[50:51]", "s50", "s51", "s[82:83]", "s82", "s83"  // set 1 (odd pairs)
 #define BH_ARMS(...) BH_X(BH_ARMS_, __VA_ARGS__)
 #define BH_ARMS_ALL                                                                                      \
-  BH_ARMS(3, BH_MK1, "s98", "s96", "s99", "s97") BH_ARMS(2, BH_MK0, "s82", "s80", "s83", "s81")          \
-  BH_ARMS(1, BH_MK1, "s66", "s64", "s67", "s65") BH_ARMS(0, BH_MK0, "s50", "s48", "s51", "s49")
+  BH_ARMS(3, "L_pro2", BH_MK1, "s86", "s84", "s87", "s85") BH_ARMS(2, "L_pro1", BH_MK0, "s70", "s68", "s71", "s69") \
+  BH_ARMS(1, "L_pro0", BH_MK1, "s54", "s52", "s55", "s53") BH_ARMS(0, "L_tail", BH_MK0, "s38", "s36", "s39", "s37")
 // end of a block: pop the next one (the test of L_pop folded into the loop-back branch)
 #define BH_POP_TAIL                                                                                      \
-  ".if %c[coop]\n s_branch L_centry_%=\n .else\n"                                                         \
-  ".if %c[pf] == 0\n s_cmp_lg_u32 s101, 0\n s_cbranch_scc1 L_take_%=\n .endif\n"                          \
-  "s_sub_u32 s30, s30, 1\n s_cbranch_scc0 L_popb_%=\n s_branch L_done_%=\n .endif\n"
-// Dispatch on the child count c (s33) by a two-level branch tree — no jump table, no computed jump:
+  ".if %c[coop]\n s_cmp_eq_u32 s14, 0\n s_cbranch_scc1 L_centry_%=\n s_branch L_cpop_%=\n .else\n"           \
+  ".if %c[pf] == 0\n s_cmp_lg_u32 s10, 0\n s_cbranch_scc1 L_take_%=\n .endif\n"                          \
+  "s_sub_u32 s14, s14, 1\n s_cbranch_scc0 L_popb_%=\n s_branch L_done_%=\n .endif\n"
+// Dispatch on the child count c (s19) by a two-level branch tree — no jump table, no computed jump:
 //   c <= 4: two cache lines are fetched (always fetching four measured +1 %), entry PRO1 (c = 3, 4) or PRO0;
 //   c >= 5: four lines, entry PRO3 (c >= 7; c > 8 also trips the "more than 8 children" redo) or PRO2.
 // The second compare sits between the EXEC write and the wait for the loads.  A block of 0 children is never
 // built, and no record of such a block can be opened: the open test `thr2 >= d2` is false for a null record
 // (thr2 = -1) whatever d2 is, NaN included.
 #define BH_STAT_WAIT                                                                                     \
-  ".if %c[stats] && %c[pf]\n s_waitcnt lgkmcnt(0)\n s_memtime s[100:101]\n s_waitcnt lgkmcnt(0)\n"          \
-  "s_sub_u32 s24, s100, s22\n s_add_u32 vcc_hi, vcc_hi, s24\n .endif\n"
+  ".if %c[stats] && %c[pf]\n s_waitcnt lgkmcnt(0)\n s_memtime s[12:13]\n s_waitcnt lgkmcnt(0)\n"            \
+  "s_sub_u32 s11, s12, s22\n s_add_u32 vcc_hi, vcc_hi, s11\n .endif\n"
 #define BH_DISPATCH_SMALL                                                                                \
   BH_STAT_WAIT                                                                                           \
-  "s_mov_b64 exec, s[34:35]\n s_cmp_gt_u32 s33, 2\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro1_%=\n"
+  "s_cmp_gt_u32 s19, 2\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro1_%=\n"
 #define BH_DISPATCH_BIG                                                                                  \
   BH_STAT_WAIT                                                                                           \
-  "s_mov_b64 exec, s[34:35]\n s_cmp_gt_u32 s33, 6\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro3_%=\n"
+  "s_cmp_gt_u32 s19, 6\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro3_%=\n"
 
-// One child block, from the stack entry in s32 (link) / s[34:35] (lane mask) to the jump back for the next entry:
+// One child block, from the stack entry in s18 (link) / EXEC (lane mask) to the jump back for the next entry:
 // shared by the depth-first walk (fast_traverse_asm) and the cooperative level-by-level walk (coop_traverse_asm).
 #define BH_WALK_BODY                                                                                     \
       "L_decode_%=:\n"                                                                                   \
-      "s_and_b32 s33, s32, 63\n"         /* child count */                                               \
-      "s_andn2_b32 s32, s32, 63\n"       /* byte offset of the block */                                  \
+      "s_and_b32 s19, s18, 63\n"         /* child count */                                               \
+      "s_andn2_b32 s18, s18, 63\n"       /* byte offset of the block */                                  \
       "L_block_%=:\n"                                                                                    \
       ".if %c[stats] && %c[pf]\n"  /* measurement: shader clock from the fetch of a block to its arrival */ \
       "s_memtime s[22:23]\n"                                                                             \
@@ -609,25 +627,26 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
       "s_sub_u32 s17, s17, 1\n"                                                                          \
       "s_cbranch_scc1 L_done_%=\n"                                                                       \
       ".endif\n"                                                                                         \
-      "s_load_dwordx16 s[36:51], s[20:21], s32 offset:0\n"                                               \
-      "s_load_dwordx16 s[52:67], s[20:21], s32 offset:64\n"                                              \
+      "s_load_dwordx16 s[24:39], s[20:21], s18 offset:0\n"                                               \
+      "s_load_dwordx16 s[40:55], s[20:21], s18 offset:64\n"                                              \
       ".if %c[stats]\n"                                                                                  \
       "s_add_u32 s17, s17, 1\n"   /* blocks popped */                                                    \
-      "s_add_u32 s24, s33, 1\n"                                                                          \
-      "s_lshr_b32 s24, s24, 1\n"                                                                         \
-      "s_min_u32 s24, s24, 4\n"                                                                          \
-      "s_add_u32 s16, s16, s24\n"  /* pairs evaluated */                                                 \
+      "s_add_u32 s11, s19, 1\n"                                                                          \
+      "s_lshr_b32 s11, s11, 1\n"                                                                         \
+      "s_min_u32 s11, s11, 4\n"                                                                          \
+      "s_add_u32 s16, s16, s11\n"  /* pairs evaluated */                                                 \
       ".endif\n"                                                                                         \
-      "s_cmp_gt_u32 s33, 4\n"                                                                            \
+      "s_cmp_gt_u32 s19, 4\n"                                                                            \
       "s_cbranch_scc1 L_big_%=\n"                                                                        \
       BH_DISPATCH_SMALL                                                                                  \
       BH_PRO_SMALL                                                                                       \
       "L_big_%=:\n"                                                                                      \
-      "s_load_dwordx16 s[68:83], s[20:21], s32 offset:128\n"                                             \
-      "s_load_dwordx16 s[84:99], s[20:21], s32 offset:192\n"                                             \
+      "s_load_dwordx16 s[56:71], s[20:21], s18 offset:128\n"                                             \
+      "s_load_dwordx16 s[72:87], s[20:21], s18 offset:192\n"                                             \
       BH_DISPATCH_BIG                                                                                    \
       BH_PRO_BIG                                                                                         \
       BH_SEG_ALL                                                                                         \
+      "L_tail_%=:\n"                                                                                     \
       BH_POP_TAIL                                                                                        \
       BH_SEGM_ALL                                                                                        \
       BH_ARMS_ALL
@@ -636,22 +655,21 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // (unsplit cell of > 8 bodies); ax..az are then invalid and the caller redoes the wave.
 // BUDGET: at most `budget` child blocks are popped (a malformed pool cannot hang the wave); the walk then
 // stops and limit_hit is set.  `root` must be an even record index.
-// STATS (measurement only, result discarded): s16 / s17 / s31 count pairs evaluated / blocks popped / pairs that
-// took the masked path instead of tracking overflow, s25 the stack entries spilled to the lanes, and the walk is
+// STATS (measurement only, result discarded): s16 / s17 / s15 count pairs evaluated / blocks popped / pairs that
+// took the masked path instead of tracking overflow, vcc_hi the stack entries spilled to the lanes, and the walk is
 // stamped with s_memtime (shader clock) and s_memrealtime (100 MHz); st[0..5] = pairs, blocks, masked pairs,
 // spilled entries, shader cycles, 10-ns ticks, masked pairs in which no active lane takes either record.
 template <bool BUDGET, bool STATS = false, bool PF = false>
 __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u64 m0, float px, float py,
                                                   float pz, float eps2, float& ax, float& ay, float& az,
                                                   int budget, bool& limit_hit, u32* st = nullptr) {
-  int maxsp, maxc, left, spills, notake = 0, waitcy = 0;
+  int maxsp, maxc, left, notake = 0, waitcy = 0;
   u64 t0 = 0, r0 = 0;
   if (STATS) {
     t0 = __builtin_amdgcn_s_memtime();
     r0 = __builtin_amdgcn_s_memrealtime();
   }
   asm volatile(
-      "s_mov_b64 s[28:29], exec\n"
       "s_mov_b64 s[20:21], %[base]\n"
       "v_mov_b32 v16, %[px]\n"
       "v_mov_b32 v17, %[py]\n"
@@ -661,63 +679,64 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
       "v_mov_b32 v21, %[eps2]\n"
       "v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
       "v_mov_b32 v48, 0\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n"
-      "s_mov_b32 s30, 0\n"
-      "s_mov_b32 s31, 0\n"
+      "s_mov_b32 s14, 0\n"
+      "s_mov_b32 s15, 0\n"
       "s_mov_b32 s16, 0\n"
       "s_mov_b32 s17, %[budget]\n"
-      "s_lshl_b32 s32, %[root], 5\n"
-      "s_mov_b32 s33, 1\n"
-      "s_mov_b64 s[34:35], %[mask]\n"
-      "s_mov_b32 s101, 0\n"              // no top-of-stack entry in scalar registers yet
-      "s_mov_b32 s25, 0\n"
+      "s_lshl_b32 s18, %[root], 5\n"
+      "s_mov_b32 s19, 1\n"
+      "s_mov_b32 s10, 0\n"              // no top-of-stack entry in scalar registers yet
       ".if %c[stats]\n s_mov_b32 vcc_lo, 0\n s_mov_b32 vcc_hi, 0\n .endif\n"
+      "s_mov_b64 exec, %[mask]\n"        // EXEC = the lane mask of the entry, from its pop to the next
       "s_branch L_block_%=\n"
       "L_take_%=:\n"                     // the entry pushed last is still in scalar registers
-      "s_mov_b32 s32, s101\n"
-      "s_mov_b64 s[34:35], s[22:23]\n"
-      "s_mov_b32 s101, 0\n"
+      "s_mov_b32 s18, s10\n"
+      "s_mov_b64 exec, s[22:23]\n"
+      "s_mov_b32 s10, 0\n"
       "s_branch L_decode_%=\n"
       "L_popb_%=:\n"
-      "v_readlane_b32 s32, v48, s30\n"   // link
-      "v_readlane_b32 s34, v50, s30\n"
-      "v_readlane_b32 s35, v51, s30\n"
+      "v_readlane_b32 s18, v48, s14\n"   // link
+      "v_readlane_b32 s12, v50, s14\n"
+      "v_readlane_b32 s13, v51, s14\n"
+      "s_mov_b64 exec, s[12:13]\n"
       BH_WALK_BODY
       "L_done_%=:\n"
       "s_waitcnt lgkmcnt(0)\n"
-      "s_mov_b64 exec, s[28:29]\n"
+      "s_mov_b64 exec, -1\n"            // (every caller enters with all 64 lanes on)
       "v_add_f32 %[ax], v42, v43\n"
       "v_add_f32 %[ay], v44, v45\n"
       "v_add_f32 %[az], v46, v47\n"
-      "s_mov_b32 %[maxsp], s31\n"
+      "s_mov_b32 %[maxsp], s15\n"
       "s_mov_b32 %[maxc], s16\n"
       "s_mov_b32 %[left], s17\n"
-      "s_mov_b32 %[spl], s25\n"
       ".if %c[stats]\n s_mov_b32 %[ntk], vcc_lo\n s_mov_b32 %[wcy], vcc_hi\n .endif\n"
       : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxsp] "=s"(maxsp), [maxc] "=s"(maxc), [left] "=s"(left),
-        [spl] "=s"(spills), [ntk] "=s"(notake), [wcy] "=s"(waitcy)
+        [ntk] "=s"(notake), [wcy] "=s"(waitcy)
       : [base] "s"(frec), [root] "s"(root), [mask] "s"(m0), [px] "v"(px), [py] "v"(py), [pz] "v"(pz),
         [eps2] "s"(eps2), [budget] "s"(STATS ? 0 : budget), [use_budget] "n"(BUDGET && !STATS ? 1 : 0),
         [stats] "n"(STATS ? 1 : 0), [pf] "n"(PF ? 1 : 0), [coop] "n"(0)
-      : "memory", "vcc", "scc", "m0", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21",
-        "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
-        "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-        "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
-        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "v16", "v17",
-        "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",
-        "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
-        "v50", "v51");
+      : "memory", "vcc", "scc", "m0",
+        "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24",
+        "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
+        "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
+        "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+        "s85", "s86", "s87", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
+        "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
+        "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
   if (STATS) {
     const u64 t1 = __builtin_amdgcn_s_memtime();
     const u64 r1 = __builtin_amdgcn_s_memrealtime();
     st[0] = (u32)maxc;   // s16: pairs
     st[1] = (u32)left;   // s17: blocks
-    st[2] = (u32)maxsp;  // s31: masked pairs
-    st[3] = (u32)spills;  // s25: stack entries that went through the lanes
+    st[2] = (u32)maxsp;  // s15: masked pairs
+    // vcc_hi: the stack entries that went through the lanes (every push in the small-launch instance, where the
+    // register counts the fetch wait instead)
+    st[3] = PF ? (u32)left - 1u : (u32)waitcy;
     st[4] = (u32)(t1 - t0);
     st[5] = (u32)(r1 - r0);
     st[6] = (u32)notake;  // vcc_lo: masked pairs without a taker
-    st[7] = (u32)waitcy;  // vcc_hi (PF instance only): shader cycles between the fetch of a block and its arrival
+    st[7] = PF ? (u32)waitcy : 0u;  // vcc_hi (PF instance): shader cycles between the fetch of a block and its arrival
     limit_hit = false;
     return true;
   }
@@ -860,8 +879,12 @@ constexpr int kForceTraceRows = 1 << 18;
 __device__ u32 g_force_trace[kForceTraceRows * 4];
 #endif
 
+// BH_WALK_SGPRS: 7 waves per SIMD instead of 6 — a gfx950 SIMD holds floor(800 / (16-aligned SGPR count + 16)) waves
+// (tools/ubench_occ.hip: highest register s72 -> 8 waves, s76 .. s88 -> 7, s92 and above -> 6); the walk's registers
+// end at s87 and the compiler keeps the rest of the kernel below that too
+#define BH_WALK_SGPRS __attribute__((amdgpu_num_sgpr(96)))
 template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false>
-__global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict__ frec_g,
+__global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const float* __restrict__ frec_g,
                                                          const float4* posm,  // (FUSE: fz.posm is the same buffer)
                                                          float4* __restrict__ acc, int lo, int hi, float G,
                                                          float eps2, int xcd_mode,
@@ -937,13 +960,16 @@ __global__ __launch_bounds__(256) void force_fast_kernel(const float* __restrict
 // Per block the same code as the depth-first walk (BH_WALK_BODY); a push is 4 v_mov + ds_write_b96 instead of
 // 3 v_writelane, a pop ds_read_b96 + 3 v_readfirstlane instead of 3 v_readlane.
 // LDS per workgroup: 2 levels x K lists x kCoopSub bytes: [count, -, -, -][kCoopCap entries of 16 bytes].
-constexpr int kCoopSub = 2048;                     // bytes per list (power of two: immediate operand of the walk)
-constexpr int kCoopCap = kCoopSub / 16 - 1;        // 127 entries per wave and level; beyond: the group is redone
+// (list size = 1 << SUBSH bytes, SUBSH 11 / 12 / 13: 127 / 255 / 511 entries per wave and level; the product uses 11 — the entries of a
+// level grow like theta^-3, see force_coop_subsh; an entry a full list cannot take is walked depth-first by its wave)
 constexpr int kCoopMaxK = 8;
+__host__ __device__ constexpr int coop_sub(int subsh) { return 1 << subsh; }
+__host__ __device__ constexpr int coop_cap(int subsh) { return (1 << subsh) / 16 - 1; }
 
 // One wave's share of the cooperative walk.  cur / nxt: LDS byte addresses of the two level buffers (cur holds the
 // root entry in list 0, every other count is zero; the caller has synchronised).  Returns false when a list
 // overflowed or a block of more than 8 children was met (ax..az are then partial sums of an incomplete walk).
+template <int SUBSH>
 __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u32 nxt, int K, int j, float px,
                                                   float py, float pz, float eps2, float& ax, float& ay, float& az) {
   int maxc;
@@ -956,70 +982,82 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
       "v_mov_b32 v20, %[eps2]\n"
       "v_mov_b32 v21, %[eps2]\n"
       "v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
+      "v_mov_b32 v48, 0\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n"
       "s_mov_b32 s16, 0\n"
-      "s_mov_b32 s28, %[cur]\n"
-      "s_mov_b32 s29, %[nxt]\n"
+      "s_mov_b32 s14, 0\n"                // entries on this wave's own stack (children a full list did not take)
+      "s_mov_b32 s17, %[cur]\n"
+      "s_mov_b32 vcc_lo, %[nxt]\n"
+      "v_mbcnt_lo_u32_b32 v57, -1, 0\n"
+      "v_mbcnt_hi_u32_b32 v57, -1, v57\n"
+      "v_lshlrev_b32 v57, %c[subsh], v57\n" // lane l: byte offset of list l in a level buffer
       "L_level_%=:\n"
+      "s_bfm_b64 exec, %[K], 0\n"         // lanes 0 .. K-1 fetch the K entry counts of this level: lane w = list w
+      "v_add_u32 v56, s17, v57\n"
+      "ds_read_b32 v58, v56\n"
+      "s_mov_b64 exec, -1\n"
       "s_mov_b32 vcc_hi, 0\n"             // entries of this level, all lists
-      "s_mov_b32 s30, 0\n"                // list index w
-      "s_mov_b32 s25, s28\n"              // header of list w
+      "s_mov_b32 m0, 0\n"                 // list index w
       "s_mul_i32 s22, %[j], %c[sub]\n"    // this wave's list of the next level: s22 next free entry, s23 its end
-      "s_add_u32 s22, s22, s29\n"
+      "s_add_u32 s22, s22, vcc_lo\n"
       "s_add_u32 s22, s22, 16\n"
       "s_add_u32 s23, s22, %c[capb]\n"
+      "s_waitcnt lgkmcnt(0)\n"
       "L_sub_%=:\n"
-      "s_cmp_ge_u32 s30, %[K]\n"
+      "s_cmp_ge_u32 m0, %[K]\n"
       "s_cbranch_scc1 L_lvlend_%=\n"
-      "v_mov_b32 v56, s25\n"
-      "ds_read_b32 v52, v56\n"
-      "s_sub_i32 s24, %[j], s30\n"        // first entry of list w for wave j: (j - w) mod K
-      "s_cmp_lt_i32 s24, 0\n"
-      "s_cselect_b32 s101, %[K], 0\n"
-      "s_add_u32 s24, s24, s101\n"
-      "s_lshl_b32 s24, s24, 4\n"
-      "s_add_u32 s101, s25, s24\n"
-      "s_add_u32 s101, s101, 16\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      "v_readfirstlane_b32 s100, v52\n"   // entries in list w
-      "s_add_u32 vcc_hi, vcc_hi, s100\n"
-      "s_lshl_b32 s100, s100, 4\n"
-      "s_add_u32 s100, s100, s25\n"
-      "s_add_u32 s100, s100, 16\n"        // end of list w
-      "s_add_u32 s25, s25, %c[sub]\n"
-      "s_add_u32 s30, s30, 1\n"
+      "s_sub_i32 s11, %[j], m0\n"         // first entry of list w for wave j: (j - w) mod K
+      "s_cmp_lt_i32 s11, 0\n"
+      "s_cselect_b32 s10, %[K], 0\n"
+      "s_add_u32 s11, s11, s10\n"
+      "s_lshl_b32 s11, s11, 4\n"
+      "s_lshl_b32 s10, m0, %c[subsh]\n"
+      "s_add_u32 s10, s10, s17\n"      // header of list w
+      "v_readlane_b32 s15, v58, m0\n"    // entries in list w
+      "s_add_u32 vcc_hi, vcc_hi, s15\n"
+      "s_lshl_b32 s15, s15, 4\n"
+      "s_add_u32 s15, s15, s10\n"
+      "s_add_u32 s15, s15, 16\n"        // end of list w
+      "s_add_u32 s10, s10, s11\n"
+      "s_add_u32 s10, s10, 16\n"        // this wave's first entry in it
+      "s_add_u32 m0, m0, 1\n"
       "L_centry_%=:\n"
-      "s_cmp_ge_u32 s101, s100\n"
+      "s_cmp_ge_u32 s10, s15\n"
       "s_cbranch_scc1 L_sub_%=\n"
-      "v_mov_b32 v56, s101\n"
+      "v_mov_b32 v56, s10\n"
       "ds_read_b96 v[52:54], v56\n"
-      "s_lshl_b32 s24, %[K], 4\n"
-      "s_add_u32 s101, s101, s24\n"
+      "s_lshl_b32 s11, %[K], 4\n"
+      "s_add_u32 s10, s10, s11\n"
       "s_waitcnt lgkmcnt(0)\n"
-      "v_readfirstlane_b32 s32, v52\n"    // link
-      "v_readfirstlane_b32 s34, v53\n"    // lane mask
-      "v_readfirstlane_b32 s35, v54\n"
+      "v_readfirstlane_b32 s18, v52\n"    // link
+      "v_readfirstlane_b32 s12, v53\n"    // lane mask
+      "v_readfirstlane_b32 s13, v54\n"
+      "s_mov_b64 exec, s[12:13]\n"
+      "s_branch L_decode_%=\n"
+      "L_cpop_%=:\n"                     // an entry of this wave's own stack (its list was full)
+      "s_sub_u32 s14, s14, 1\n"
+      "v_readlane_b32 s18, v48, s14\n"
+      "v_readlane_b32 s12, v50, s14\n"
+      "v_readlane_b32 s13, v51, s14\n"
+      "s_mov_b64 exec, s[12:13]\n"
       BH_WALK_BODY
       "L_lvlend_%=:\n"
       "s_mov_b64 exec, -1\n"
       "s_cmp_eq_u32 vcc_hi, 0\n"          // an empty level: nobody pushed anything, every wave leaves here
       "s_cbranch_scc1 L_done_%=\n"
-      "s_mul_i32 s24, %[j], %c[sub]\n"    // publish this wave's entry count of the next level
-      "s_add_u32 s24, s24, s29\n"
-      "s_sub_u32 s100, s22, s24\n"
-      "s_sub_u32 s100, s100, 16\n"
-      "s_lshr_b32 s100, s100, 4\n"
-      "s_cmp_gt_u32 s100, %c[cap]\n"      // list overflow: entries beyond the capacity were not written
-      "s_cselect_b32 s101, 1024, 0\n"
-      "s_max_u32 s16, s16, s101\n"
-      "s_min_u32 s100, s100, %c[cap]\n"
-      "v_mov_b32 v56, s24\n"
-      "v_mov_b32 v52, s100\n"
+      "s_mul_i32 s11, %[j], %c[sub]\n"    // publish this wave's entry count of the next level
+      "s_add_u32 s11, s11, vcc_lo\n"
+      "s_sub_u32 s15, s22, s11\n"
+      "s_sub_u32 s15, s15, 16\n"
+      "s_lshr_b32 s15, s15, 4\n"
+
+      "v_mov_b32 v56, s11\n"
+      "v_mov_b32 v52, s15\n"
       "ds_write_b32 v56, v52\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_barrier\n"
-      "s_mov_b32 s24, s28\n"              // swap the level buffers
-      "s_mov_b32 s28, s29\n"
-      "s_mov_b32 s29, s24\n"
+      "s_mov_b32 s11, s17\n"              // swap the level buffers
+      "s_mov_b32 s17, vcc_lo\n"
+      "s_mov_b32 vcc_lo, s11\n"
       "s_branch L_level_%=\n"
       "L_done_%=:\n"
       "s_waitcnt lgkmcnt(0)\n"
@@ -1029,17 +1067,18 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
       "s_mov_b32 %[maxc], s16\n"
       : [ax] "=&v"(ax), [ay] "=&v"(ay), [az] "=&v"(az), [maxc] "=s"(maxc)
       : [base] "s"(frec), [cur] "s"(cur), [nxt] "s"(nxt), [K] "s"(K), [j] "s"(j), [px] "v"(px), [py] "v"(py),
-        [pz] "v"(pz), [eps2] "s"(eps2), [sub] "n"(kCoopSub), [capb] "n"(kCoopCap * 16), [cap] "n"(kCoopCap),
+        [pz] "v"(pz), [eps2] "s"(eps2), [sub] "n"(coop_sub(SUBSH)), [subsh] "n"(SUBSH), [capb] "n"(coop_cap(SUBSH) * 16),
+        [cap] "n"(coop_cap(SUBSH)),
         [use_budget] "n"(0), [stats] "n"(0), [pf] "n"(0), [coop] "n"(1)
-      : "memory", "vcc", "scc", "m0", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21",
-        "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
-        "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-        "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
-        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "v16", "v17",
-        "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",
-        "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v52", "v53",
-        "v54", "v55", "v56");
+      : "memory", "vcc", "scc", "m0",
+        "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24",
+        "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
+        "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
+        "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+        "s85", "s86", "s87", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
+        "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
+        "v43", "v44", "v45", "v46", "v47", "v48", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58");
   return maxc <= 8;
 }
 
@@ -1048,10 +1087,10 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
 // (fuse_integrate_and_fold; g = the group's index in the launch).  A group whose walk overflowed a level list (or holds
 // an unsplit cell of more than 8 bodies) is redone by wave 0 with the generic depth-first loop: the same decision on
 // every run, so still reproducible.
-__host__ __device__ constexpr size_t coop_lds_bytes(int K) {
-  return (size_t)K * (2 * kCoopSub + 64 * 3 * sizeof(float) + sizeof(u32));
+__host__ __device__ constexpr size_t coop_lds_bytes(int K, int subsh) {
+  return (size_t)K * (2 * coop_sub(subsh) + 64 * 3 * sizeof(float) + sizeof(u32));
 }
-template <bool FUSE>
+template <bool FUSE, int SUBSH>
 __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane, const float* __restrict__ frec_g,
                                            const float4* posm, float4* __restrict__ acc, int lo, int hi, float eps2,
                                            bh_devinfo* __restrict__ info, int g, int group, const bh_fuse_args& fz,
@@ -1069,6 +1108,7 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
   const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
   if (m0 == 0) return;  // the whole workgroup: every wave holds the same bodies
   // level buffers: [2][K][kCoopSub bytes]; then the partial accelerations [K][64][3] and K flags
+  constexpr int kCoopSub = coop_sub(SUBSH);
   u32* const lvl = coop_lds;
   float* const part = reinterpret_cast<float*>(coop_lds + 2 * K * (kCoopSub / 4));
   u32* const bad = coop_lds + 2 * K * (kCoopSub / 4) + K * 192;
@@ -1083,7 +1123,7 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
   __syncthreads();
   const u32 cur = (u32)(size_t)(__attribute__((address_space(3))) u32*)lvl;
   float ax, ay, az;
-  const bool ok = coop_traverse_asm(frec_g, cur, cur + (u32)K * kCoopSub, K, j, px, py, pz, eps2, ax, ay, az);
+  const bool ok = coop_traverse_asm<SUBSH>(frec_g, cur, cur + (u32)K * kCoopSub, K, j, px, py, pz, eps2, ax, ay, az);
 #ifdef BH_FORCE_TRACE
   if (lane == 0 && trace_row + j < kForceTraceRows) {
     u32* r = g_force_trace + (size_t)(trace_row + j) * 4;
@@ -1119,16 +1159,16 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
 }
 
 // every group of the launch by K = blockDim.x / 64 waves (2..8): launches that would not fill the GPU otherwise
-template <bool FUSE>
-__global__ __launch_bounds__(512) void force_coop_kernel(const float* __restrict__ frec_g, const float4* posm,
+template <bool FUSE, int SUBSH>
+__global__ __launch_bounds__(512) BH_WALK_SGPRS void force_coop_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                          float4* __restrict__ acc, int lo, int hi, float eps2,
                                                          int xcd_mode, bh_devinfo* __restrict__ info, int group,
                                                          bh_fuse_args fz) {
   extern __shared__ __attribute__((aligned(16))) u32 coop_lds[];
   const int K = (int)(blockDim.x >> 6);
   const int g = block_chunk(xcd_mode);  // one group per workgroup
-  coop_group<FUSE>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, lo, hi, eps2, info,
-                   g, group, fz, g * K);
+  coop_group<FUSE, SUBSH>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, lo, hi, eps2,
+                          info, g, group, fz, g * K);
 }
 
 // A launch that fills the GPU many times over still ends with one wave lifetime (~0.35 ms at 1M bodies) in which no
@@ -1139,21 +1179,24 @@ __global__ __launch_bounds__(512) void force_coop_kernel(const float* __restrict
 // (coop_group: a quarter of the lifetime) — the hardware dispatches workgroups in index order, so the short jobs fill
 // the slots the long ones leave.  Which groups take which walk depends on the body count only.
 constexpr int kMixedK = 4;
-template <bool FUSE>
-__global__ __launch_bounds__(256) void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
+constexpr int kMixedRun = 16;  // chunks (workgroups of four groups) per XCD run: 64 groups, as in the one-wave launch —
+                               // a run of 64 such chunks is 143 us of one XCD's time at 1M bodies, and the XCD that
+                               // holds one run more than the others ends the launch that much later
+template <bool FUSE, int SUBSH>
+__global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                           float4* __restrict__ acc, int hi, float eps2, int xcd_mode,
                                                           bh_devinfo* __restrict__ info, int nbulk, int gb,
                                                           bh_fuse_args fz) {
-  __shared__ __attribute__((aligned(16))) u32 coop_lds[coop_lds_bytes(kMixedK) / 4];
+  __shared__ __attribute__((aligned(16))) u32 coop_lds[coop_lds_bytes(kMixedK, SUBSH) / 4];
   const int lane = threadIdx.x & 63;
   const int wib = rfl((int)(threadIdx.x >> 6));
   if ((int)blockIdx.x >= nbulk) {
     const int t = (int)blockIdx.x - nbulk;
-    coop_group<FUSE>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
-                     gb + t * kMixedK);
+    coop_group<FUSE, SUBSH>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
+                            gb + t * kMixedK);
     return;
   }
-  const int w = block_chunk_of(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group
+  const int w = block_chunk_of<kMixedRun>(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group
   if (w >= gb) return;
   const int i = w * 64 + lane;  // (groups below gb are full: gb * 64 <= hi)
 #ifdef BH_FORCE_TRACE
@@ -1334,6 +1377,20 @@ static int force_coop(const bh_ctx* c, int group) {
   return k >= kCoopMaxK ? kCoopMaxK : (k < 2 ? 1 : (int)k);
 }
 
+// Level-list size of the cooperative walk (1 << subsh bytes per wave and level): 127 entries.  The entries of a level
+// are the cells the group's bodies open on it — the longest list any wave writes grows like theta^-3 and hardly with
+// the body count (K = 4, 1M Plummer: 76 at theta 0.5, 105 at 0.4, 170 at 0.3, 334 at 0.2; profiles/r04_coop/lists.txt);
+// what a full list does not take goes onto the wave's own stack (BH_PUSH1).  Larger lists cost the mixed launch its
+// occupancy (LDS is allocated per workgroup for the one-wave groups too: 35 KB instead of 19.5 -> 4 waves per SIMD).
+static int force_coop_subsh(const bh_ctx* c) {
+#ifdef BH_STUDY
+  static const int env = getenv("BH_COOP_SUBSH") ? atoi(getenv("BH_COOP_SUBSH")) : 0;
+  if (env >= 11 && env <= 13) return env;
+#endif
+  (void)c;
+  return 11;
+}
+
 // Mixed launches (force_mixed_kernel): the bodies below this bound are walked one wave per 64-body group, the rest
 // four waves per group.  The short jobs have to refill what the long ones free while they drain — about half the
 // resident waves' worth of groups, whatever the launch size (profiles/r04_drain/: T = 3,072 groups on 256 CUs).
@@ -1408,6 +1465,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
       // [0, bulk) in 64-body groups by one wave each, bodies [bulk, n) by K waves per group.
       const int K = force_coop(c, group);
       const int bulk = debug_budget ? c->n : force_bulk_bodies(c, group, K);
+      const int subsh = force_coop_subsh(c);
       const bool full = lo == 0 && hi == c->n;
       const bool fuse = fuse_integrate && fused && full && (c->n + group - 1) / group <= c->fuse_waves;
       const bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
@@ -1416,13 +1474,16 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
         const int gb = bulk / 64, tail = (c->n - bulk + 63) / 64;
         const int mmode = resolve_xcd_mode(c, bulk, 64);
         int nbulk = gb / 4;
-        if (mmode == 2) nbulk = (nbulk + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
-        if (fuse)
-          force_mixed_kernel<true><<<nbulk + tail, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2,
-                                                                       mmode, c->info, nbulk, gb, fz);
-        else
-          force_mixed_kernel<false><<<nbulk + tail, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2,
-                                                                        mmode, c->info, nbulk, gb, bh_fuse_args{});
+        if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
+#define BH_MIXED(F, S)                                                                                        \
+  force_mixed_kernel<F, S><<<nbulk + tail, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2, mmode, \
+                                                                c->info, nbulk, gb, F ? fz : bh_fuse_args{})
+        if (fuse) {
+          if (subsh == 11) BH_MIXED(true, 11); else if (subsh == 12) BH_MIXED(true, 12); else BH_MIXED(true, 13);
+        } else {
+          if (subsh == 11) BH_MIXED(false, 11); else if (subsh == 12) BH_MIXED(false, 12); else BH_MIXED(false, 13);
+        }
+#undef BH_MIXED
         if (fuse) *fused = true;
         return hipGetLastError();
       }
@@ -1432,12 +1493,15 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
         int gc = (hi - clo + group - 1) / group;
         const int cmode = resolve_xcd_mode(c, hi - clo, group);
         if (cmode == 2) gc = (gc + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
-        if (fuse && bulk == 0)
-          force_coop_kernel<true><<<gc, Kc * 64, coop_lds_bytes(Kc), c->stream>>>((const float*)c->frec, posm, c->acc,
-                                                                                 clo, hi, e2, cmode, c->info, group, fz);
-        else
-          force_coop_kernel<false><<<gc, Kc * 64, coop_lds_bytes(Kc), c->stream>>>(
-              (const float*)c->frec, posm, c->acc, clo, hi, e2, cmode, c->info, group, bh_fuse_args{});
+#define BH_COOP(F, S)                                                                                         \
+  force_coop_kernel<F, S><<<gc, Kc * 64, coop_lds_bytes(Kc, S), c->stream>>>(                                  \
+      (const float*)c->frec, posm, c->acc, clo, hi, e2, cmode, c->info, group, F ? fz : bh_fuse_args{})
+        if (fuse && bulk == 0) {
+          if (subsh == 11) BH_COOP(true, 11); else if (subsh == 12) BH_COOP(true, 12); else BH_COOP(true, 13);
+        } else {
+          if (subsh == 11) BH_COOP(false, 11); else if (subsh == 12) BH_COOP(false, 12); else BH_COOP(false, 13);
+        }
+#undef BH_COOP
         if (fuse && bulk == 0) *fused = true;
         if (lo >= bulk) return hipGetLastError();
         hi = bulk;  // the rest by one wave per group, below
@@ -1450,7 +1514,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
           force_fast_kernel<0, false, true, true><<<g2, tpb, 0, c->stream>>>(
               (const float*)c->frec, posm, c->acc, lo, hi, G, e2, mode, c->info, 0, 0, group, fz);
         else
-          force_fast_kernel<0, false, false, true><<<g2, tpb, 0, c->stream>>>(
+          force_fast_kernel<0, false, false, true><<<g2, tpb, (size_t)lds_pad, c->stream>>>(
               (const float*)c->frec, posm, c->acc, lo, hi, G, e2, mode, c->info, 0, 0, group, fz);
         *fused = true;
         return hipGetLastError();

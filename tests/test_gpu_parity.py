@@ -297,7 +297,7 @@ def test_force_coop_walk_matches_the_one_wave_walk(pkg, n):
 @pytest.mark.parametrize("name", ["coincident", "collinear", "outlier", "pairs", "tiny", "grid", "zero_mass"])
 def test_force_coop_walk_edge_inputs(pkg, name):
     """the cooperative walk on the edge inputs: coincident bodies form unsplit cells of more than 8 bodies
-    (the group is then redone by wave 0 with the generic loop: force_redo_waves > 0, same results), chains of close
+    (the group is then redone by wave 0 with the generic loop, same results), chains of close
     pairs are deep, zero masses are skipped.  Against the one-wave walk, same bound as above; leaf_cap 4 as well."""
     rng = np.random.default_rng(5)
     ic = special_ics(name, 3000, rng)
@@ -318,25 +318,27 @@ def test_force_coop_walk_edge_inputs(pkg, name):
             assert np.abs(a - ref).max() <= 2e-5 * scale, (name, leaf_cap, K)
 
 
-def test_force_coop_level_list_overflow_is_redone(pkg):
-    """theta = 0.1 opens far more cells per level than a wave's level list holds (127 entries): the group's walk is
-    redone by wave 0 with the generic depth-first loop (force_redo_waves counts it) and the result equals the
-    one-wave walk's up to the summation order of thousands of terms per body (relative |da| median <= 3e-6, max <= 2e-4;
-    measured 5.4e-5)"""
+@pytest.mark.parametrize("theta", [0.3, 0.1])
+def test_force_coop_full_level_lists_spill_to_the_wave_stack(pkg, theta):
+    """theta = 0.3 / 0.1 open far more cells per level than a wave's level list holds (127 entries; the longest list
+    at theta 0.3 is ~170, tools/coop_lists.py): what a full list cannot take goes onto the wave's own cross-lane stack
+    and is walked depth-first by that wave (BH_PUSH1, coop branch) — nothing is redone, nothing is lost: against the
+    one-wave walk relative |da| median <= 3e-6, max <= 2e-4 (summation order of thousands of terms per body)."""
     n = 20000
     ic = pkg.plummer(n, seed=8)
-    e = _engine(pkg, ic, force_coop=1, theta=0.1)
+    e = _engine(pkg, ic, force_coop=1, theta=theta)
     e.tree_stages(); e.force()
     ref = np.stack(e.download_acc(), 1).astype(np.float64)
     e.close()
-    e = _engine(pkg, ic, force_coop=2, force_group=64, theta=0.1)
-    e.tree_stages(); e.force()
-    a = np.stack(e.download_acc(), 1).astype(np.float64)
-    st = e.stats()
-    e.close()
-    assert st.status_flags == 0 and st.force_redo_waves > 0
-    rel = np.sqrt(((a - ref) ** 2).sum(1)) / np.sqrt((ref ** 2).sum(1))
-    assert np.median(rel) <= 3e-6 and rel.max() <= 2e-4, (float(np.median(rel)), float(rel.max()))
+    for K in (2, 4):
+        e = _engine(pkg, ic, force_coop=K, force_group=64, theta=theta)
+        e.tree_stages(); e.force()
+        a = np.stack(e.download_acc(), 1).astype(np.float64)
+        st = e.stats()
+        e.close()
+        assert st.status_flags == 0 and st.force_redo_waves == 0
+        rel = np.sqrt(((a - ref) ** 2).sum(1)) / np.sqrt((ref ** 2).sum(1))
+        assert np.median(rel) <= 3e-6 and rel.max() <= 2e-4, (K, float(np.median(rel)), float(rel.max()))
 
 
 def _check_tree(pkg, orc, ic, **kw):
