@@ -1360,8 +1360,24 @@ __global__ __launch_bounds__(256) void unpack_u32x3_kernel(const u32* __restrict
 // 0.317 / 0.251.  Results do not depend on the group size.
 static int force_group(const bh_ctx* c, int bodies) {
   if (c->p.force_group == 16 || c->p.force_group == 32 || c->p.force_group == 64) return c->p.force_group;
-  if (!c->dd && c->p.force_variant == 0 && c->p.force_coop != 1) return c->n <= 32 * 1024 ? 32 : 64;  // cooperative walk
+  if (!c->dd && c->p.force_variant == 0 && c->p.force_coop != 1) return 64;  // cooperative walk: full groups, K waves
   return bodies <= 20 * 1024 ? 16 : (bodies <= 56 * 1024 ? 32 : 64);
+}
+
+constexpr int kWalkWaves = 7;  // resident waves per SIMD of the walk kernels (BH_WALK_SGPRS)
+// Groups at the end of a launch that are walked by four waves each (force_mixed_kernel; a launch of fewer groups is
+// cooperative throughout): the short jobs have to refill what the long ones free while they drain — a third of the
+// resident waves' worth of groups, whatever the launch size (same-box sweep at 1M bodies, force ms for 0 / 2,048 /
+// 2,560 / 3,072 / 3,584 / 4,096 / 5,120 such groups: 1.166 / 1.091 / 1.091 / 1.099 / 1.097 / 1.110 / 1.114;
+// 500,000 bodies: 0.692 / 0.601 / - / 0.604 / - / 0.605; 2M: 2.252 / 2.187 / - / 2.177 / - / 2.178; theta 0.3 at 1M:
+// 3.533 / 3.245 / - / 3.220 / - / 3.232 — profiles/r04_drain/).
+static long long force_tail_groups(const bh_ctx* c) {
+  long long T = (long long)c->num_cus * 4 * kWalkWaves / 3;
+#ifdef BH_STUDY
+  static const int env_tail = getenv("BH_FORCE_TAIL") ? atoi(getenv("BH_FORCE_TAIL")) : -1;
+  if (env_tail >= 0) T = env_tail;
+#endif
+  return T;
 }
 
 // Waves per group (bh_params.force_coop: 0 = by context size, 1 = one wave per group: the depth-first walk, 2..8).
@@ -1372,9 +1388,13 @@ static int force_coop(const bh_ctx* c, int group) {
   if (c->dd || c->p.force_variant != 0) return 1;
   if (c->p.force_coop >= 1 && c->p.force_coop <= kCoopMaxK) return c->p.force_coop;
   const long long groups = ((long long)c->n + group - 1) / group;
-  const long long slots = (long long)c->num_cus * 4 * 6;
-  const long long k = slots / (groups > 0 ? groups : 1);
-  return k >= kCoopMaxK ? kCoopMaxK : (k < 2 ? 1 : (int)k);
+  // up to twice the tail of a mixed launch everything is walked cooperatively (same-box, force ms mixed / all by four
+  // waves: 160,000 bodies 0.260 / 0.226, 200,000 0.303 / 0.280, 300,000 0.396 / 0.391; 500,000: 0.603 / 0.627)
+  if (groups > 2 * force_tail_groups(c)) return 1;  // mixed launch: one wave per group first, the last groups by four
+  // eight waves while eight per group still fit the GPU at once (16,384 bodies: 0.048 ms against 0.064 with four;
+  // 32,768: 0.063 / 0.075), else four — one per SIMD of a CU; five to seven measure worse than either (65,536 bodies,
+  // K = 4 / 5 / 6 / 7 / 8: 0.108 / 0.106 / 0.108 / 0.139 / 0.119)
+  return groups * kCoopMaxK <= (long long)c->num_cus * 4 * kWalkWaves ? kCoopMaxK : 4;
 }
 
 // Level-list size of the cooperative walk (1 << subsh bytes per wave and level): 127 entries.  The entries of a level
@@ -1392,17 +1412,12 @@ static int force_coop_subsh(const bh_ctx* c) {
 }
 
 // Mixed launches (force_mixed_kernel): the bodies below this bound are walked one wave per 64-body group, the rest
-// four waves per group.  The short jobs have to refill what the long ones free while they drain — about half the
-// resident waves' worth of groups, whatever the launch size (profiles/r04_drain/: T = 3,072 groups on 256 CUs).
+// (force_tail_groups) four waves per group.
 // 0: every group cooperatively (K > 1: the launch does not fill the GPU); n: none (force_coop = 1, other walks).
 static int force_bulk_bodies(const bh_ctx* c, int group, int K) {
   if (K > 1) return 0;
   if (c->dd || c->p.force_variant != 0 || c->p.force_coop != 0 || group != 64) return c->n;
-  long long T = (long long)c->num_cus * 4 * 6 / 2;
-#ifdef BH_STUDY
-  static const int env_tail = getenv("BH_FORCE_TAIL") ? atoi(getenv("BH_FORCE_TAIL")) : -1;
-  if (env_tail >= 0) T = env_tail;
-#endif
+  const long long T = force_tail_groups(c);
   const long long G = ((long long)c->n + 63) / 64;
   const long long gb = (G - T > 0 ? G - T : 0) & ~3ll;  // whole workgroups of four one-wave groups
   return T == 0 ? c->n : (int)(gb * 64);

@@ -27,7 +27,7 @@ e.sync()
 # rows of the launch the default engine makes (csrc/bh_force.hip: force_coop, force_bulk_bodies): one per wave
 G = (n + 63) // 64
 slots = 256 * 4 * 6
-T = int(os.environ.get("BH_FORCE_TAIL", slots // 2))
+T = int(os.environ.get("BH_FORCE_TAIL", 256 * 4 * 7 // 3))
 if G <= slots // 2:          # every group by K waves
     K = min(8, slots // G) if n > 32 * 1024 else min(8, slots // ((n + 31) // 32))
     W = ((n + 63) // 64 if n > 32 * 1024 else (n + 31) // 32) * K
