@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 3 /* 2: bh_params grew key_curve (72 bytes); 3: bh_dd_phase_*, timing mode 3 */
+#define BH_ABI_VERSION 4 /* 2: bh_params grew key_curve (72 bytes); 3: bh_dd_phase_*, timing mode 3; 4: force_coop,
+                             bh_dd_get_info, larger X1 payload (boundary proposals), bh_walk_stats fields */
 
 typedef struct bh_ctx bh_ctx; /* opaque; replaces the globals ref:31-40 */
 
@@ -328,6 +329,12 @@ int bh_dd_phase_let(bh_ctx* c, const void* gathered_x3, void* send_x4, int strid
 int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* counts, int* fits);
 int bh_dd_phase_end(bh_ctx* c, void* send_x1);
 int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc);
+/* what the last step's migration did, for logs and tests (synchronises): out[0] bodies this rank holds, [1] emigrants
+   it found in its last classification, [2] steps since bh_dd_init in which the domain boundaries moved, [3] what the
+   last step did with them: 0 kept (the boundaries are positions in space that persist from step to step and are
+   re-keyed under every step's cube), 1 moved to the exact quantiles (a rank's body count had left n / P by more than
+   1.5 %), 2 drawn from position samples (first step, or a boundary would have had to cross a whole rank) */
+int bh_dd_get_info(bh_ctx* c, int32_t out[8]);
 
 /* per-step device times (hipEvent pairs recorded on the context's stream while
    bh_set_timing is on) of the most recent steps, oldest first: ms_force[i], ms_step[i].

@@ -126,6 +126,7 @@ SYMBOLS = [
     ("bh_dd_phase_force", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     ("bh_dd_phase_end", C.c_int, [_P, _P]),
     ("bh_dd_download", C.c_int, [_P, _F, _F, _F]),
+    ("bh_dd_get_info", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("bh_ic_plummer", C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_float] + [_F] * 7),
     ("bh_ic_disc", C.c_int, [C.c_int, C.c_uint64, C.c_float] + [_F] * 7),
     ("bh_ic_disc_msvc", C.c_int, [C.c_int, C.c_uint32, C.c_float] + [_F] * 7),

@@ -78,11 +78,16 @@ struct bh_dd_state {
   int* fpos;       // same, exclusive scan of flag
   int* nloc;       // [world] body count of every rank after this step's migration
   int samp_cap;    // sample slots per rank in X1 (kSampTotal / world)
-  u64* skeys;      // [world-1] splitter keys under the current cube, ascending
+  u64* skeys;      // [world-1] splitter keys under the current cube
+  float4* spos;    // [world-1] splitter POSITIONS (w = 1): a boundary stays where it is in space from step to step
+                   // and is re-keyed under every step's cube; moved only when a rank's body count leaves the
+                   // tolerance band (dd_split_kernel)
   int* piece_tmp;  // [BH_DD_PIECE_CAP] unsorted piece records
   int* piece_idx;  // [BH_DD_PIECE_CAP] pieces in body order
   int* ddi;        // [16] device scalars: 0 piece counter, 1 remote boxes, 2 top pieces, 3 top children,
-                   //      4..7 migration results, 8 pieces of this step
+                   //      4..7 migration results, 8 pieces of this step, 9 steps that moved the splitters,
+                   //      10 splitter positions valid, 11 what the last dd_split_kernel did (0 kept, 1 exact
+                   //      quantiles from the ranks' candidates, 2 sample quantiles), 12 emigrants found on this rank
   float4* boxes;   // [world * BH_DD_PIECE_CAP] remote piece boxes (corner, edge), margin applied
   float4* rbox;    // [2 * world] bounding box of each remote rank's pieces + its range in boxes[]
   top5* top_ps;    // [2][kTopMax + 1] fp64 prefix of the piece sums (one per pass: the passes overlap)
@@ -136,7 +141,12 @@ constexpr int kTopCap = 4 * 4096 + 8;  // records of one top tree incl. padding 
 constexpr int kSampTotal = 2048;  // position samples in the whole system (bitonic sort in LDS by one block, on the
                                   // critical path of every step: 49 us with 4096, quantile error 1/256 of a rank at 8 ranks)
 __host__ __device__ inline int samp_cap_of(int world) { return kSampTotal / world; }
-__host__ __device__ inline int x1_floats(int world) { return 8 + 4 * samp_cap_of(world); }
+// X1 payload of a rank, floats: [0..5] min / max, [6] body count, [7] -, [8..11] / [12..15] the positions this rank
+// proposes for its lower / upper domain boundary (w = 1: valid), [16 ..] position samples
+constexpr int kX1Samples0 = 16;
+__host__ __device__ inline int x1_floats(int world) { return kX1Samples0 + 4 * samp_cap_of(world); }
+constexpr float kSplitTolerance = 0.015f;  // a rank's body count may leave n / P by this fraction before the
+                                           // boundaries move
 
 __device__ __forceinline__ int owner_of(u64 key, const u64* sk, int nsplit) {
   int o = 0;
@@ -148,14 +158,45 @@ __device__ __forceinline__ int owner_of(u64 key, const u64* sk, int nsplit) {
 // samples k = 0 .. : the body at local index (k + 1/2) * g, g = n_total / kSampTotal — the same
 // stride on every rank, so the merged samples weight every body equally.  send[0..5] = the rank's min / max
 // (mm: folded by the previous step's integrate kernel, or by bbox_partial/final after an upload).
+// Boundary candidates: every rank knows every rank's body count (nloc: written by the last migration of the previous
+// step, identical everywhere), hence the index every boundary has in the global body order and the index it should
+// have, (q + 1) n / P.  A boundary that has to move INTO this rank's range by d bodies goes to the position of this
+// rank's d-th body from that end — the bodies are stored in the key order of the previous step's sort, which one
+// integrate step disturbs only locally — so the rank on that side proposes it (w = 1), and dd_split_kernel takes the
+// proposals when it decides to rebalance: exact quantiles, and only the bodies between the old and the new boundary
+// change owner.
 __global__ __launch_bounds__(256) void dd_x1_pack_kernel(float* __restrict__ send, const float* __restrict__ mm,
                                                          int n_loc, const float4* __restrict__ posm, double g,
-                                                         int samp_cap) {
+                                                         int samp_cap, const int* __restrict__ nloc, int world,
+                                                         int rank, long long n_total) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < 6) send[t] = mm[t];
   if (t == 0) {
     send[6] = __int_as_float(n_loc);
     send[7] = 0.0f;
+    long long before = 0, total = 0;
+    for (int q = 0; q < world; q++) {
+      if (q < rank) before += nloc[q];
+      total += nloc[q];
+    }
+    const bool known = total == n_total && nloc[rank] == n_loc;
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    if (known && rank > 0) {
+      const long long d = (long long)rank * n_total / world - before;  // > 0: the lower boundary moves up into this range
+      if (d > 0 && d < n_loc) {
+        lo = posm[d];
+        lo.w = 1.0f;
+      }
+    }
+    if (known && rank < world - 1) {
+      const long long d = before + n_loc - (long long)(rank + 1) * n_total / world;  // > 0: the upper one moves down
+      if (d > 0 && d < n_loc) {
+        hi = posm[n_loc - d];
+        hi.w = 1.0f;
+      }
+    }
+    reinterpret_cast<float4*>(send + 8)[0] = lo;
+    reinterpret_cast<float4*>(send + 8)[1] = hi;
   }
   if (t >= samp_cap) return;
   const long long idx = (long long)(((double)t + 0.5) * g);
@@ -164,18 +205,28 @@ __global__ __launch_bounds__(256) void dd_x1_pack_kernel(float* __restrict__ sen
     o = posm[idx];
     o.w = 1.0f;
   }
-  reinterpret_cast<float4*>(send + 8)[t] = o;
+  reinterpret_cast<float4*>(send + kX1Samples0)[t] = o;
 }
 
-// the global cube from the gathered per-rank min / max (exact: min and max are associative; same arithmetic as
-// write_cube of bh_tree.hip, ref:148-154), then: keys of all samples under the new cube, bitonic sort,
-// equal-count quantiles -> splitter keys
+// The global cube from the gathered per-rank min / max (exact: min and max are associative; same arithmetic as
+// write_cube of bh_tree.hip, ref:148-154), then this step's splitter keys.  The splitters are POSITIONS that persist
+// (spos): re-keyed under the new cube they cut the curve where they cut it in the previous step, so only bodies
+// that really crossed a boundary change owner (round 3 re-drew them from 2,048 position samples every step: the
+// quantile noise alone moved 2-5 % of every rank's bodies per step).  They move only when some rank's body count
+// has left n / P by more than `tol`: then every boundary goes to the exact quantile its neighbours propose
+// (dd_x1_pack_kernel), or — first step, or a proposal missing because a boundary would have to cross a whole rank —
+// to the sample quantiles as in round 3.  Every rank runs this on the same gathered data and the same spos: same result.
 __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict__ g, int world, int xf,
                                                         int samp_cap, float* __restrict__ bounds,
-                                                        int curve, u64* __restrict__ skeys) {
+                                                        int curve, u64* __restrict__ skeys,
+                                                        float4* __restrict__ spos, int* __restrict__ ddi,
+                                                        long long n_total, float tol) {
   __shared__ u64 k[kSampTotal];
+  __shared__ unsigned short ki[kSampTotal];
   __shared__ int nvalid;
   __shared__ float cube[8];
+  __shared__ int s_mode;  // 0: keep, 1: the ranks' proposals, 2: sample quantiles
+  __shared__ float4 prop[64];
   const int tid = threadIdx.x;
   if (tid == 0) {
     nvalid = 0;
@@ -191,20 +242,62 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
     cube[6] = fmaxf(cube[3] - cube[0], 1.0f);                                 // root edge s0, ref:55
     cube[7] = 0.0f;
     for (int q = 0; q < 8; q++) bounds[q] = cube[q];
+    // what to do with the boundaries
+    int mode = 0;
+    if (world > 1) {
+      if (!ddi[10]) {
+        mode = 2;
+      } else {
+        const double fair = (double)n_total / (double)world;
+        bool out = false;
+        for (int r = 0; r < world; r++) {
+          const double nr = (double)__float_as_int(g[(size_t)r * xf + 6]);
+          if (fabs(nr - fair) > (double)tol * fair) out = true;
+        }
+        if (out) {
+          mode = 1;
+          long long before = 0;
+          for (int q = 0; q + 1 < world; q++) {
+            before += __float_as_int(g[(size_t)q * xf + 6]);
+            const long long want = (long long)(q + 1) * n_total / world;
+            const float4 up = reinterpret_cast<const float4*>(g + (size_t)(q + 1) * xf + 8)[0];  // rank q+1, lower end
+            const float4 dn = reinterpret_cast<const float4*>(g + (size_t)q * xf + 8)[1];        // rank q, upper end
+            if (want > before && up.w > 0.5f) prop[q] = up;
+            else if (want < before && dn.w > 0.5f) prop[q] = dn;
+            else if (want == before) prop[q] = spos[q];
+            else mode = 2;
+          }
+        }
+      }
+      if (mode) ddi[9] += 1;
+      ddi[10] = 1;
+    }
+    ddi[11] = mode;
+    s_mode = mode;
   }
   __syncthreads();
+  const int mode = s_mode;
+  if (mode != 2) {
+    if (tid < world - 1) {
+      const float4 p = mode == 1 ? prop[tid] : spos[tid];
+      if (mode == 1) spos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
+      skeys[tid] = body_key<kB>(curve, p.x, p.y, p.z, cube[0], cube[1], cube[2], cube[6]);
+    }
+    return;
+  }
   int mine = 0;
   for (int i = tid; i < kSampTotal; i += 1024) {
     u64 key = ~0ull;
     const int r = i / samp_cap, t = i - r * samp_cap;
     if (r < world) {
-      const float4 p = reinterpret_cast<const float4*>(g + (size_t)r * xf + 8)[t];
+      const float4 p = reinterpret_cast<const float4*>(g + (size_t)r * xf + kX1Samples0)[t];
       if (p.w > 0.5f) {
         key = body_key<kB>(curve, p.x, p.y, p.z, cube[0], cube[1], cube[2], cube[6]);
         mine++;
       }
     }
     k[i] = key;
+    ki[i] = (unsigned short)i;
   }
   if (mine) atomicAdd(&nvalid, mine);
   __syncthreads();
@@ -219,13 +312,27 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
         if ((a > b) == up) {
           k[i] = b;
           k[partner] = a;
+          const unsigned short ia = ki[i];
+          ki[i] = ki[partner];
+          ki[partner] = ia;
         }
       }
       __syncthreads();
     }
   }
   const int M = nvalid;  // valid samples sort first (invalid = all ones)
-  if (tid < world - 1) skeys[tid] = M > 0 ? k[(int)(((long long)(tid + 1) * M) / world)] : ~0ull;
+  if (tid < world - 1) {
+    if (M > 0) {
+      const int at = (int)(((long long)(tid + 1) * M) / world);
+      const int i = ki[at], r = i / samp_cap, t = i - r * samp_cap;
+      const float4 p = reinterpret_cast<const float4*>(g + (size_t)r * xf + kX1Samples0)[t];
+      spos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
+      skeys[tid] = k[at];
+    } else {
+      spos[tid] = make_float4(cube[0], cube[1], cube[2], 1.0f);
+      skeys[tid] = ~0ull;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ X2
@@ -241,7 +348,8 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(const float4* __restri
                                                           const u64* __restrict__ skeys, int nsplit, int me,
                                                           unsigned char* __restrict__ kept, int* __restrict__ bcnt,
                                                           int* __restrict__ bbase, u32* __restrict__ done,
-                                                          int* __restrict__ header, int limit) {
+                                                          int* __restrict__ header, int limit,
+                                                          int* __restrict__ ddi12) {
   __shared__ u64 sk[64];
   __shared__ int wsum[4];
   __shared__ int s_last;
@@ -297,6 +405,7 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(const float4* __restri
     const int found = carry;
     const int sent = min(found, limit);
     bbase[nb] = found;
+    if (ddi12) *ddi12 = found;
     header[0] = found;
     header[1] = n - found;
     header[2] = sent;
@@ -1444,7 +1553,7 @@ void bh_dd_free(bh_ctx* c) {
     (void)hipStreamSynchronize(d->stream_own);
     (void)hipStreamDestroy(d->stream_own);
   }
-  void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
+  void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->spos, d->piece_tmp,
                   d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2,
                   d->cls_done, d->abs_done, d->arrive, c->dd_minmax, d->wmask, d->list_e, d->list_w, d->list_m, d->dstd,
                   d->dtot, d->csum, d->mark_cnt, d->mark_done};
@@ -1526,6 +1635,8 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->fpos, (fl + 1 + 64) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->nloc, 64 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->skeys, 64 * 8) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->spos, 64 * sizeof(float4)) == hipSuccess;
+  ok = ok && hipMemset(d->spos, 0, 64 * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_tmp, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_idx, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->ddi, 16 * 4) == hipSuccess;
@@ -1632,7 +1743,8 @@ int bh_dd_cube_pack(bh_ctx* c, void* send_x1) {
   const double g = 1.34 * (double)d->n_total / (double)kSampTotal;
   const int th = d->samp_cap > 8 ? d->samp_cap : 8;
   dd_x1_pack_kernel<<<(th + 255) / 256, 256, 0, c->stream>>>((float*)send_x1, c->dd_minmax, c->n, c->posm[c->cur],
-                                                             g > 1.0 ? g : 1.0, d->samp_cap);
+                                                             g > 1.0 ? g : 1.0, d->samp_cap, d->nloc, d->world,
+                                                             d->rank, d->n_total);
   BH_HIP(c, hipGetLastError());
   return BH_OK;
 }
@@ -1642,7 +1754,7 @@ int bh_dd_cube_apply(bh_ctx* c, const void* gathered_x1) {
   bh_dd_state* d = c->dd;
   const int xf = x1_floats(d->world);
   dd_split_kernel<<<1, 1024, 0, c->stream>>>((const float*)gathered_x1, d->world, xf, d->samp_cap, c->bounds,
-                                             c->p.key_curve, d->skeys);
+                                             c->p.key_curve, d->skeys, d->spos, d->ddi, d->n_total, kSplitTolerance);
   BH_HIP(c, hipGetLastError());
   c->stage = BH_ST_UPLOADED | BH_ST_BBOX;
   c->ever |= BH_ST_BBOX;
@@ -1661,7 +1773,7 @@ int bh_dd_migrate_pack(bh_ctx* c, void* send_x2, int limit) {
   int* bbase = d->fpos + blocks + 1;
   dd_classify_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], n, c->bounds, c->p.key_curve, d->skeys,
                                                     d->world - 1, d->rank, kept, bcnt, bbase, d->cls_done,
-                                                    (int*)send_x2, limit);
+                                                    (int*)send_x2, limit, d->ddi + 12);
   dd_compact_kernel<<<blocks, 256, 0, c->stream>>>(c->posm[c->cur], c->velid[c->cur], n, kept, bbase,
                                                    c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], (float4*)send_x2,
                                                    limit);
@@ -1931,6 +2043,19 @@ int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* c
 int bh_dd_phase_end(bh_ctx* c, void* send_x1) {
   const int s = bh_integrate(c);
   return s ? s : bh_dd_cube_pack(c, send_x1);
+}
+
+// what the step's migration did, for logs and tests (synchronises): out[0] bodies this rank holds, [1] emigrants it
+// found in its last classification, [2] steps since bh_dd_init in which the domain boundaries moved, [3] what the last
+// step did with them (0 kept, 1 exact quantiles proposed by the ranks, 2 sample quantiles), [4..7] reserved
+int bh_dd_get_info(bh_ctx* c, int32_t out[8]) {
+  if (!c || !c->dd || !out) return BH_ERR_BAD_ARG;
+  int h[16];
+  BH_HIP(c, hipMemcpyAsync(h, c->dd->ddi, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  out[0] = c->n; out[1] = h[12]; out[2] = h[9]; out[3] = h[11];
+  out[4] = out[5] = out[6] = out[7] = 0;
+  return BH_OK;
 }
 
 int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc) {

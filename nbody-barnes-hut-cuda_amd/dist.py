@@ -189,7 +189,7 @@ class DomainStepper:
     stitched tree for its own bodies.  Four all-gathers per step, no replicated stage."""
 
     def __init__(self, pkg, ic, comm, device, stream=None, params=None, slack=1.3, mig_frac=0.5,
-                 let_cap=None, order=None, split=True, let_mode=None, **kw):
+                 let_cap=None, order=None, split=True, let_mode=None, mig_log=False, **kw):
         self.comm = comm
         self.split = bool(split)
         # X4: 0 = all-gather of the union segment (round 2), 1 = per-destination segments, all-to-all
@@ -212,6 +212,7 @@ class DomainStepper:
         self.mig_stride = min(self.mig_cap, 4096)
         self.mig_rounds = 0
         self.mig_last = 0
+        self.mig_log = [] if mig_log else None   # per step (emigrants, boundaries): synchronises — tests and tools only
         e_cls = pkg.Engine
         lmin = 4 + 512  # header + needs row + piece slots (BH_DD_PIECE_CAP, csrc/bh_dd.hip kSegBlocks0)
         self.let_cap = int(let_cap) if let_cap else lmin + self.n_cap
@@ -253,6 +254,7 @@ class DomainStepper:
         self.n_cap, self.mig_cap, self.let_cap = int(n_cap), int(mig_cap), int(let_cap)
         self.mig_stride = min(self.mig_cap, 4096)
         self.mig_rounds = self.mig_last = self.let_retries = self.n_loc = 0
+        self.mig_log = None
         self.let_counts = None
         P = self.world
         u8 = dict(dtype=torch.uint8, device=tensor_device)
@@ -363,6 +365,7 @@ class DomainStepper:
                 c.all_gather(self.x1r, self.x1s)
                 self._mark(1)
                 limit, first = self.mig_stride, None                   # X2: bodies that changed owner
+                self.mig_stride_used = limit                           # (slots per rank of this step's first round)
                 failed = None   # a rank-local failure must not strand the others inside a collective: the
                 rounds = 0      # failing rank keeps taking part with empty payloads and marks its LET segment
                 while True:
@@ -389,7 +392,11 @@ class DomainStepper:
                     self.mig_rounds += 1                                # rare: a splitter changed octant
                     limit = min(self.mig_cap, max(limit, _round_up(most, 256)))
                 self.mig_last = first
-                self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 2.0 + 4096, 256)))
+                if self.mig_log is not None and hasattr(e, "dd_info"):   # tests / tools: (emigrants, boundaries) per step
+                    self.mig_log.append((first, e.dd_info()[3]))
+                # next step's slots: one and a half times what this step moved (boundaries that persist move a fraction of a per
+                # cent of a rank per step; a rebalance or a collapse moves more and goes in several rounds)
+                self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 1.5 + 512, 256)))
                 self._mark(2)
                 if failed is not None:
                     self.x3s.zero_()

@@ -371,6 +371,13 @@ class Engine:
     def dd_phase_end(self, send_x1_ptr):
         self._ck(lib.bh_dd_phase_end(self._h, C.c_void_p(int(send_x1_ptr))), "bh_dd_phase_end")
 
+    def dd_info(self):
+        """(bodies held, emigrants found in the last step, steps in which the domain boundaries moved, what the last
+        step did with them: 0 kept / 1 exact quantiles / 2 sample quantiles) — synchronises; logs and tests"""
+        out = np.zeros(8, np.int32)
+        self._ck(lib.bh_dd_get_info(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))), "bh_dd_get_info")
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def dd_download(self):
         """local bodies in local Morton order: posm [n,4], vel [n,3], ids [n], acc [n,3]"""
         n = self.n

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(pkg):
 def test_struct_layouts(pkg):
     assert C.sizeof(pkg.BhNode) == 32
     assert C.sizeof(pkg.BhParams) == 5 * 4 + 4 * 4 + 9 * 4
-    assert pkg.lib.bh_abi_version() == 3
+    assert pkg.lib.bh_abi_version() == 4
 
 
 def test_default_params_are_reference_constants(pkg):
@@ -143,7 +143,7 @@ def test_dd_query_sizes_are_host_side_and_consistent():
     n_cap, world, mig_cap, let_cap = 1_304_096, 8, 652_048, 4 + BH_DD_PIECE_CAP + 1_304_096
     assert lib.bh_dd_query(n_cap, world, mig_cap, let_cap, C.byref(sz)) == 0
     assert sz.x2_bytes == 32 + 32 * mig_cap and sz.x3_bytes == 80 * (1 + BH_DD_PIECE_CAP)
-    assert sz.x1_bytes == 4 * (8 + 4 * (2048 // world))  # 2048 position samples in the whole system
+    assert sz.x1_bytes == 4 * (16 + 4 * (2048 // world))  # min / max, count, two boundary proposals, 2048 samples in all
     assert sz.let_min == 4 + BH_DD_PIECE_CAP and sz.let_cap == let_cap  # header + 3 needs-row records + piece slots
     # pool = local tree + body digests | two top trees | world LET segments (+ read-ahead padding)
     assert sz.top_base >= 3 * n_cap and sz.seg_base > sz.top_base

@@ -100,7 +100,8 @@ def test_domain_stepper_protocol(world, scenario, let_mode, tmp_path):
         assert all(x["error"] is None and x["integrates"] == 4 and x["force_local"] == 4 for x in res)
         # step 1: 6000 emigrants against the initial X2 size of 4096 -> one extra round, after which
         # the size follows the observed count (capped by the buffer) and step 2's 9000 fit at once
-        assert res[0]["mig_rounds"] == 1 and res[0]["mig_stride"] >= 2048
+        # (the last step's 50 leave the floor of 1024 slots)
+        assert res[0]["mig_rounds"] == 1 and res[0]["mig_stride"] >= 1024
         # step 1 needs 4700 records against the first stride; step 2 jumps to 15000 -> retries
         assert res[0]["let_retries"] == 2
         assert res[0]["stride"] >= 15500

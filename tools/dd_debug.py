@@ -42,6 +42,7 @@ def main():
     stream = torch.cuda.Stream(0)
     steppers = [None] * P
     slow = [0] * P
+    info = [None] * P
     errs = []
 
     def log(*a):
@@ -61,12 +62,16 @@ def main():
                 sst = st.e.stats()
                 flags = sst.status_flags
                 slow[r] = sst.sort_slow_buckets
+                info[r] = st.e.dd_info()
                 group.barrier.wait()
                 if r == 0 and not args.quiet:
                     hdr = st.x3r.cpu().numpy().view(np.int32).reshape(P, -1)[:, 0]
                     log(f"   pieces per rank {hdr.tolist()}")
                     log(f"step {s}: n_loc={[x.n_loc for x in steppers]} stride={st.stride} "
-                        f"let={st.let_counts.tolist()} retries={st.let_retries} emig={st.mig_last} "
+                        f"let={st.let_counts.tolist()} retries={st.let_retries} emig_max={st.mig_last} "
+                        f"emig_per_rank={[i[1] for i in info]} boundaries_moved={info[0][2]} (this step: "
+                        f"{('kept', 'exact quantiles', 'sample quantiles')[info[0][3]]}) "
+                        f"x2_received_bytes={P * (32 + 32 * st.mig_stride_used)} "
                         f"mig_rounds={st.mig_rounds} flags={flags} slow_buckets={slow} "
                         f"{(time.time() - t0) * 1e3:.1f} ms")
                 group.barrier.wait()
