@@ -604,14 +604,16 @@ __global__ __launch_bounds__(256) void dd_absorb_copy_kernel(const float4* __res
 }
 
 // ------------------------------------------------------------------ X3: pieces
-__device__ __forceinline__ bool is_spine(const bh_node* __restrict__ rec, const int* __restrict__ er_lo,
-                                         const int* __restrict__ er_hi, int e, int n) {
-  return rec[e].kind == BH_KIND_INTERNAL && (er_lo[e] == 0 || er_hi[e] == n);
+// (the local tree's COM stage writes only the force kernel's digests, as in bh_step: a record's body range is still
+// in the bit patterns of its x / y, where the build left it — put_rec, bh_tree.hip)
+__device__ __forceinline__ int rec_lo(const bh_node& r) { return __float_as_int(r.x); }
+__device__ __forceinline__ int rec_hi(const bh_node& r) { return __float_as_int(r.y); }
+__device__ __forceinline__ bool is_spine(const bh_node* __restrict__ rec, int e, int n) {
+  const bh_node r = rec[e];
+  return r.kind == BH_KIND_INTERNAL && (rec_lo(r) == 0 || rec_hi(r) == n);
 }
 
 __global__ __launch_bounds__(256) void dd_spine_kernel(const bh_node* __restrict__ rec,
-                                                       const int* __restrict__ er_lo,
-                                                       const int* __restrict__ er_hi,
                                                        const bh_devinfo* __restrict__ info, int rec_cap, int n,
                                                        int* __restrict__ piece_tmp, int* __restrict__ ddi) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -621,11 +623,11 @@ __global__ __launch_bounds__(256) void dd_spine_kernel(const bh_node* __restrict
     piece_tmp[atomicAdd(&ddi[0], 1)] = 0;
     return;
   }
-  if (!is_spine(rec, er_lo, er_hi, e, n)) return;
+  if (!is_spine(rec, e, n)) return;
   const bh_node r = rec[e];
   for (int k = 0; k < r.count; k++) {
     const int c = r.first + k;
-    if (!is_spine(rec, er_lo, er_hi, c, n)) {
+    if (!is_spine(rec, c, n)) {
       const int idx = atomicAdd(&ddi[0], 1);  // order fixed below by the body range
       if (idx < BH_DD_PIECE_CAP) piece_tmp[idx] = c;
     }
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(256) void dd_spine_kernel(const bh_node* __restrict
 
 __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
     const int* __restrict__ piece_tmp, const int* ddi, int* ddi_w, const bh_node* __restrict__ rec,
-    const int* __restrict__ er_lo, const int* __restrict__ er_hi, const u64* __restrict__ keys,
+    const u64* __restrict__ keys,
     const bh_d4* __restrict__ P, const float4* __restrict__ posm, const float* __restrict__ bounds, int curve,
     int me, int n_loc, bh_dd_piece* __restrict__ out, int* __restrict__ piece_idx,
     bh_devinfo* __restrict__ info) {
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
   }
   if (t < np) {
     idx[t] = piece_tmp[t];
-    lo[t] = er_lo[idx[t]];
+    lo[t] = rec_lo(rec[idx[t]]);
   }
   __syncthreads();
   if (t == 0) {
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
   for (int u = 0; u < np; u++) rank += (lo[u] < lo[t]) ? 1 : 0;  // pieces are disjoint: distinct starts
   const int e = idx[t];
   piece_idx[rank] = e;
-  const int a = lo[t], b = er_hi[e];
+  const int a = lo[t], b = rec_hi(rec[e]);
   bh_dd_piece d;
   d.key = keys[a];
   d.rec_idx = e;
@@ -1853,10 +1855,10 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
   BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
   BH_HIP(c, bhk_build(c));
   BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
-  BH_HIP(c, bhk_com_records(c, true));
-  dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->er_lo, c->er_hi, c->info, c->rec_cap,
-                                                                   c->n, d->piece_tmp, d->ddi);
-  dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, d->ddi, c->rec, c->er_lo, c->er_hi,
+  BH_HIP(c, bhk_com_records(c, false));  // digests only (the walk's records); the piece kernels read the proto records
+  dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->info, c->rec_cap, c->n, d->piece_tmp,
+                                                                   d->ddi);
+  dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, d->ddi, c->rec,
                                                            c->keys[c->key_buf], c->P, c->posm[c->cur], c->bounds,
                                                            c->p.key_curve, d->rank, c->n, (bh_dd_piece*)send_x3,
                                                            d->piece_idx, c->info);

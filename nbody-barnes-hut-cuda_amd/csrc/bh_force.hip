@@ -971,7 +971,8 @@ __host__ __device__ constexpr int coop_cap(int subsh) { return (1 << subsh) / 16
 // overflowed or a block of more than 8 children was met (ax..az are then partial sums of an incomplete walk).
 template <int SUBSH>
 __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u32 nxt, int K, int j, float px,
-                                                  float py, float pz, float eps2, float& ax, float& ay, float& az) {
+                                                  float py, float pz, float eps2, float& ax, float& ay, float& az,
+                                                  bool& limit_hit) {
   int maxc;
   asm volatile(
       "s_mov_b64 s[20:21], %[base]\n"
@@ -983,6 +984,7 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
       "v_mov_b32 v21, %[eps2]\n"
       "v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
       "v_mov_b32 v48, 0\n v_mov_b32 v50, 0\n v_mov_b32 v51, 0\n"
+      "v_mov_b32 v59, 0\n"                // levels walked (all lanes alike)
       "s_mov_b32 s16, 0\n"
       "s_mov_b32 s14, 0\n"                // entries on this wave's own stack (children a full list did not take)
       "s_mov_b32 s17, %[cur]\n"
@@ -1034,6 +1036,12 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
       "s_mov_b64 exec, s[12:13]\n"
       "s_branch L_decode_%=\n"
       "L_cpop_%=:\n"                     // an entry of this wave's own stack (its list was full)
+      "s_add_u32 vcc_hi, vcc_hi, 0x10000\n"  // at most 65,535 of them per level (upper half of vcc_hi): a cycle in a
+      "s_cbranch_scc0 5f\n"              // malformed pool (imported records) ends here, not in a hang
+      "s_or_b32 s16, s16, 2048\n"
+      "s_mov_b32 s14, 0\n"
+      "s_branch L_centry_%=\n"
+      "5:\n"
       "s_sub_u32 s14, s14, 1\n"
       "v_readlane_b32 s18, v48, s14\n"
       "v_readlane_b32 s12, v50, s14\n"
@@ -1042,8 +1050,17 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
       BH_WALK_BODY
       "L_lvlend_%=:\n"
       "s_mov_b64 exec, -1\n"
-      "s_cmp_eq_u32 vcc_hi, 0\n"          // an empty level: nobody pushed anything, every wave leaves here
+      "s_and_b32 s11, vcc_hi, 0xffff\n"   // (lower half: the level's entries, the same number on every wave)
+      "s_cmp_eq_u32 s11, 0\n"            // an empty level: nobody pushed anything, every wave leaves here
       "s_cbranch_scc1 L_done_%=\n"
+      "v_add_u32 v59, 1, v59\n"           // a tree has at most 21 levels below the root (+ the top tree's): a walk
+      "s_nop 0\n"
+      "v_readfirstlane_b32 s11, v59\n"    // that is still descending after 96 follows a cycle; every wave of the
+      "s_cmp_gt_u32 s11, 96\n"            // workgroup sees the same count and leaves together
+      "s_cbranch_scc0 6f\n"
+      "s_or_b32 s16, s16, 2048\n"
+      "s_branch L_done_%=\n"
+      "6:\n"
       "s_mul_i32 s11, %[j], %c[sub]\n"    // publish this wave's entry count of the next level
       "s_add_u32 s11, s11, vcc_lo\n"
       "s_sub_u32 s15, s22, s11\n"
@@ -1078,7 +1095,8 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
         "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
         "s85", "s86", "s87", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
         "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
-        "v43", "v44", "v45", "v46", "v47", "v48", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58");
+        "v43", "v44", "v45", "v46", "v47", "v48", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+  limit_hit = (maxc & 2048) != 0;  // level cap or spill budget: the pool is malformed (domain-decomposed pools)
   return maxc <= 8;
 }
 
@@ -1094,7 +1112,7 @@ template <bool FUSE, int SUBSH>
 __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane, const float* __restrict__ frec_g,
                                            const float4* posm, float4* __restrict__ acc, int lo, int hi, float eps2,
                                            bh_devinfo* __restrict__ info, int g, int group, const bh_fuse_args& fz,
-                                           int trace_row) {
+                                           int trace_row, int root = 0) {
   const int i = lo + g * group + lane;
   const bool valid = lane < group && i < hi;
 #ifdef BH_FORCE_TRACE
@@ -1115,7 +1133,7 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
   if (threadIdx.x < (unsigned)K) {
     lvl[threadIdx.x * (kCoopSub / 4)] = threadIdx.x == 0 ? 1u : 0u;  // level 0: the root in list 0
     if (threadIdx.x == 0) {
-      lvl[4] = 1u;  // link of record 0: byte offset 0 | one record (root: record 0 of the pool)
+      lvl[4] = ((u32)root << 5) | 1u;  // link of the root: its byte offset | one record
       lvl[5] = (u32)m0;
       lvl[6] = (u32)(m0 >> 32);
     }
@@ -1123,7 +1141,9 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
   __syncthreads();
   const u32 cur = (u32)(size_t)(__attribute__((address_space(3))) u32*)lvl;
   float ax, ay, az;
-  const bool ok = coop_traverse_asm<SUBSH>(frec_g, cur, cur + (u32)K * kCoopSub, K, j, px, py, pz, eps2, ax, ay, az);
+  bool lim = false;
+  const bool ok = coop_traverse_asm<SUBSH>(frec_g, cur, cur + (u32)K * kCoopSub, K, j, px, py, pz, eps2, ax, ay, az,
+                                           lim);
 #ifdef BH_FORCE_TRACE
   if (lane == 0 && trace_row + j < kForceTraceRows) {
     u32* r = g_force_trace + (size_t)(trace_row + j) * 4;
@@ -1136,12 +1156,17 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
   part[(j * 64 + lane) * 3 + 0] = ax;
   part[(j * 64 + lane) * 3 + 1] = ay;
   part[(j * 64 + lane) * 3 + 2] = az;
-  if (lane == 0) bad[j] = ok ? 0u : 1u;
+  if (lane == 0) bad[j] = lim ? 2u : (ok ? 0u : 1u);
   __syncthreads();
   if (j != 0) return;
-  bool redo = false;
-  for (int w = 0; w < K; w++) redo = redo || bad[w] != 0u;
-  if (!redo) {
+  bool redo = false, limited = false;
+  for (int w = 0; w < K; w++) {
+    redo = redo || bad[w] != 0u;
+    limited = limited || bad[w] == 2u;
+  }
+  if (limited) {  // forces of this step are invalid (BH_FLAG_TRAVERSAL_LIMIT); nothing is redone
+    if (lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
+  } else if (!redo) {
     for (int w = 1; w < K; w++) {  // fixed order: wave 0 + wave 1 + ...
       ax += part[(w * 64 + lane) * 3 + 0];
       ay += part[(w * 64 + lane) * 3 + 1];
@@ -1151,8 +1176,9 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
     bool limit = false;
     ax = ay = az = 0.0f;
     if (lane == 0) atomicAdd(&info->redo_waves, 1);
-    if (!fast_traverse<3, false>((cfloat_t*)frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit) && lane == 0)
-      atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
+    if (!fast_traverse<3, true>((cfloat_t*)frec_g, root, m0, px, py, pz, eps2, ax, ay, az, kTraversalBudget, limit) &&
+        lane == 0)
+      atomicOr(&info->flags, limit ? BH_FLAG_TRAVERSAL_LIMIT : BH_FLAG_STACK_OVERFLOW);
   }
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
   if (FUSE) fuse_integrate_and_fold(fz, g, i, valid, lane, px, py, pz, pm, ax, ay, az);
@@ -1182,18 +1208,18 @@ constexpr int kMixedK = 4;
 constexpr int kMixedRun = 16;  // chunks (workgroups of four groups) per XCD run: 64 groups, as in the one-wave launch —
                                // a run of 64 such chunks is 143 us of one XCD's time at 1M bodies, and the XCD that
                                // holds one run more than the others ends the launch that much later
-template <bool FUSE, int SUBSH>
+template <bool FUSE, int SUBSH, bool BUDGET = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                           float4* __restrict__ acc, int hi, float eps2, int xcd_mode,
                                                           bh_devinfo* __restrict__ info, int nbulk, int gb,
-                                                          bh_fuse_args fz) {
+                                                          bh_fuse_args fz, int root = 0) {
   __shared__ __attribute__((aligned(16))) u32 coop_lds[coop_lds_bytes(kMixedK, SUBSH) / 4];
   const int lane = threadIdx.x & 63;
   const int wib = rfl((int)(threadIdx.x >> 6));
   if ((int)blockIdx.x >= nbulk) {
     const int t = (int)blockIdx.x - nbulk;
     coop_group<FUSE, SUBSH>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
-                            gb + t * kMixedK);
+                            gb + t * kMixedK, root);
     return;
   }
   const int w = block_chunk_of<kMixedRun>(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group
@@ -1207,12 +1233,15 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
   const u64 m0 = ~0ull;
   bool limit = false;
-  if (!fast_traverse_asm<false, false, false>(frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit)) {
+  if (!fast_traverse_asm<BUDGET, false, false>(frec_g, root, m0, px, py, pz, eps2, ax, ay, az, kTraversalBudget, limit) &&
+      !limit) {
     ax = ay = az = 0.0f;
     if (lane == 0) atomicAdd(&info->redo_waves, 1);
-    if (!fast_traverse<3, false>((cfloat_t*)frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit) && lane == 0)
+    if (!fast_traverse<3, BUDGET>((cfloat_t*)frec_g, root, m0, px, py, pz, eps2, ax, ay, az, kTraversalBudget, limit) &&
+        !limit && lane == 0)
       atomicOr(&info->flags, BH_FLAG_STACK_OVERFLOW);
   }
+  if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
 #ifdef BH_FORCE_TRACE
   if (lane == 0 && w < kForceTraceRows) {
@@ -1493,11 +1522,16 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
 #define BH_MIXED(F, S)                                                                                        \
   force_mixed_kernel<F, S><<<nbulk + tail, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2, mmode, \
                                                                 c->info, nbulk, gb, F ? fz : bh_fuse_args{})
+#ifdef BH_STUDY
         if (fuse) {
           if (subsh == 11) BH_MIXED(true, 11); else if (subsh == 12) BH_MIXED(true, 12); else BH_MIXED(true, 13);
         } else {
           if (subsh == 11) BH_MIXED(false, 11); else if (subsh == 12) BH_MIXED(false, 12); else BH_MIXED(false, 13);
         }
+#else
+        (void)subsh;
+        if (fuse) BH_MIXED(true, 11); else BH_MIXED(false, 11);
+#endif
 #undef BH_MIXED
         if (fuse) *fused = true;
         return hipGetLastError();
@@ -1511,11 +1545,15 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
 #define BH_COOP(F, S)                                                                                         \
   force_coop_kernel<F, S><<<gc, Kc * 64, coop_lds_bytes(Kc, S), c->stream>>>(                                  \
       (const float*)c->frec, posm, c->acc, clo, hi, e2, cmode, c->info, group, F ? fz : bh_fuse_args{})
+#ifdef BH_STUDY
         if (fuse && bulk == 0) {
           if (subsh == 11) BH_COOP(true, 11); else if (subsh == 12) BH_COOP(true, 12); else BH_COOP(true, 13);
         } else {
           if (subsh == 11) BH_COOP(false, 11); else if (subsh == 12) BH_COOP(false, 12); else BH_COOP(false, 13);
         }
+#else
+        if (fuse && bulk == 0) BH_COOP(true, 11); else BH_COOP(false, 11);
+#endif
 #undef BH_COOP
         if (fuse && bulk == 0) *fused = true;
         if (lo >= bulk) return hipGetLastError();
@@ -1587,6 +1625,19 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   // a wave pops one child block per opened cell: no wave of a well-formed pool can pop more blocks than
   // the pool has records, so this bound never fires on valid data and always ends a walk over a cycle
   const int budget = kTraversalBudget;
+  // big jobs first, short jobs last (force_mixed_kernel), as in bh_step: every pass of the domain-decomposed step is
+  // a launch with its own drain
+  if (c->p.force_variant == 0 && c->p.force_coop == 0 && lo == 0 && group == 64 &&
+      (long long)(hi + 63) / 64 > 2 * force_tail_groups(c)) {
+    const long long G = ((long long)hi + 63) / 64;
+    const int gb = (int)((G - force_tail_groups(c)) & ~3ll), tail = (int)(G - gb);
+    const int mmode = resolve_xcd_mode(c, gb * 64, 64);
+    int nbulk = gb / 4;
+    if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
+    force_mixed_kernel<false, 11, true><<<nbulk + tail, 256, 0, stream>>>(
+        (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, bh_fuse_args{}, root);
+    return hipGetLastError();
+  }
   if (c->p.force_variant == 1)
     force_fast_kernel<1, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
                                                        c->p.eps2, mode, c->info, root, budget, group);
