@@ -77,7 +77,9 @@ def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=10):
 
 
 def issue_roofline(ws, simds, launch_ms):
-    """VALU-issue floor of one force launch from the walk's own event counters (bh_force_walk_stats, counted in
+    """(The counters are those of the one-wave-per-group walk over ALL groups; the groups a launch walks
+    cooperatively evaluate the same record pairs and differ in how a stack entry travels — LDS instead of lanes.)
+    VALU-issue floor of one force launch from the walk's own event counters (bh_force_walk_stats, counted in
     THIS run) priced with the per-form issue costs above.  Instruction counts follow csrc/bh_force.hip:
     a pair = 3 v_pk_add + 3 v_pk_fma + 2 v_cmp + 2 v_rsq + 3 v_pk_mul + 3 v_pk_fma (+ 2 v_cndmask if a record was
     opened) and 2 scalar (s_or + branch); a block = 2-4 s_load + ~13 scalar / branch; a push = ~9 scalar; a stack
@@ -111,6 +113,48 @@ def issue_roofline(ws, simds, launch_ms):
                          "and lone-wave issue rates at the end of the launch are not in it)",
         "wave_lifetime_ms": {"mean": ws.wave_cycles_mean / clock_hz * 1e3, "max": ws.wave_cycles_max / clock_hz * 1e3},
     }
+
+
+def residency_from_trace(rows, slots):
+    """rows: uint32[waves, 4] of Engine.force_launch_trace (start, end on the 100 MHz clock, HW_ID, XCC_ID).
+    -> what the launch did with the GPU's wave slots: Σ wave lifetime / span = mean resident waves,
+    when the last wave started, how many waves were resident along the launch, how long the SIMDs idle at its end."""
+    import numpy as np
+    if rows is None or len(rows) == 0:
+        return None
+    t0 = rows[:, 0].astype(np.int64)
+    t1 = rows[:, 1].astype(np.int64)
+    base = t0.min()
+    t0 = (t0 - base) * 0.01  # us
+    t1 = (t1 - base) * 0.01
+    span = float(t1.max())
+    hw, xcc = rows[:, 2], rows[:, 3] & 0xF
+    key = ((xcc.astype(np.int64) * 16 + ((hw >> 12) & 0xF)) * 16 + ((hw >> 8) & 0xF)) * 4 + ((hw >> 4) & 3)
+    uk, inv = np.unique(key, return_inverse=True)
+    last_end = np.zeros(len(uk))
+    np.maximum.at(last_end, inv, t1)
+    W = len(t0)
+    ev = np.concatenate([np.stack([t0, np.ones(W)], 1), np.stack([t1, -np.ones(W)], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    res = np.cumsum(ev[:, 1])
+    tt = ev[:, 0]
+    at = {}
+    for frac in (0.25, 0.5, 0.75, 0.9, 0.95):
+        k = min(int(np.searchsorted(tt, frac * span)), len(res) - 1)
+        at[f"{frac:.2f}"] = int(res[k])
+    life = t1 - t0
+    mean_res = float(life.sum() / span)
+    return {"waves": int(W), "simds_seen": int(len(uk)), "wave_slots": int(slots), "span_us": span,
+            "mean_resident_waves": mean_res, "mean_resident_frac_of_slots": mean_res / slots,
+            "peak_resident_waves": int(res.max()),
+            "last_wave_start_frac_of_span": float(t0.max() / span),
+            "resident_waves_at_frac_of_span": at,
+            "wave_lifetime_us": {"mean": float(life.mean()), "p10": float(np.percentile(life, 10)),
+                                 "p90": float(np.percentile(life, 90)), "max": float(life.max())},
+            "simd_idle_before_launch_end_us": {"mean": float((span - last_end).mean()),
+                                               "max": float((span - last_end).max())},
+            "note": "one traced launch of the same kernel, grid and placement as the timed steps' force launch, not "
+                    "fused with the integrate step (bh_force_launch_trace)"}
 
 
 def _oracle_steps(O, n, theta, ic, nthreads, budget_s, max_steps):
@@ -384,6 +428,19 @@ def main():
             ws = eng.force_walk_stats()          # the walk's event counters + in-kernel clock, counted now
             props = torch.cuda.get_device_properties(local_rank)
             issue = issue_roofline(ws, 4 * props.multi_processor_count, avg_force_ms)
+            # what the launch does with the GPU's wave slots (7 per SIMD: the walk kernels use 94 scalar registers)
+            issue["residency"] = residency_from_trace(eng.force_launch_trace(), 4 * props.multi_processor_count * 7)
+            groups = (n_total + 63) // 64
+            tail = 4 * props.multi_processor_count * 7 // 3
+            if groups > 2 * tail:
+                launch = (f"force_mixed_kernel<FUSE> (csrc/bh_force.hip): groups 0..{(groups - tail) // 4 * 4 - 1} one wave "
+                          f"each (hand-scheduled depth-first walk), the last {groups - (groups - tail) // 4 * 4} groups four "
+                          "waves each (cooperative level-by-level walk) so that the short jobs fill the slots the long "
+                          "ones leave")
+            else:
+                launch = (f"force_coop_kernel<FUSE> (csrc/bh_force.hip): {groups} groups, "
+                          f"{8 if groups * 8 <= 4 * props.multi_processor_count * 7 else 4} waves per group "
+                          "(cooperative level-by-level walk)")
             # useful arithmetic of the recurrence (ref:205-213): 20 flop per interaction TAKEN by a body (accepted
             # cells V - O and body interactions P: 3 sub, 5 for d2 + eps2, rsq, 2 for the MAC, 3 for f, 6 for the
             # accumulate) and 11 per cell a body OPENS (the MAC half only: its force half is discarded)
@@ -395,8 +452,8 @@ def main():
                 "bound": "valu", "achieved": useful_tflops, "peak": FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": useful_tflops / FP32_VECTOR_TFLOPS,
                 "traffic": traffic, "traffic_provenance": traffic_src,
-                "kernel": "force_fast_kernel<0,false,...,FUSE> (csrc/bh_force.hip, hand-scheduled walk; in bh_step the "
-                          "launch also integrates its bodies and folds the next cube, ~3 us of the launch time)",
+                "kernel": launch + "; in bh_step the launch also integrates its bodies and folds the next cube "
+                          "(~3 us of the launch time)",
                 "avg_launch_ms": avg_force_ms,
                 "launches_timed": int(len(f_ms)),
                 "why_valu": "the walk is bound by VALU instruction ISSUE: every record field arrives in SGPRs, and "

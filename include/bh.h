@@ -198,6 +198,13 @@ typedef struct bh_walk_stats {
   uint64_t reserved[1];
 } bh_walk_stats;
 int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out);
+/* Measurement only: the force launch bh_step would make for all bodies (the same kernel, grid and placement; not
+   fused with the integrate step) with one row of four words per wave: start and end of its walk on the chip-wide
+   100 MHz clock, HW_ID, XCC_ID — the resident waves over time, when the last wave starts, how long every SIMD idles
+   before the launch ends (bench.py roofline.issue.residency, tools/force_trace.py).  rows[4 * capacity_rows];
+   *n_rows = rows written, 0 when the context's force walk has no traced instance (strict_fp, literal_force,
+   force_variant 1, domain-decomposed) or the capacity is too small (a launch has at most 4 rows per 64 bodies). */
+int bh_force_launch_trace(bh_ctx* c, uint32_t* rows, int capacity_rows, int* n_rows);
 
 /* ---- data out ---- */
 /* caller (upload) order; any pointer may be NULL */

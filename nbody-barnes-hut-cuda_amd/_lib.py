@@ -84,6 +84,7 @@ SYMBOLS = [
     ("bh_force_range", C.c_int, [_P, C.c_int, C.c_int]),
     ("bh_force_count", C.c_int, [_P]),
     ("bh_force_walk_stats", C.c_int, [_P, C.POINTER(BhWalkStats)]),
+    ("bh_force_launch_trace", C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
     ("bh_download", C.c_int, [_P] + [_F] * 6),
     ("bh_download_acc", C.c_int, [_P] + [_F] * 3),
     ("bh_download_bounds", C.c_int, [_P, _F]),

@@ -441,6 +441,30 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
   return BH_OK;
 }
 
+int bh_force_launch_trace(bh_ctx* c, uint32_t* rows, int capacity_rows, int* n_rows) {
+  if (!rows || !n_rows || capacity_rows < 1) return BH_ERR_BAD_ARG;
+  BH_NEED(c, BH_ST_COM);
+  *n_rows = 0;
+  u32* dev = nullptr;
+  BH_HIP(c, hipMalloc((void**)&dev, (size_t)capacity_rows * 16));
+  int nr = 0;
+  hipError_t e = hipMemsetAsync(dev, 0, (size_t)capacity_rows * 16, c->stream);
+  if (e == hipSuccess) e = bhk_force_trace(c, dev, capacity_rows, &nr);
+  if (e == hipSuccess && nr > 0) e = hipMemcpyAsync(rows, dev, (size_t)nr * 16, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dev);
+  if (e != hipSuccess) {
+    c->last_hip = (int)e;
+    return BH_ERR_HIP;
+  }
+  if (nr > 0) {  // the launch stored accelerations like bh_force
+    c->stage |= BH_ST_FORCE;
+    c->ever |= BH_ST_FORCE;
+  }
+  *n_rows = nr;
+  return BH_OK;
+}
+
 int bh_force_count(bh_ctx* c) {
   BH_NEED(c, BH_ST_COM);
   const size_t N = (size_t)c->n;

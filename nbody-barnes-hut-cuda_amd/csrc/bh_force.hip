@@ -757,6 +757,7 @@ struct bh_fuse_args {
   u32* cnt;         // [1 + groups] counters of the two-level "last wave" hand-off (left at zero)
   float* bounds_next;
   int waves;        // waves of this launch that own bodies
+  u32* trace;       // TRACE instances: [rows][4] (see trace_row); else unused
 };
 
 __device__ __forceinline__ float fuse_wave_min(float v) {
@@ -874,16 +875,22 @@ __device__ __forceinline__ void fuse_integrate_and_fold(const bh_fuse_args& fz, 
   }
 }
 
-#ifdef BH_FORCE_TRACE  // tools/force_trace.py: per-wave start / end of walk on the 100 MHz clock, HW_ID, XCC_ID
-constexpr int kForceTraceRows = 1 << 18;
-__device__ u32 g_force_trace[kForceTraceRows * 4];
-#endif
+// Measurement (bh_force_launch_trace, TRACE instances of the walk kernels): one row per wave — start / end of its walk on
+// the chip-wide 100 MHz clock, HW_ID, XCC_ID — from which bench.py and tools/force_trace.py take the resident waves
+// over time, the start of the last wave and the idle tail of every SIMD.
+__device__ __forceinline__ void trace_row(u32* tr, int row, u32 t0) {
+  u32* r = tr + (size_t)row * 4;
+  r[0] = t0;
+  r[1] = (u32)__builtin_amdgcn_s_memrealtime();
+  r[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+  r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+}
 
 // BH_WALK_SGPRS: 7 waves per SIMD instead of 6 — a gfx950 SIMD holds floor(800 / (16-aligned SGPR count + 16)) waves
 // (tools/ubench_occ.hip: highest register s72 -> 8 waves, s76 .. s88 -> 7, s92 and above -> 6); the walk's registers
 // end at s87 and the compiler keeps the rest of the kernel below that too
 #define BH_WALK_SGPRS __attribute__((amdgpu_num_sgpr(96)))
-template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false>
+template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const float* __restrict__ frec_g,
                                                          const float4* posm,  // (FUSE: fz.posm is the same buffer)
                                                          float4* __restrict__ acc, int lo, int hi, float G,
@@ -900,9 +907,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const flo
   // a SIMD — half the bodies walk a smaller union of records and two waves per SIMD hide each other's latency
   const int i = lo + (chunk * (int)(blockDim.x >> 6) + wib) * group + lane;
   const bool valid = lane < group && i < hi;
-#ifdef BH_FORCE_TRACE
-  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
-#endif
+  const u32 tr0 = TRACE ? (u32)__builtin_amdgcn_s_memrealtime() : 0u;
   float px, py, pz, pm;
   {
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
@@ -927,17 +932,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const flo
   }
   if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   if (valid) acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
-#ifdef BH_FORCE_TRACE
-  {
-    const int wv = chunk * (int)(blockDim.x >> 6) + wib;
-    if (lane == 0 && wv < kForceTraceRows) {
-      g_force_trace[wv * 4 + 0] = tr0;
-      g_force_trace[wv * 4 + 1] = (u32)__builtin_amdgcn_s_memrealtime();
-      g_force_trace[wv * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-      g_force_trace[wv * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-    }
-  }
-#endif
+  if (TRACE && lane == 0) trace_row(fz.trace, chunk * (int)(blockDim.x >> 6) + wib, tr0);
   if (!FUSE) return;
 
   fuse_integrate_and_fold(fz, chunk * (int)(blockDim.x >> 6) + wib, i, valid, lane, px, py, pz, pm, ax, ay, az);
@@ -1108,16 +1103,14 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
 __host__ __device__ constexpr size_t coop_lds_bytes(int K, int subsh) {
   return (size_t)K * (2 * coop_sub(subsh) + 64 * 3 * sizeof(float) + sizeof(u32));
 }
-template <bool FUSE, int SUBSH>
+template <bool FUSE, int SUBSH, bool TRACE = false>
 __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane, const float* __restrict__ frec_g,
                                            const float4* posm, float4* __restrict__ acc, int lo, int hi, float eps2,
                                            bh_devinfo* __restrict__ info, int g, int group, const bh_fuse_args& fz,
-                                           int trace_row, int root = 0) {
+                                           int trace_row0, int root = 0) {
   const int i = lo + g * group + lane;
   const bool valid = lane < group && i < hi;
-#ifdef BH_FORCE_TRACE
-  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
-#endif
+  const u32 tr0 = TRACE ? (u32)__builtin_amdgcn_s_memrealtime() : 0u;
   float px, py, pz, pm;
   {
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
@@ -1144,15 +1137,7 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
   bool lim = false;
   const bool ok = coop_traverse_asm<SUBSH>(frec_g, cur, cur + (u32)K * kCoopSub, K, j, px, py, pz, eps2, ax, ay, az,
                                            lim);
-#ifdef BH_FORCE_TRACE
-  if (lane == 0 && trace_row + j < kForceTraceRows) {
-    u32* r = g_force_trace + (size_t)(trace_row + j) * 4;
-    r[0] = tr0;
-    r[1] = (u32)__builtin_amdgcn_s_memrealtime();
-    r[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-    r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-  }
-#endif
+  if (TRACE && lane == 0) trace_row(fz.trace, trace_row0 + j, tr0);
   part[(j * 64 + lane) * 3 + 0] = ax;
   part[(j * 64 + lane) * 3 + 1] = ay;
   part[(j * 64 + lane) * 3 + 2] = az;
@@ -1185,7 +1170,7 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
 }
 
 // every group of the launch by K = blockDim.x / 64 waves (2..8): launches that would not fill the GPU otherwise
-template <bool FUSE, int SUBSH>
+template <bool FUSE, int SUBSH, bool TRACE = false>
 __global__ __launch_bounds__(512) BH_WALK_SGPRS void force_coop_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                          float4* __restrict__ acc, int lo, int hi, float eps2,
                                                          int xcd_mode, bh_devinfo* __restrict__ info, int group,
@@ -1193,8 +1178,8 @@ __global__ __launch_bounds__(512) BH_WALK_SGPRS void force_coop_kernel(const flo
   extern __shared__ __attribute__((aligned(16))) u32 coop_lds[];
   const int K = (int)(blockDim.x >> 6);
   const int g = block_chunk(xcd_mode);  // one group per workgroup
-  coop_group<FUSE, SUBSH>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, lo, hi, eps2,
-                          info, g, group, fz, g * K);
+  coop_group<FUSE, SUBSH, TRACE>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, lo, hi,
+                                 eps2, info, g, group, fz, g * K);
 }
 
 // A launch that fills the GPU many times over still ends with one wave lifetime (~0.35 ms at 1M bodies) in which no
@@ -1208,7 +1193,7 @@ constexpr int kMixedK = 4;
 constexpr int kMixedRun = 16;  // chunks (workgroups of four groups) per XCD run: 64 groups, as in the one-wave launch —
                                // a run of 64 such chunks is 143 us of one XCD's time at 1M bodies, and the XCD that
                                // holds one run more than the others ends the launch that much later
-template <bool FUSE, int SUBSH, bool BUDGET = false>
+template <bool FUSE, int SUBSH, bool BUDGET = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                           float4* __restrict__ acc, int hi, float eps2, int xcd_mode,
                                                           bh_devinfo* __restrict__ info, int nbulk, int gb,
@@ -1218,16 +1203,14 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
   const int wib = rfl((int)(threadIdx.x >> 6));
   if ((int)blockIdx.x >= nbulk) {
     const int t = (int)blockIdx.x - nbulk;
-    coop_group<FUSE, SUBSH>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
-                            gb + t * kMixedK, root);
+    coop_group<FUSE, SUBSH, TRACE>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
+                                   gb + t * kMixedK, root);
     return;
   }
   const int w = block_chunk_of<kMixedRun>(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group
   if (w >= gb) return;
   const int i = w * 64 + lane;  // (groups below gb are full: gb * 64 <= hi)
-#ifdef BH_FORCE_TRACE
-  const u32 tr0 = (u32)__builtin_amdgcn_s_memrealtime();
-#endif
+  const u32 tr0 = TRACE ? (u32)__builtin_amdgcn_s_memrealtime() : 0u;
   const float4 p = posm[i];  // ref:196
   float px = p.x, py = p.y, pz = p.z;
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
@@ -1243,15 +1226,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
   }
   if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
-#ifdef BH_FORCE_TRACE
-  if (lane == 0 && w < kForceTraceRows) {
-    u32* r = g_force_trace + (size_t)w * 4;
-    r[0] = tr0;
-    r[1] = (u32)__builtin_amdgcn_s_memrealtime();
-    r[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-    r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-  }
-#endif
+  if (TRACE && lane == 0) trace_row(fz.trace, w, tr0);
   if (FUSE) fuse_integrate_and_fold(fz, w, i, true, lane, px, py, pz, p.w, ax, ay, az);
 }
 
@@ -1589,6 +1564,54 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
   return hipGetLastError();
 }
 
+// Measurement: the launch bh_step would make for all bodies (same kernel, same grid, same placement; not fused with
+// the integrate step), with one trace row per wave (trace_row).  *rows = rows written (<= cap_rows, else nothing runs).
+hipError_t bhk_force_trace(bh_ctx* c, u32* trace, int cap_rows, int* rows) {
+  *rows = 0;
+  if (c->p.strict_fp || c->p.literal_force || c->p.force_variant != 0 || c->dd ||
+      (long long)BH_FREC_POOL(c->rec_cap, c->n) >= (1ll << 27))
+    return hipSuccess;  // no trace for the other walks
+  const int n = c->n, group = force_group(c, n);
+  const int K = force_coop(c, group), bulk = force_bulk_bodies(c, group, K);
+  const int waves = (n + group - 1) / group;
+  const float4* posm = c->posm[c->cur];
+  bh_fuse_args fz{};
+  fz.trace = trace;
+  if (bulk > 0 && bulk < n) {
+    const int gb = bulk / 64, tail = (n - bulk + 63) / 64;
+    if (gb + kMixedK * tail > cap_rows) return hipSuccess;
+    const int mmode = resolve_xcd_mode(c, bulk, 64);
+    int nbulk = gb / 4;
+    if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
+    force_mixed_kernel<false, 11, false, true><<<nbulk + tail, 256, 0, c->stream>>>(
+        (const float*)c->frec, posm, c->acc, n, c->p.eps2, mmode, c->info, nbulk, gb, fz);
+    *rows = gb + kMixedK * tail;
+  } else if (bulk == 0) {
+    if (waves * K > cap_rows) return hipSuccess;
+    int gc = waves;
+    const int cmode = resolve_xcd_mode(c, n, group);
+    if (cmode == 2) gc = (gc + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+    force_coop_kernel<false, 11, true><<<gc, K * 64, coop_lds_bytes(K, 11), c->stream>>>(
+        (const float*)c->frec, posm, c->acc, 0, n, c->p.eps2, cmode, c->info, group, fz);
+    *rows = waves * K;
+  } else {
+    if (waves > cap_rows) return hipSuccess;
+    int tpb = c->p.force_block;
+    if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
+    const int mode = resolve_xcd_mode(c, n, group);
+    int g2 = (waves * 64 + tpb - 1) / tpb;
+    if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+    if (n <= kPrefetchMaxBodies)
+      force_fast_kernel<0, false, true, false, true><<<g2, tpb, 0, c->stream>>>(
+          (const float*)c->frec, posm, c->acc, 0, n, c->p.G, c->p.eps2, mode, c->info, 0, 0, group, fz);
+    else
+      force_fast_kernel<0, false, false, false, true><<<g2, tpb, 0, c->stream>>>(
+          (const float*)c->frec, posm, c->acc, 0, n, c->p.G, c->p.eps2, mode, c->info, 0, 0, group, fz);
+    *rows = waves;
+  }
+  return hipGetLastError();
+}
+
 // the instruction stream of the launch bhk_force would make: the same bodies per wave (force_group) and the same
 // instance of the walk — with the scalar-cache prefetch and every stack entry in the lanes up to kPrefetchMaxBodies
 // bodies, with the stack top in scalar registers above (round-3 review: the small configurations were counted with
@@ -1650,12 +1673,6 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   return hipGetLastError();
 }
 
-#ifdef BH_FORCE_TRACE
-extern "C" int bh_debug_force_trace(void* out, int rows) {
-  if (rows > kForceTraceRows) rows = kForceTraceRows;
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_force_trace), (size_t)rows * 16);
-}
-#endif
 
 hipError_t bhk_pack(bh_ctx* c) {
   const int n = c->n;

@@ -309,6 +309,7 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
 hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows);  // measurement: per-wave event counters of the fast walk
 int bhk_force_walk_rows(const bh_ctx* c);               // waves (rows) of that launch
 #define BH_WALK_ROW 16                                  // u32 words per row
+hipError_t bhk_force_trace(bh_ctx* c, u32* trace, int cap_rows, int* rows);  // measurement: one row per wave
 hipError_t bhk_integrate(bh_ctx* c, bool with_bbox);
 void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 

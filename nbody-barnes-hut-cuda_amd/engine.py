@@ -151,6 +151,16 @@ class Engine:
         self._ck(lib.bh_force_walk_stats(self._h, C.byref(st)), "bh_force_walk_stats")
         return st
 
+    def force_launch_trace(self):
+        """-> uint32[rows, 4]: per wave of the force launch bh_step would make: start, end of its walk (100 MHz clock),
+        HW_ID, XCC_ID (measurement only; empty for contexts whose walk has no traced instance)"""
+        cap = max(1024, (self.n + 63) // 64 * 8 + 64)
+        rows = np.zeros((cap, 4), np.uint32)
+        n = C.c_int(0)
+        self._ck(lib.bh_force_launch_trace(self._h, rows.ctypes.data_as(C.POINTER(C.c_uint32)), cap, C.byref(n)),
+                 "bh_force_launch_trace")
+        return rows[:n.value].copy()
+
     def integrate(self):
         self._ck(lib.bh_integrate(self._h), "bh_integrate")
 

@@ -341,6 +341,39 @@ def test_force_coop_full_level_lists_spill_to_the_wave_stack(pkg, theta):
         assert np.median(rel) <= 3e-6 and rel.max() <= 2e-4, (K, float(np.median(rel)), float(rel.max()))
 
 
+@pytest.mark.parametrize("n", [5000, 70000, 400000])
+def test_force_launch_trace_is_the_product_launch(pkg, n):
+    """bh_force_launch_trace (measurement: bench.py's roofline.issue.residency) runs the traced instance of the launch
+    bh_step makes — cooperative throughout (5,000 / 70,000 bodies: 8 / 4 waves per group) or mixed (400,000) — and
+    stores the same accelerations as bh_force, bit for bit; one row per wave, every SIMD of the GPU seen at the larger
+    sizes, no wave ends before it starts"""
+    ic = pkg.plummer(n, seed=4)
+    e = _engine(pkg, ic)
+    e.tree_stages(); e.force()
+    a = np.stack(e.download_acc(), 1)
+    rows = e.force_launch_trace()
+    b = np.stack(e.download_acc(), 1)
+    assert a.tobytes() == b.tobytes()
+    groups = (n + 63) // 64
+    tail = 256 * 4 * 7 // 3
+    if groups * 8 <= 256 * 4 * 7:
+        want = groups * 8
+    elif groups <= 2 * tail:
+        want = groups * 4
+    else:
+        gb = (groups - tail) // 4 * 4
+        want = gb + 4 * (groups - gb)
+    assert rows.shape == (want, 4), (rows.shape, want)
+    dt = (rows[:, 1].astype(np.int64) - rows[:, 0].astype(np.int64))
+    assert (dt >= 0).all() and dt.max() < 100_000_000
+    assert e.stats().status_flags == 0
+    e.close()
+    s = _engine(pkg, ic, strict_fp=1)
+    s.tree_stages()
+    assert len(s.force_launch_trace()) == 0      # no traced instance of the strict walk
+    s.close()
+
+
 def _check_tree(pkg, orc, ic, **kw):
     e = _engine(pkg, ic, **kw)
     e.tree_stages()

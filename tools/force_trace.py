@@ -1,9 +1,9 @@
-"""Per-wave timeline of one fused force launch (trace build: tools/mkvariant.sh ftrace -DBH_FORCE_TRACE, selected with
-BH_LIB_PATH): start / end of every wave's walk on the chip-wide 100 MHz clock, the SIMD it ran on (HW_ID, XCC_ID).
+"""Per-wave timeline of the force launch bh_step makes (bh_force_launch_trace: the traced instance of the same kernel,
+grid and placement): start / end of every wave's walk on the chip-wide 100 MHz clock, the SIMD it ran on (HW_ID, XCC_ID).
 What it answers: when is the last wave dispatched (T_q), how many waves are resident over time, how long each SIMD
 sits idle before the launch ends (the drain), and how much of the launch a perfect redistribution could recover.
 
-    BH_LIB_PATH=tools/bin/libs/ftrace.so python tools/force_trace.py [n] [theta] [steps]
+    python tools/force_trace.py [n] [theta] [steps]      (BH_LIB_PATH=tools/bin/libs/study.so BH_FORCE_TAIL=0: all one-wave)
 Writes gpurun_out/force_trace_<n>_<theta>.npy (raw rows) and prints the summary."""
 import ctypes as C
 import os
@@ -23,24 +23,9 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 e = pkg.Engine(n, theta=theta)
 e.upload(*pkg.plummer(n, seed=42))
 e.step(steps)
-e.sync()
-# rows of the launch the default engine makes (csrc/bh_force.hip: force_coop, force_bulk_bodies): one per wave
-G = (n + 63) // 64
-slots = 256 * 4 * 6
-T = int(os.environ.get("BH_FORCE_TAIL", 256 * 4 * 7 // 3))
-if G <= slots // 2:          # every group by K waves
-    K = min(8, slots // G) if n > 32 * 1024 else min(8, slots // ((n + 31) // 32))
-    W = ((n + 63) // 64 if n > 32 * 1024 else (n + 31) // 32) * K
-else:
-    gb = max(G - T, 0) & ~3
-    W = G if (T == 0 or gb == 0) else gb + 4 * (G - gb)
-    if gb == 0 and T > 0:
-        W = 4 * G
-rows = np.zeros((W, 4), np.uint32)
-fn = pkg.lib.bh_debug_force_trace
-fn.restype = C.c_int
-fn.argtypes = [C.c_void_p, C.c_int]
-assert fn(rows.ctypes.data_as(C.c_void_p), W) == 0
+e.tree_stages()
+rows = e.force_launch_trace()   # the launch bh_step makes for this context (bh_force_launch_trace)
+W = len(rows)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.save(os.path.join(ROOT, "gpurun_out", f"force_trace_{n}_{theta}.npy"), rows)
 
