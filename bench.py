@@ -219,7 +219,9 @@ def cpu_baseline(n, theta, seed):
         "value": n / r["best_s"], "unit": "particles/s/step", "cores": r["threads"], "kind": "port",
         "sample": f"{r['steps']} whole step(s) of the same {n}-body theta={theta} workload, all stages, "
                   f"OpenMP x{r['threads']} bound to cores; best step {r['best_s']:.3f} s, median {r['median_s']:.3f} s "
-                  f"(force stage of the last step {r['force_s_last']:.3f} s)",
+                  f"(force stage of the last step {r['force_s_last']:.3f} s); the oracle is built with gcc -O3 "
+                  "-fopenmp -ffp-contract=off and NOT -march=native (BASELINE.md §2.1 names it: the .so is built "
+                  "in the build container and travels to the GPU box, so it targets baseline x86-64)",
         "ms_per_step": r["best_s"] * 1e3, "ms_per_step_median": r["median_s"] * 1e3,
         "oracle_counts_per_body": {k: r["counts"][k] / n for k in ("V", "O", "P")},
     }

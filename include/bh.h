@@ -327,7 +327,8 @@ int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts);
      bh_dd_phase_migrate = bh_dd_cube_apply + bh_dd_migrate_pack
      bh_dd_phase_tree    = bh_dd_migrate_apply, then bh_dd_tree unless *more (another migration round comes first)
      bh_dd_phase_let     = bh_dd_force_local (if own_pass) + bh_dd_let_pack
-     bh_dd_phase_force   = bh_dd_top + bh_dd_force + bh_dd_let_check (*fits = 0: repeat X4 with a larger stride)
+     bh_dd_phase_force   = bh_dd_top + bh_dd_let_check, then — every LET fitted — bh_dd_force, whose launch also integrates
+                           the bodies when the rank holds enough of them (*fits = 0: nothing walked, repeat X4 larger)
      bh_dd_phase_end     = bh_integrate + bh_dd_cube_pack (the next step's X1 payload: this rank's min / max are
                            folded by the integrate kernel, no bounding-box launches) */
 int bh_dd_phase_migrate(bh_ctx* c, const void* gathered_x1, void* send_x2, int limit);

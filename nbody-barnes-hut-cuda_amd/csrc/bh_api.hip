@@ -390,8 +390,13 @@ int bh_force(bh_ctx* c) {
 int bh_integrate(bh_ctx* c) {
   BH_NEED(c, BH_ST_FORCE);
   c->bounds_next_ok = false;
-  // domain-decomposed step: the kernel also folds this rank's min / max, the next step's X1 payload
-  BH_HIP(c, bhk_integrate(c, c->dd != nullptr));
+  // domain-decomposed step: the kernel also folds this rank's min / max, the next step's X1 payload — unless the
+  // step's last force pass has done both already (bh_dd_force)
+  if (c->dd && c->dd_integrated) {
+    c->dd_integrated = false;
+  } else {
+    BH_HIP(c, bhk_integrate(c, c->dd != nullptr));
+  }
   c->dd_minmax_ok = c->dd != nullptr;
   c->stage = BH_ST_UPLOADED;  // positions changed: bbox..force must be redone
   return BH_OK;

@@ -758,6 +758,9 @@ struct bh_fuse_args {
   float* bounds_next;
   int waves;        // waves of this launch that own bodies
   u32* trace;       // TRACE instances: [rows][4] (see trace_row); else unused
+  const float4* acc_add;  // domain-decomposed step: the accelerations of the pass that ran before this one (own pieces),
+                          // added first as integrate_kernel adds acc + acc2; null otherwise
+  int raw;          // 1: bounds_next receives the raw min / max (this rank's share of the next global cube), not a cube
 };
 
 __device__ __forceinline__ float fuse_wave_min(float v) {
@@ -787,6 +790,10 @@ __device__ __forceinline__ void fuse_integrate_and_fold(const bh_fuse_args& fz, 
   float mn[3] = {1e10f, 1e10f, 1e10f};  // sentinels ref:138
   float mx[3] = {-1e10f, -1e10f, -1e10f};
   if (valid) {  // ref:227-249, source text, no contraction: v += a dt; clamp |v| to max_speed; p += v dt
+    if (fz.acc_add) {  // own pass + remote pass, in integrate_kernel's order
+      const float4 a0 = fz.acc_add[i];
+      ax = a0.x + ax; ay = a0.y + ay; az = a0.z + az;
+    }
     float4 v = fz.velid[i];
     const float DT = fz.dt, MAX_SPEED = fz.max_speed;
     float vx = v.x + ax * DT;
@@ -865,7 +872,12 @@ __device__ __forceinline__ void fuse_integrate_and_fold(const bh_fuse_args& fz, 
     fn[q] = fuse_wave_min(fn[q]);
     fx[q] = fuse_wave_max(fx[q]);
   }
-  if (lane == 0) {  // the cube of ref:148-154 (write_cube, bh_tree.hip)
+  if (lane == 0 && fz.raw) {  // domain-decomposed step: this rank's min / max (the X1 payload)
+    float* b = fz.bounds_next;
+    b[0] = fn[0]; b[1] = fn[1]; b[2] = fn[2];
+    b[3] = fx[0]; b[4] = fx[1]; b[5] = fx[2];
+    b[6] = b[7] = 0.0f;
+  } else if (lane == 0) {  // the cube of ref:148-154 (write_cube, bh_tree.hip)
     float* b = fz.bounds_next;
     const float size = fmaxf(fx[0] - fn[0], fmaxf(fx[1] - fn[1], fx[2] - fn[2]));  // ref:148
     b[0] = fn[0]; b[1] = fn[1]; b[2] = fn[2];
@@ -1637,7 +1649,12 @@ hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][BH
 
 // domain-decomposed stepping: the local bodies traverse the stitched pool (local tree + imported
 // LET segments) from the top-tree root
-hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream, float4* acc) {
+// fuse_add: non-null = this is the LAST pass of the step (every earlier pass has finished): the launch adds those
+// accelerations (null pointer value (float4*)1: there were none), integrates the bodies and folds this rank's min / max
+// into c->dd_minmax (force_mixed_kernel FUSE); *fused tells whether it did (large local body counts only).
+hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream, float4* acc, const float4* fuse_add,
+                          bool fuse, bool* fused) {
+  if (fused) *fused = false;
   if (hi <= lo) return hipSuccess;
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
@@ -1657,6 +1674,16 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
     const int mmode = resolve_xcd_mode(c, gb * 64, 64);
     int nbulk = gb / 4;
     if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
+    if (fuse && fused && hi == c->n && (int)G <= c->fuse_waves) {
+      bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
+                      c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->dd_minmax, (int)G};
+      fz.acc_add = fuse_add;
+      fz.raw = 1;
+      force_mixed_kernel<true, 11, true><<<nbulk + tail, 256, 0, stream>>>(
+          (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, fz, root);
+      *fused = true;
+      return hipGetLastError();
+    }
     force_mixed_kernel<false, 11, true><<<nbulk + tail, 256, 0, stream>>>(
         (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, bh_fuse_args{}, root);
     return hipGetLastError();

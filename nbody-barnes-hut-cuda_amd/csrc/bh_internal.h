@@ -185,6 +185,7 @@ struct bh_ctx {
   int fuse_waves;
   float* dd_minmax;   // [8] dd mode: this rank's min / max of the positions the last integrate wrote (X1 payload)
   bool dd_minmax_ok;  // set by bh_integrate in dd mode, cleared by anything else that writes positions
+  bool dd_integrated; // the last force pass of the domain-decomposed step already integrated the bodies (bh_dd_force)
 
   // counters (bh_force_count)
   u32 *cV, *cO, *cP;
@@ -304,8 +305,9 @@ hipError_t bhk_gather_bodies(bh_ctx* c, hipStream_t stream);  // no-op unless a 
 hipError_t bhk_build(bh_ctx* c);
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate = false, bool* fused = nullptr);
-hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream,
-                          float4* acc);  // fast kernel from pool record `root`
+hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream, float4* acc,
+                          const float4* fuse_add = nullptr, bool fuse = false,
+                          bool* fused = nullptr);  // fast kernel from pool record `root`
 hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows);  // measurement: per-wave event counters of the fast walk
 int bhk_force_walk_rows(const bh_ctx* c);               // waves (rows) of that launch
 #define BH_WALK_ROW 16                                  // u32 words per row

@@ -5,7 +5,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-f = [i for i, r in enumerate(rows) if "force_fast_kernel" in r["Kernel_Name"]]
+f = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("force_fast_kernel", "force_mixed_kernel", "force_coop_kernel"))]
 i0, i1 = f[which - 1] + 1, f[which] + 1
 t0 = int(rows[i0]["Start_Timestamp"])
 end_prev = int(rows[i0 - 1]["End_Timestamp"])
