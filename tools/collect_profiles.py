@@ -40,21 +40,30 @@ for d in ("prof_fetch", "prof_write"):
             pmc.setdefault(k, {})[c] = {"dispatches": len(v), "mean_KiB": sum(v) / len(v)}
 json.dump(pmc, open(os.path.join(out, "pmc_fetch_write_per_kernel.json"), "w"), indent=1)
 
-fk = [k for k in pmc if "force_fast_kernel" in k]
+# the force launch of bh_step: the FUSED instance (first template argument `true` of force_mixed_kernel /
+# force_coop_kernel, last of force_fast_kernel) — the one bench.py's roofline names (round-3 review: the record used to
+# come from the un-fused launch of the stage calls); the dispatch with the most traffic if several qualify
+def fused(k):
+    return ("force_mixed_kernel<true" in k or "force_coop_kernel<true" in k or
+            ("force_fast_kernel<" in k and k.split("force_fast_kernel<")[1].split(">")[0].replace(" ", "").endswith("true")))
+fk = sorted([k for k in pmc if fused(k) and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]],
+            key=lambda k: -pmc[k]["FETCH_SIZE"]["mean_KiB"])
 if fk:
     k = fk[0]
     cal = {}
-    for name in ("keys_kernel", "integrate_kernel"):
+    for name in ("keys_split_kernel", "com_kernel"):
         kk = [x for x in pmc if name in x]
         if kk:
             cal[name] = {c: pmc[kk[0]][c]["mean_KiB"] for c in pmc[kk[0]]}
     fetch, write = pmc[k]["FETCH_SIZE"]["mean_KiB"], pmc[k]["WRITE_SIZE"]["mean_KiB"]
-    rec = {"n": 1000000, "theta": 0.5, "kernel": "force_fast_kernel", "FETCH_SIZE_KiB": fetch,
+    rec = {"n": 1000000, "theta": 0.5, "kernel": k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
+           "fused_with_integrate": True, "dispatches": pmc[k]["FETCH_SIZE"]["dispatches"], "FETCH_SIZE_KiB": fetch,
            "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "calibration_KiB": cal,
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile.sh), mean over the "
                   "force launches of `bench.py --steps 5`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE "
-                  "counts 64 B per 128-B request (MI355X_MICROARCH.md HBM section). Calibrated in the same run: keys_kernel "
-                  "reads 16 MB and integrate_kernel reads 48 MB (FETCH_SIZE reports half of each); WRITE_SIZE is exact.",
+                  "counts 64 B per 128-B request (MI355X_MICROARCH.md HBM section). The same table holds the streaming kernels "
+                  "of the step as a cross-check (keys_split_kernel reads 16 B and writes 8 B per body, com_kernel<false> "
+                  "writes 32 B per record; FETCH_SIZE reports half of what they read, WRITE_SIZE is exact).",
            "profile": tag}
     path = os.path.join(ROOT, "profiles", "force_traffic.json")
     try:
