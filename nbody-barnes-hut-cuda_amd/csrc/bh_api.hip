@@ -815,13 +815,4 @@ int bh_device_acc(bh_ctx* c, void** dptr, int64_t* bytes) {
   return BH_OK;
 }
 
-#ifdef BH_STUDY  // design-study builds: the raw device info block (pad[0]: longest level list of the cooperative walk)
-int bh_debug_devinfo(bh_ctx* c, int32_t out[8]) {
-  if (!c || !out) return BH_ERR_BAD_ARG;
-  int s = d2h(c, out, c->info, sizeof(bh_devinfo));
-  if (s) return s;
-  return sync_raw(c);
-}
-#endif
-
 }  // extern "C"

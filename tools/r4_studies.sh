@@ -5,7 +5,6 @@ S=$GRAFT_REPO_ROOT/tools/bin/libs/study.so   # tools/mkvariant.sh study -DBH_STU
 ./tools/bin/ubench_occ > $O/r4_ubench_occ.txt 2>&1; cat $O/r4_ubench_occ.txt
 python tools/walk_probe.py > $O/r4_walk_probe.txt 2>&1; grep -v amdgpu $O/r4_walk_probe.txt
 python tools/coop_sweep.py 16384 32768 65536 125000 200000 300000 500000 > $O/r4_coop_sweep.txt 2>&1; grep -v amdgpu $O/r4_coop_sweep.txt
-BH_COOP_SUBSH=13 BH_LIB_PATH=$S python tools/coop_lists.py > $O/r4_coop_lists.txt 2>&1; grep -v amdgpu $O/r4_coop_lists.txt | head -20
 # the drain: force ms per number of cooperatively walked groups at the end of the launch (0 = every group by one wave)
 for cfg in "1000000 0.5" "1000000 0.3" "500000 0.5" "2000000 0.5"; do
   set -- $cfg
