@@ -339,8 +339,8 @@ int bh_dd_phase_end(bh_ctx* c, void* send_x1);
 int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc);
 /* what the last step's migration did, for logs and tests (synchronises): out[0] bodies this rank holds, [1] emigrants
    it found in its last classification, [2] steps since bh_dd_init in which the domain boundaries moved, [3] what the
-   last step did with them: 0 kept (the boundaries are positions in space that persist from step to step and are
-   re-keyed under every step's cube), 1 moved to the exact quantiles (a rank's body count had left n / P by more than
+   last step did with them: 0 kept (a rank owns a fixed interval of the curve: the splitter keys persist from step
+   to step), 1 moved to the exact quantiles (a rank's body count had left n / P by more than
    1.5 %), 2 drawn from position samples (first step, or a boundary would have had to cross a whole rank) */
 int bh_dd_get_info(bh_ctx* c, int32_t out[8]);
 

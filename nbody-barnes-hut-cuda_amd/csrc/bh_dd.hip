@@ -78,15 +78,13 @@ struct bh_dd_state {
   int* fpos;       // same, exclusive scan of flag
   int* nloc;       // [world] body count of every rank after this step's migration
   int samp_cap;    // sample slots per rank in X1 (kSampTotal / world)
-  u64* skeys;      // [world-1] splitter keys under the current cube
-  float4* spos;    // [world-1] splitter POSITIONS (w = 1): a boundary stays where it is in space from step to step
-                   // and is re-keyed under every step's cube; moved only when a rank's body count leaves the
-                   // tolerance band (dd_split_kernel)
+  u64* skeys;      // [world-1] splitter keys: they PERSIST from step to step (a rank owns a fixed interval of the
+                   // curve) and move only when a rank's body count leaves the tolerance band (dd_split_kernel)
   int* piece_tmp;  // [BH_DD_PIECE_CAP] unsorted piece records
   int* piece_idx;  // [BH_DD_PIECE_CAP] pieces in body order
   int* ddi;        // [16] device scalars: 0 piece counter, 1 remote boxes, 2 top pieces, 3 top children,
                    //      4..7 migration results, 8 pieces of this step, 9 steps that moved the splitters,
-                   //      10 splitter positions valid, 11 what the last dd_split_kernel did (0 kept, 1 exact
+                   //      10 splitter keys valid, 11 what the last dd_split_kernel did (0 kept, 1 exact
                    //      quantiles from the ranks' candidates, 2 sample quantiles), 12 emigrants found on this rank
   float4* boxes;   // [world * BH_DD_PIECE_CAP] remote piece boxes (corner, edge), margin applied
   float4* rbox;    // [2 * world] bounding box of each remote rank's pieces + its range in boxes[]
@@ -209,20 +207,20 @@ __global__ __launch_bounds__(256) void dd_x1_pack_kernel(float* __restrict__ sen
 }
 
 // The global cube from the gathered per-rank min / max (exact: min and max are associative; same arithmetic as
-// write_cube of bh_tree.hip, ref:148-154), then this step's splitter keys.  The splitters are POSITIONS that persist
-// (spos): re-keyed under the new cube they cut the curve where they cut it in the previous step, so only bodies
-// that really crossed a boundary change owner (round 3 re-drew them from 2,048 position samples every step: the
-// quantile noise alone moved 2-5 % of every rank's bodies per step).  They move only when some rank's body count
+// write_cube of bh_tree.hip, ref:148-154), then this step's splitter keys.  The splitter KEYS persist: a rank owns a
+// fixed interval of the curve, and only bodies whose key really left it change owner (round 3 re-drew the splitters
+// from 2,048 position samples every step: the quantile noise alone moved 2-5 % of every rank's bodies per step).
+// (Persisting splitter POSITIONS and re-keying them under every new cube measures the same emigrant counts at 8 x 1M,
+// but a position that a coarse cell plane sweeps over jumps by octants along the curve and takes a rank's whole range
+// with it: a 300-step soak ended in a body-capacity overflow that way.)  The keys move only when some rank's body count
 // has left n / P by more than `tol`: then every boundary goes to the exact quantile its neighbours propose
 // (dd_x1_pack_kernel), or — first step, or a proposal missing because a boundary would have to cross a whole rank —
-// to the sample quantiles as in round 3.  Every rank runs this on the same gathered data and the same spos: same result.
+// to the sample quantiles as in round 3.  Every rank runs this on the same gathered data and the same keys: same result.
 __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict__ g, int world, int xf,
                                                         int samp_cap, float* __restrict__ bounds,
                                                         int curve, u64* __restrict__ skeys,
-                                                        float4* __restrict__ spos, int* __restrict__ ddi,
-                                                        long long n_total, float tol) {
+                                                        int* __restrict__ ddi, long long n_total, float tol) {
   __shared__ u64 k[kSampTotal];
-  __shared__ unsigned short ki[kSampTotal];
   __shared__ int nvalid;
   __shared__ float cube[8];
   __shared__ int s_mode;  // 0: keep, 1: the ranks' proposals, 2: sample quantiles
@@ -262,10 +260,23 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
             const long long want = (long long)(q + 1) * n_total / world;
             const float4 up = reinterpret_cast<const float4*>(g + (size_t)(q + 1) * xf + 8)[0];  // rank q+1, lower end
             const float4 dn = reinterpret_cast<const float4*>(g + (size_t)q * xf + 8)[1];        // rank q, upper end
-            if (want > before && up.w > 0.5f) prop[q] = up;
-            else if (want < before && dn.w > 0.5f) prop[q] = dn;
-            else if (want == before) prop[q] = spos[q];
-            else mode = 2;
+            // A proposal is a body picked by its place in the PREVIOUS step's key order; its key under the new cube
+            // must still lie in the range of the rank that proposed it (between this boundary's old key and that
+            // rank's other boundary).  A body that one of the cube's coarse planes has just passed has jumped by
+            // octants along the curve: taking it would hand a whole stretch of the curve to the wrong rank (a
+            // 300-step soak of 8 x 500k met one in its 16th rebalance and overflowed a rank).  Such a boundary stays
+            // where it is for this step; the next step proposes another body.
+            float4 take = make_float4(0.f, 0.f, 0.f, 0.f);  // (w = 0: this boundary stays)
+            if (want > before && up.w > 0.5f) {
+              const u64 kc = body_key<kB>(curve, up.x, up.y, up.z, cube[0], cube[1], cube[2], cube[6]);
+              if (kc >= skeys[q] && (q + 2 >= world || kc < skeys[q + 1])) take = up;
+            } else if (want < before && dn.w > 0.5f) {
+              const u64 kc = body_key<kB>(curve, dn.x, dn.y, dn.z, cube[0], cube[1], cube[2], cube[6]);
+              if (kc < skeys[q] && (q == 0 || kc >= skeys[q - 1])) take = dn;
+            } else if (want != before) {
+              mode = 2;
+            }
+            prop[q] = take;
           }
         }
       }
@@ -277,10 +288,9 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
   }
   __syncthreads();
   const int mode = s_mode;
-  if (mode != 2) {
-    if (tid < world - 1) {
-      const float4 p = mode == 1 ? prop[tid] : spos[tid];
-      if (mode == 1) spos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
+  if (mode != 2) {  // 0: the keys stay; 1: the proposed positions, keyed under this step's cube
+    if (mode == 1 && tid < world - 1 && prop[tid].w > 0.5f) {
+      const float4 p = prop[tid];
       skeys[tid] = body_key<kB>(curve, p.x, p.y, p.z, cube[0], cube[1], cube[2], cube[6]);
     }
     return;
@@ -297,7 +307,6 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
       }
     }
     k[i] = key;
-    ki[i] = (unsigned short)i;
   }
   if (mine) atomicAdd(&nvalid, mine);
   __syncthreads();
@@ -312,9 +321,6 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
         if ((a > b) == up) {
           k[i] = b;
           k[partner] = a;
-          const unsigned short ia = ki[i];
-          ki[i] = ki[partner];
-          ki[partner] = ia;
         }
       }
       __syncthreads();
@@ -323,13 +329,8 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
   const int M = nvalid;  // valid samples sort first (invalid = all ones)
   if (tid < world - 1) {
     if (M > 0) {
-      const int at = (int)(((long long)(tid + 1) * M) / world);
-      const int i = ki[at], r = i / samp_cap, t = i - r * samp_cap;
-      const float4 p = reinterpret_cast<const float4*>(g + (size_t)r * xf + kX1Samples0)[t];
-      spos[tid] = make_float4(p.x, p.y, p.z, 1.0f);
-      skeys[tid] = k[at];
+      skeys[tid] = k[(int)(((long long)(tid + 1) * M) / world)];
     } else {
-      spos[tid] = make_float4(cube[0], cube[1], cube[2], 1.0f);
       skeys[tid] = ~0ull;
     }
   }
@@ -1555,7 +1556,7 @@ void bh_dd_free(bh_ctx* c) {
     (void)hipStreamSynchronize(d->stream_own);
     (void)hipStreamDestroy(d->stream_own);
   }
-  void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->spos, d->piece_tmp,
+  void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
                   d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2,
                   d->cls_done, d->abs_done, d->arrive, c->dd_minmax, d->wmask, d->list_e, d->list_w, d->list_m, d->dstd,
                   d->dtot, d->csum, d->mark_cnt, d->mark_done};
@@ -1637,8 +1638,6 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->fpos, (fl + 1 + 64) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->nloc, 64 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->skeys, 64 * 8) == hipSuccess;
-  ok = ok && hipMalloc((void**)&d->spos, 64 * sizeof(float4)) == hipSuccess;
-  ok = ok && hipMemset(d->spos, 0, 64 * sizeof(float4)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_tmp, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_idx, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->ddi, 16 * 4) == hipSuccess;
@@ -1756,7 +1755,7 @@ int bh_dd_cube_apply(bh_ctx* c, const void* gathered_x1) {
   bh_dd_state* d = c->dd;
   const int xf = x1_floats(d->world);
   dd_split_kernel<<<1, 1024, 0, c->stream>>>((const float*)gathered_x1, d->world, xf, d->samp_cap, c->bounds,
-                                             c->p.key_curve, d->skeys, d->spos, d->ddi, d->n_total, kSplitTolerance);
+                                             c->p.key_curve, d->skeys, d->ddi, d->n_total, kSplitTolerance);
   BH_HIP(c, hipGetLastError());
   c->stage = BH_ST_UPLOADED | BH_ST_BBOX;
   c->ever |= BH_ST_BBOX;

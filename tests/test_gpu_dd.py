@@ -151,8 +151,8 @@ def test_dd_migration_across_ranks():
 
 
 def test_dd_boundaries_persist_and_rebalance():
-    """The domain boundaries are positions in space that persist from step to step (re-keyed under every step's
-    cube) and move only when a rank's body count leaves n / P by more than 1.5 %: 200 steps of a system whose two halves
+    """The domain boundaries (splitter keys) persist from step to step and move only when a rank's body count leaves
+    n / P by more than 1.5 %: 200 steps of a system whose two halves
     stream through each other at first (so the counts drift and the boundaries HAVE to move several times) and then
     settles.  Checked: nobody lost or duplicated; the boundaries moved more than once but in a minority of the
     steps; in the steps that kept them the emigrants are what physically crossed a boundary — per step well under
