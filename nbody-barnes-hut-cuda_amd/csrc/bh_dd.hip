@@ -772,6 +772,9 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
                                                       int* __restrict__ lpos, int* __restrict__ bcnt,
                                                       int* __restrict__ bbase, u32* __restrict__ done) {
   __shared__ float4 sb[kMarkBoxes];
+  __shared__ float4 clo[kMarkBoxes / 8], chi[kMarkBoxes / 8];  // bounding boxes of 8 consecutive piece boxes each (round 4):
+                                                               // the pieces are in curve order, so such a cluster is
+                                                               // compact and one test dismisses eight
   __shared__ float4 srb[128];
   __shared__ float4 cxyz[kMarkChunk];  // candidate: com, threshold
   __shared__ int cidx[kMarkChunk];     // candidate: record index
@@ -786,6 +789,16 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
   for (int i = threadIdx.x; i < 2 * world; i += 256) srb[i] = rbox[i];
   for (int i = threadIdx.x; i < min(NB, kMarkBoxes); i += 256) sb[i] = boxes[i];
   __syncthreads();
+  for (int cl = threadIdx.x; 8 * cl < min(NB, kMarkBoxes); cl += 256) {
+    float4 lo = make_float4(1e30f, 1e30f, 1e30f, 0.f), hi = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
+    for (int i = 8 * cl; i < min(min(NB, kMarkBoxes), 8 * cl + 8); i++) {
+      const float4 b = sb[i];
+      lo.x = fminf(lo.x, b.x); lo.y = fminf(lo.y, b.y); lo.z = fminf(lo.z, b.z);
+      hi.x = fmaxf(hi.x, b.x + b.w); hi.y = fmaxf(hi.y, b.y + b.w); hi.z = fmaxf(hi.z, b.z + b.w);
+    }
+    clo[cl] = lo;
+    chi[cl] = hi;
+  }
   for (int i = threadIdx.x; i < kMarkChunk; i += 256) {
     const int e = e0 + i;
     if (e > rec_cap) break;
@@ -821,12 +834,30 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
         const float dz = fmaxf(fmaxf(lo.z - q.z, q.z - hi.z), 0.0f);
         if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 > q.w) continue;  // the whole rank is too far
       }
-      for (int i = b0; i < b1; i++) {
-        const float4 b = i < kMarkBoxes ? sb[i] : boxes[i];
-        const float dx = fmaxf(fmaxf(b.x - q.x, q.x - (b.x + b.w)), 0.0f);
-        const float dy = fmaxf(fmaxf(b.y - q.y, q.y - (b.y + b.w)), 0.0f);
-        const float dz = fmaxf(fmaxf(b.z - q.z, q.z - (b.z + b.w)), 0.0f);
-        if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 <= q.w) {
+      for (int i = b0; i < b1;) {
+        const int iend = min(b1, (i | 7) + 1);  // the rest of this cluster of eight that belongs to rank r
+        if (iend <= kMarkBoxes) {               // (a cluster may reach into the neighbouring rank's boxes: a superset)
+          const float4 lo2 = clo[i >> 3], hi2 = chi[i >> 3];
+          const float dx = fmaxf(fmaxf(lo2.x - q.x, q.x - hi2.x), 0.0f);
+          const float dy = fmaxf(fmaxf(lo2.y - q.y, q.y - hi2.y), 0.0f);
+          const float dz = fmaxf(fmaxf(lo2.z - q.z, q.z - hi2.z), 0.0f);
+          if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 > q.w) {
+            i = iend;
+            continue;
+          }
+        }
+        bool hit = false;
+        for (; i < iend; i++) {
+          const float4 b = i < kMarkBoxes ? sb[i] : boxes[i];
+          const float dx = fmaxf(fmaxf(b.x - q.x, q.x - (b.x + b.w)), 0.0f);
+          const float dy = fmaxf(fmaxf(b.y - q.y, q.y - (b.y + b.w)), 0.0f);
+          const float dz = fmaxf(fmaxf(b.z - q.z, q.z - (b.z + b.w)), 0.0f);
+          if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 <= q.w) {
+            hit = true;
+            break;
+          }
+        }
+        if (hit) {
           open = true;
           mask |= 1u << r;
           break;
