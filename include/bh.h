@@ -83,18 +83,22 @@ typedef struct bh_params {
   int32_t step_graph;    /* bh_step: 0 = launch its kernels one by one (default), 1 = replay the step as a HIP
                             graph, one per ping-pong parity of the body arrays (measured slower on ROCm 7.2:
                             DESIGN.md)                                                                  */
-  int32_t force_group;   /* bodies per wave of the default force kernel: 64, 32 or 16 (upper lanes idle), or
-                            0 = by launch size: 16 up to 20,480 bodies, 32 up to 57,344, else 64;
-                            speed only                                                               */
+  int32_t force_group;   /* bodies per group of the default force kernel: 64, 32 or 16 (upper lanes idle), or
+                            0 = automatic: 64 (with force_coop = 1, the one-wave walk: 16 up to 20,480 bodies, 32 up to
+                            57,344, else 64).  The one-wave walk's results do not depend on it; with several waves
+                            per group a body's bits depend on its group's composition                       */
   int32_t key_curve;     /* numbering of the 2^21-per-axis cell grid behind the 63-bit keys: 0 = Morton / Z order
                             (the reference's, ref:42-63), 1 = Hilbert order (default).  Same cells, same tree up
                             to the order of the children inside a block and of the bodies in memory; the
                             64-body groups of the force walk are more compact (-5 % force time).  30-bit keys
                             are always Morton (reference-literal code)                                */
-  int32_t force_coop;    /* waves that share the walk of one group of bodies (round 4): 0 = by context size
-                            (as many, up to 8, as keep the launch within ~6 waves per SIMD: 2+ up to ~196,000 bodies),
-                            1 = one wave per group (the depth-first walk), 2..8.  Results are reproducible bit for
-                            bit for a given value; different values differ in the association of the fp32 sums   */
+  int32_t force_coop;    /* waves that share the walk of one group of bodies (round 4): 0 = by context size — 8 while
+                            eight per group fit the GPU at once (~57,000 bodies), 4 up to ~305,000 bodies, above that
+                            one wave per group except for the last ~2,400 groups of the launch, which get four (the
+                            short jobs fill the wave slots the long ones leave: DESIGN.md §4) —, 1 = one wave per
+                            group throughout (the depth-first walk), 2..8 = that many for every group.  Results are
+                            reproducible bit for bit for a given body count and value; different values differ in
+                            the association of the fp32 sums only                                            */
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:

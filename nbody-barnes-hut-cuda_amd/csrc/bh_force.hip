@@ -24,9 +24,14 @@
 //     (>= the 7*21+1 bound for 63-bit keys);
 //   * children of a cell are one contiguous, 64-byte-aligned block of digest pairs, so an opened cell costs
 //     two or four back-to-back scalar loads and up to 4 packed pair evaluations;
-//   * blockIdx is remapped (block_chunk) so that the waves of an XCD share parts of the tree in its private L2.
+//   * blockIdx is remapped (block_chunk) so that the waves of an XCD share parts of the tree in its private L2;
+//   * round 4: a launch is judged by what it does with the GPU's wave slots (bh_force_launch_trace).  The walk lives
+//     in 78 scalar registers (7 waves per SIMD); K waves of one workgroup can share the walk of ONE group level by
+//     level (coop_traverse_asm / force_coop_kernel: launches that do not fill the GPU), and a launch that does fill
+//     it walks its last groups that way so that short jobs fill the slots the long ones leave (force_mixed_kernel).
 // force_kernel<STRICT, COUNT> below is the plain per-record loop on the canonical 32-byte records (bit-exact
-// reference arithmetic, V/O/P counters); force_fast_kernel is the benchmarked one.  integrate lives in bh_tree.hip.
+// reference arithmetic, V/O/P counters); force_fast_kernel / force_coop_kernel / force_mixed_kernel are the benchmarked
+// ones (bhk_force picks by body count).  integrate lives in bh_tree.hip (and in the FUSE epilogue here).
 #include <stdlib.h>
 
 #include "bh_internal.h"
@@ -420,11 +425,13 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // Code:  PRO(q) = MAC(q)              entry of a block of 2q+1 or 2q+2 children
 //        SEG(q) = FORCE(q) || MAC(q-1)   q = 3..1;  SEG(0) = FORCE(0);  SEGm(q) = the same with the open masks
 //        ARMS(q)= pushes of pair q, then SEGm(q)
-// Fixed registers inside the block: s[36:99] record window (pair p at s[36+16p..]), s10-s35, s100, s101 state;
-// v[16:17] = (px,py), v[18:19] = (pz,-), v[20:21] = (eps2,eps2); pair sets (even / odd pairs) d = v[22:27] /
-// v[30:35], rinv = v[28:29] / v[36:37], open masks s[18:19],s[14:15] / s[12:13],s[10:11]; v[38:39] d2,
-// v[40:41] f, v[42:47] six partial accumulators, v48 / v50 / v51 cross-lane stack (link, mask lo, mask hi),
-// s101 / s[22:23] its top entry.
+// Fixed registers inside the block (round 4: everything below s88, see BH_WALK_SGPRS): s[24:87] record window (pair
+// p at s[24+16p..]), s10-s23 state; v[16:17] = (px,py), v[18:19] = (pz,-), v[20:21] = (eps2,eps2); pair sets (even /
+// odd pairs) d = v[22:27] / v[30:35], rinv = v[28:29] / v[36:37]; the open masks live in the window's dead dwords
+// (the `first` fields, which the walk never reads: s[34:35], s[66:67] / s[50:51], s[82:83] — written by v_cmp after
+// the block's loads have landed, dead before the next block's loads are issued); v[38:39] d2, v[40:41] f, v[42:47] six
+// partial accumulators, v48 / v50 / v51 cross-lane stack (link, mask lo, mask hi), s10 / s[22:23] its top entry;
+// EXEC = the lane mask of the entry in hand, written when the entry is popped.
 #define BH_S0 "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v28", "v29", "s[34:35]", "s[66:67]"
 #define BH_S1 "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v36", "v37", "s[50:51]", "s[82:83]"
 // MAC of the pair (X, Y, Z, THR0, THR1) into set (DX, DY, DZ, R, R0, R1, MA, MB)
@@ -572,7 +579,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   "s_branch " SKIP "_%=\n"                                                                                \
   "L_pushB" #q "_%=:\n" BH_PUSH1(F1, M1, MBLO, MBHI)                                                      \
   "s_branch L_segm" #q "_%=\n"
-// pair p of the window: x s[36+16p:37+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11, meta +12/+13, link +14/+15
+// pair p of the window: x s[24+16p:25+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11 (dead: the open masks), meta +12/+13, link +14/+15
 #define BH_P0 "s[24:25]", "s[26:27]", "s[28:29]", "s32", "s33"
 #define BH_P1 "s[40:41]", "s[42:43]", "s[44:45]", "s48", "s49"
 #define BH_P2 "s[56:57]", "s[58:59]", "s[60:61]", "s64", "s65"
@@ -600,7 +607,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // Dispatch on the child count c (s19) by a two-level branch tree — no jump table, no computed jump:
 //   c <= 4: two cache lines are fetched (always fetching four measured +1 %), entry PRO1 (c = 3, 4) or PRO0;
 //   c >= 5: four lines, entry PRO3 (c >= 7; c > 8 also trips the "more than 8 children" redo) or PRO2.
-// The second compare sits between the EXEC write and the wait for the loads.  A block of 0 children is never
+// The second compare sits before the wait for the loads.  A block of 0 children is never
 // built, and no record of such a block can be opened: the open test `thr2 >= d2` is false for a null record
 // (thr2 = -1) whatever d2 is, NaN included.
 #define BH_STAT_WAIT                                                                                     \
