@@ -531,7 +531,8 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   "s_mov_b32 m0, s11\n"                                                                                   \
   "s_branch 3f\n"                                                                                         \
   "4:\n"                                                                                                  \
-  "s_max_u32 s16, s16, 1024\n" /* (64 entries there; beyond: the group is redone) */                       \
+  "s_or_b32 s16, s16, 0x40000000\n" /* (64 entries there; beyond: the group is redone — a flag bit above any  */ \
+                                    /* child count, which s16 otherwise holds the maximum of)                  */ \
   "3:\n"                                                                                                  \
   ".elseif %c[pf]\n"  /* small launches: straight into the lanes (see BH_POP_TAIL) */                      \
   "s_mov_b32 m0, s14\n"                                                                                   \
@@ -1052,7 +1053,7 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
       "L_cpop_%=:\n"                     // an entry of this wave's own stack (its list was full)
       "s_add_u32 vcc_hi, vcc_hi, 0x10000\n"  // at most 65,535 of them per level (upper half of vcc_hi): a cycle in a
       "s_cbranch_scc0 5f\n"              // malformed pool (imported records) ends here, not in a hang
-      "s_or_b32 s16, s16, 2048\n"
+      "s_or_b32 s16, s16, 0x20000000\n"
       "s_mov_b32 s14, 0\n"
       "s_branch L_centry_%=\n"
       "5:\n"
@@ -1072,7 +1073,7 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
       "v_readfirstlane_b32 s11, v59\n"    // that is still descending after 96 follows a cycle; every wave of the
       "s_cmp_gt_u32 s11, 96\n"            // workgroup sees the same count and leaves together
       "s_cbranch_scc0 6f\n"
-      "s_or_b32 s16, s16, 2048\n"
+      "s_or_b32 s16, s16, 0x20000000\n"
       "s_branch L_done_%=\n"
       "6:\n"
       "s_mul_i32 s11, %[j], %c[sub]\n"    // publish this wave's entry count of the next level
@@ -1110,8 +1111,10 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
         "s85", "s86", "s87", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
         "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
         "v43", "v44", "v45", "v46", "v47", "v48", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
-  limit_hit = (maxc & 2048) != 0;  // level cap or spill budget: the pool is malformed (domain-decomposed pools)
-  return maxc <= 8;
+  // s16 = the largest child count met (an unsplit cell of thousands of bodies: up to n < 2^29) | bit 30: the wave's
+  // own stack overflowed | bit 29: level cap or spill budget, the pool is malformed (domain-decomposed pools)
+  limit_hit = (maxc & 0x20000000) != 0;
+  return (maxc & 0x1fffffff) <= 8 && (maxc & 0x40000000) == 0;
 }
 
 // One workgroup of K waves walks one group of `group` bodies (wave j of K; lds: coop_lds_bytes(K)).  Wave 0 adds

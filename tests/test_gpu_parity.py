@@ -318,6 +318,29 @@ def test_force_coop_walk_edge_inputs(pkg, name):
             assert np.abs(a - ref).max() <= 2e-5 * scale, (name, leaf_cap, K)
 
 
+def test_force_coop_unsplit_cells_of_thousands_of_bodies(pkg):
+    """a depth cap of 5 leaves unsplit cells of several thousand bodies; their child count (the walk keeps the largest
+    it met to detect blocks of more than 8 children) must not read as one of the walk's flag bits — found by
+    tools/coop_fuzz.py in round 4: a count above 2,047 looked like "traversal limit" and the group kept partial sums.
+    Such groups are redone by wave 0 with the generic loop: same accelerations as the one-wave walk, no flag."""
+    n = 88123
+    ic = pkg.plummer(n, seed=5)
+    e = _engine(pkg, ic, force_coop=1, max_depth=5, theta=0.8)
+    e.tree_stages(); e.force()
+    ref = np.stack(e.download_acc(), 1).astype(np.float64)
+    assert e.stats().status_flags == 0
+    e.close()
+    for K in (2, 4):
+        e = _engine(pkg, ic, force_coop=K, max_depth=5, theta=0.8)
+        e.tree_stages(); e.force()
+        a = np.stack(e.download_acc(), 1).astype(np.float64)
+        st = e.stats()
+        e.close()
+        assert st.status_flags == 0 and st.force_redo_waves > 0
+        rel = np.sqrt(((a - ref) ** 2).sum(1)) / np.sqrt((ref ** 2).sum(1))
+        assert rel.max() <= 2e-4, (K, float(rel.max()))
+
+
 @pytest.mark.parametrize("theta", [0.3, 0.1])
 def test_force_coop_full_level_lists_spill_to_the_wave_stack(pkg, theta):
     """theta = 0.3 / 0.1 open far more cells per level than a wave's level list holds (127 entries; the longest list
