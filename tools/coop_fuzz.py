@@ -2,7 +2,7 @@
 initial conditions (Plummer, disc, clumps with coincident bodies), waves per group and group sizes; the accelerations
 must agree to the association of fp32 sums (relative |da| median <= 3e-6, max <= 5e-4 of a body's |a|; absolute for
 bodies whose force nearly cancels), no device flag may be raised, and two runs of the same setting must give the same
-bits.   python tools/coop_fuzz.py [cases] [seed]"""
+bits.   python tools/coop_fuzz.py [cases] [seed] [log10 of the largest n: 5.55; 6.2 reaches the mixed launch]"""
 import os
 import sys
 
@@ -15,9 +15,10 @@ import bhpkg  # noqa: E402
 pkg = bhpkg.load()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+top = float(sys.argv[3]) if len(sys.argv) > 3 else 5.55
 bad = 0
 for t in range(cases):
-    n = int(10 ** rng.uniform(0.3, 5.55))
+    n = int(10 ** rng.uniform(0.3 if top < 6 else 5.3, top))
     theta = float(rng.choice([0.2, 0.3, 0.5, 0.5, 0.8, 1.0]))
     leaf_cap = int(rng.choice([1, 1, 1, 4, 8, 16]))
     max_depth = int(rng.choice([21, 21, 21, 8, 5]))
