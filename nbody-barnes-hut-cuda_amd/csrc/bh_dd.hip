@@ -758,11 +758,39 @@ __global__ __launch_bounds__(256) void dd_boxes_kernel(const bh_dd_piece* __rest
 
 // w[e] = records cell e must export = its child count when some remote body could open it:
 // min over the remote boxes of |com - box|^2 + eps2 <= (s/theta)^2, with slack on both sides.
-// A cell with (s/theta)^2 < eps2 is accepted at any distance, so it is never a candidate.  Each block
-// compacts the candidates of its 1024 records in LDS and tests them densely: first against each
-// rank's bounding box, then against that rank's piece boxes.
-constexpr int kMarkChunk = 1024;
-constexpr int kMarkBoxes = 1024;  // remote boxes staged in LDS (more are read from memory)
+// A cell with (s/theta)^2 < eps2 is accepted at any distance, so it is never a candidate.  A block takes chunks of 512
+// records: every thread tests its records against the ranks' bounding boxes; the cells that are near some rank are
+// compacted in LDS and tested against those ranks' piece boxes by eight lanes each.
+constexpr int kMarkChunk = 512;
+constexpr int kMarkBoxes = 512;  // remote boxes staged in LDS (more are read from memory)
+constexpr int kMarkPer = kMarkChunk / 256;
+// no point of the box [lo, hi] can open the candidate q = (com, threshold): |com - box|^2 + eps2 > thr2, with slack
+__device__ __forceinline__ bool box_too_far(const float4 lo, const float4 hi, const float4 q, float eps2) {
+  const float dx = fmaxf(fmaxf(lo.x - q.x, q.x - hi.x), 0.0f);
+  const float dy = fmaxf(fmaxf(lo.y - q.y, q.y - hi.y), 0.0f);
+  const float dz = fmaxf(fmaxf(lo.z - q.z, q.z - hi.z), 0.0f);
+  return (dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 > q.w;
+}
+#ifdef BH_DD_TRACE
+// design-study instrumentation (tools/dd_mark_trace.py): 100 MHz stamps / sums per block of dd_mark_kernel
+__device__ unsigned long long g_dd_trace[2048][8];
+extern "C" int bh_debug_dd_trace(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dd_trace), sizeof(g_dd_trace));
+}
+#define DT_SET(k, v) if (threadIdx.x == 0 && blockIdx.x < 2048) g_dd_trace[blockIdx.x][k] = (v);
+#define DT_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define DT_SET(k, v)
+#define DT_NOW() 0ull
+#endif
+// Round 4 (tools/dd_mark_trace.py): one block per 1,024 records of the POOL's capacity, one thread per candidate
+// cell, was 94 us per rank-step at 8 x 1M bodies and 66 us at 8 x 125,000 — five rounds of blocks at 51 KB of LDS,
+// most of them staging the boxes for chunks past the tree's last record; in the others a quarter of the records were
+// candidates, most of them near no rank at all, and the few near several ranks ran hundreds of dependent LDS reads in
+// one lane while the rest of their wave idled; the block that finished last then scanned 3,800 chunk counts with
+// sixteen barriers per 256.  Now: blocks loop over the chunks that hold records, the rank-box test happens before a
+// cell becomes a candidate, eight lanes share a candidate's piece tests (four pieces per lane and step), and the final
+// scan covers the chunks with records, serially per thread plus one block-wide step.
 __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict__ frec,
                                                       const bh_devinfo* __restrict__ info, int rec_cap,
                                                       const float4* __restrict__ boxes,
@@ -770,163 +798,177 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
                                                       const int* __restrict__ ddi, float eps2,
                                                       int* __restrict__ w, unsigned* __restrict__ wmask,
                                                       int* __restrict__ lpos, int* __restrict__ bcnt,
-                                                      int* __restrict__ bbase, u32* __restrict__ done) {
+                                                      int* __restrict__ bbase, u32* __restrict__ done, int nchunks) {
   __shared__ float4 sb[kMarkBoxes];
-  __shared__ float4 clo[kMarkBoxes / 8], chi[kMarkBoxes / 8];  // bounding boxes of 8 consecutive piece boxes each (round 4):
-                                                               // the pieces are in curve order, so such a cluster is
-                                                               // compact and one test dismisses eight
   __shared__ float4 srb[128];
-  __shared__ float4 cxyz[kMarkChunk];  // candidate: com, threshold
-  __shared__ int cidx[kMarkChunk];     // candidate: record index
-  __shared__ int ccnt[kMarkChunk];     // candidate: child count
-  __shared__ unsigned char oflag[kMarkChunk];  // per-destination mode: record of this block exports its children
+  __shared__ float4 cxyz[kMarkChunk];     // candidate: com, threshold
+  __shared__ int cidx[kMarkChunk];        // candidate: record index
+  __shared__ int ccnt[kMarkChunk];        // candidate: child count
+  __shared__ unsigned cnear[kMarkChunk];  // candidate: ranks whose bounding box is near enough
+  __shared__ unsigned char oflag[kMarkChunk];  // per-destination mode: record of this chunk exports its children
   __shared__ int ncand;
-  const int E = min(info->n_entries, rec_cap);
-  const int NB = ddi[1];
-  const int e0 = blockIdx.x * kMarkChunk;
-  if (threadIdx.x == 0) ncand = 0;
-  for (int i = threadIdx.x; i < kMarkChunk; i += 256) oflag[i] = 0;
-  for (int i = threadIdx.x; i < 2 * world; i += 256) srb[i] = rbox[i];
-  for (int i = threadIdx.x; i < min(NB, kMarkBoxes); i += 256) sb[i] = boxes[i];
-  __syncthreads();
-  for (int cl = threadIdx.x; 8 * cl < min(NB, kMarkBoxes); cl += 256) {
-    float4 lo = make_float4(1e30f, 1e30f, 1e30f, 0.f), hi = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
-    for (int i = 8 * cl; i < min(min(NB, kMarkBoxes), 8 * cl + 8); i++) {
-      const float4 b = sb[i];
-      lo.x = fminf(lo.x, b.x); lo.y = fminf(lo.y, b.y); lo.z = fminf(lo.z, b.z);
-      hi.x = fmaxf(hi.x, b.x + b.w); hi.y = fmaxf(hi.y, b.y + b.w); hi.z = fmaxf(hi.z, b.z + b.w);
-    }
-    clo[cl] = lo;
-    chi[cl] = hi;
-  }
-  for (int i = threadIdx.x; i < kMarkChunk; i += 256) {
-    const int e = e0 + i;
-    if (e > rec_cap) break;
-    bool cand = false;
-    bh_frec r;
-    if (e < E) {
-      r = frec_get(frec, e);
-      cand = r.thr2 * 1.0001f >= eps2;  // implies thr2 >= 0: an openable, massive cell
-    }
-    if (cand) {
-      const int k = atomicAdd(&ncand, 1);
-      cxyz[k] = make_float4(r.x, r.y, r.z, r.thr2 * 1.0001f);
-      cidx[k] = e;
-      ccnt[k] = r.meta & 0x7fffffff;
-    } else {
-      w[e] = 0;
-      if (wmask) wmask[e] = 0u;
-    }
-  }
-  __syncthreads();
-  const int nc = ncand;
-  for (int c = threadIdx.x; c < nc; c += 256) {
-    const float4 q = cxyz[c];
-    bool open = false;
-    unsigned mask = 0u;  // per-destination mode: every rank is tested, not only up to the first that opens
-    for (int r = 0; r < world && (wmask || !open); r++) {
-      const float4 lo = srb[2 * r], hi = srb[2 * r + 1];
-      const int b0 = __float_as_int(lo.w), b1 = __float_as_int(hi.w);
-      if (b1 <= b0) continue;
-      {
-        const float dx = fmaxf(fmaxf(lo.x - q.x, q.x - hi.x), 0.0f);
-        const float dy = fmaxf(fmaxf(lo.y - q.y, q.y - hi.y), 0.0f);
-        const float dz = fmaxf(fmaxf(lo.z - q.z, q.z - hi.z), 0.0f);
-        if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 > q.w) continue;  // the whole rank is too far
-      }
-      for (int i = b0; i < b1;) {
-        const int iend = min(b1, (i | 7) + 1);  // the rest of this cluster of eight that belongs to rank r
-        if (iend <= kMarkBoxes) {               // (a cluster may reach into the neighbouring rank's boxes: a superset)
-          const float4 lo2 = clo[i >> 3], hi2 = chi[i >> 3];
-          const float dx = fmaxf(fmaxf(lo2.x - q.x, q.x - hi2.x), 0.0f);
-          const float dy = fmaxf(fmaxf(lo2.y - q.y, q.y - hi2.y), 0.0f);
-          const float dz = fmaxf(fmaxf(lo2.z - q.z, q.z - hi2.z), 0.0f);
-          if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 > q.w) {
-            i = iend;
-            continue;
-          }
-        }
-        bool hit = false;
-        for (; i < iend; i++) {
-          const float4 b = i < kMarkBoxes ? sb[i] : boxes[i];
-          const float dx = fmaxf(fmaxf(b.x - q.x, q.x - (b.x + b.w)), 0.0f);
-          const float dy = fmaxf(fmaxf(b.y - q.y, q.y - (b.y + b.w)), 0.0f);
-          const float dz = fmaxf(fmaxf(b.z - q.z, q.z - (b.z + b.w)), 0.0f);
-          if ((dx * dx + dy * dy + dz * dz) * 0.9999f + eps2 <= q.w) {
-            hit = true;
-            break;
-          }
-        }
-        if (hit) {
-          open = true;
-          mask |= 1u << r;
-          break;
-        }
-      }
-    }
-    w[cidx[c]] = open ? ccnt[c] : 0;
-    if (wmask) {
-      wmask[cidx[c]] = mask;
-      if (open && ccnt[c] > 0) oflag[cidx[c] - e0] = 1;
-    }
-  }
-  if (!wmask) return;
-  // per-destination mode: the exporting cells are compacted here (record order inside the block, blocks in order:
-  // deterministic) instead of by a separate flag scan over the whole record pool.  lpos[e] = position inside the
-  // block; the block that finishes last turns the block counts into bases (bbase, bbase[blocks] = list length);
-  // dd_let_list_kernel adds them up.
-  __syncthreads();
   __shared__ int wsum2[4];
   __shared__ int s_last;
+  const int E = min(info->n_entries, rec_cap);
+  const int NB = ddi[1];
+  // per-destination mode reads w / wmask only below E (dd_let_list_kernel); the union mode scans w up to rec_cap
+  const int used = wmask ? min(nchunks, (E + kMarkChunk - 1) / kMarkChunk) : nchunks;
+  for (int i = threadIdx.x; i < 2 * world; i += 256) srb[i] = rbox[i];
+  for (int i = threadIdx.x; i < min(NB, kMarkBoxes); i += 256) sb[i] = boxes[i];
+  DT_SET(0, DT_NOW())
+  unsigned long long dt_a = 0, dt_b = 0, dt_c = 0, dt_n = 0, dt_t = 0;
+  (void)dt_a; (void)dt_b; (void)dt_c; (void)dt_n; (void)dt_t;
+  for (int chunk = blockIdx.x; chunk < used; chunk += gridDim.x) {
+    const int e0 = chunk * kMarkChunk;
+    if (e0 >= E) {  // block-uniform: no record here (union mode only)
+      for (int i = threadIdx.x; i < kMarkChunk && e0 + i <= rec_cap; i += 256) w[e0 + i] = 0;
+      continue;
+    }
+    __syncthreads();  // (the previous chunk's candidate arrays are free; first chunk: the boxes are staged)
+    dt_t = DT_NOW();
+    if (threadIdx.x == 0) ncand = 0;
+    for (int i = threadIdx.x; i < kMarkChunk; i += 256) oflag[i] = 0;
+    __syncthreads();
+    {
+      float4 q[kMarkPer];
+      int meta[kMarkPer];
+#pragma unroll
+      for (int u = 0; u < kMarkPer; u++) {  // loads first
+        const int e = e0 + u * 256 + (int)threadIdx.x;
+        q[u] = make_float4(0.f, 0.f, 0.f, -1.0f);
+        meta[u] = 0;
+        if (e < E) {
+          const float* f = reinterpret_cast<const float*>(frec) + (size_t)(e >> 1) * 16 + (e & 1);
+          q[u] = make_float4(f[0], f[2], f[4], f[8] * 1.0001f);
+          meta[u] = reinterpret_cast<const int*>(f)[12];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kMarkPer; u++) {
+        const int e = e0 + u * 256 + (int)threadIdx.x;
+        if (e > rec_cap) break;
+        unsigned near = 0u;
+        if (e < E && q[u].w >= eps2)  // implies thr2 >= 0: an openable, massive cell
+          for (int r = 0; r < world; r++) {
+            const float4 lo = srb[2 * r], hi = srb[2 * r + 1];
+            if (__float_as_int(hi.w) > __float_as_int(lo.w) && !box_too_far(lo, hi, q[u], eps2)) near |= 1u << r;
+          }
+        if (near) {
+          const int k = atomicAdd(&ncand, 1);
+          cxyz[k] = q[u];
+          cidx[k] = e;
+          ccnt[k] = meta[u] & 0x7fffffff;
+          cnear[k] = near;
+        } else {
+          w[e] = 0;
+          if (wmask) wmask[e] = 0u;
+        }
+      }
+    }
+    __syncthreads();
+    dt_a += DT_NOW() - dt_t; dt_t = DT_NOW(); dt_n += (unsigned long long)ncand;
+    // eight lanes per candidate (every branch below is uniform over a team: its lanes stay together)
+    const int nc = ncand;
+    const int team = threadIdx.x >> 3, tl = threadIdx.x & 7, tshift = (threadIdx.x & 63) & ~7;
+    for (int c0 = 0; c0 < nc; c0 += 32) {
+      const int c = c0 + team;
+      if (c >= nc) continue;
+      const float4 q = cxyz[c];
+      unsigned mask = 0u;
+      for (unsigned rm = cnear[c]; rm; rm &= rm - 1) {
+        const int r = __ffs(rm) - 1;
+        const int b0 = __float_as_int(srb[2 * r].w), b1 = __float_as_int(srb[2 * r + 1].w);
+        bool hit = false;
+        for (int i0 = b0 + tl; i0 < b1 + tl && !hit; i0 += 32) {
+          bool h = false;
+          float4 bx[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = min(i0 + 8 * u, b1 - 1);  // (a repeated box changes nothing)
+            bx[u] = i < kMarkBoxes ? sb[i] : boxes[i];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            h = h || !box_too_far(bx[u], make_float4(bx[u].x + bx[u].w, bx[u].y + bx[u].w, bx[u].z + bx[u].w, 0.f), q, eps2);
+          hit = ((unsigned)(__ballot(h) >> tshift) & 0xffu) != 0u;
+        }
+        if (hit) mask |= 1u << r;
+        if (hit && !wmask) break;  // union mode: the first rank that opens settles it
+      }
+      if (tl == 0) {
+        const bool open = mask != 0u;
+        w[cidx[c]] = open ? ccnt[c] : 0;
+        if (wmask) {
+          wmask[cidx[c]] = mask;
+          if (open && ccnt[c] > 0) oflag[cidx[c] - e0] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    dt_b += DT_NOW() - dt_t; dt_t = DT_NOW();
+    if (!wmask) continue;
+    // per-destination mode: the exporting cells are compacted here (record order inside the chunk, chunks in order:
+    // deterministic) instead of by a separate flag scan over the whole record pool.  lpos[e] = position inside the
+    // chunk; the block that finishes last turns the chunk counts into bases (bbase, bbase[nchunks] = list length);
+    // dd_let_list_kernel adds them up.
+    {
+      static_assert(kMarkPer == 2, "two flags per thread");
+      const int t2 = 2 * (int)threadIdx.x;
+      const int f0 = oflag[t2], f1 = oflag[t2 + 1];
+      const int s2 = f0 + f1;
+      int inc = s2;
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const int u = __shfl_up(inc, dd, 64);
+        if (lane >= dd) inc += u;
+      }
+      if (lane == 63) wsum2[wv] = inc;
+      __syncthreads();
+      int pre = inc - s2;
+      for (int k = 0; k < wv; k++) pre += wsum2[k];
+      if (f0) lpos[e0 + t2] = pre;
+      if (f1) lpos[e0 + t2 + 1] = pre + f0;
+    }
+    if (threadIdx.x == 0) bh_publish_i32(bcnt + chunk, wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3]);
+    dt_c += DT_NOW() - dt_t;
+  }
+  DT_SET(1, dt_a) DT_SET(2, dt_b) DT_SET(3, dt_c) DT_SET(4, dt_n) DT_SET(5, DT_NOW())
+  if (!wmask) return;
+  if (threadIdx.x == 0) {
+    bh_published();
+    s_last = bh_last_block(done, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // bases of the chunks that hold records: thread t adds up `per` consecutive counts, one block-wide exclusive scan
+  // of the 256 sums, then every thread writes its chunks' bases
+  const int per = (used + 255) / 256;
+  const int c0 = (int)threadIdx.x * per;
+  int sum = 0;
+  for (int k = 0; k < per; k++)
+    if (c0 + k < used) sum += bh_collect_i32(bcnt + c0 + k);
+  int inc = sum;
   {
-    const int t4 = 4 * (int)threadIdx.x;
-    const int f0 = oflag[t4], f1 = oflag[t4 + 1], f2 = oflag[t4 + 2], f3 = oflag[t4 + 3];
-    const int s4 = f0 + f1 + f2 + f3;
-    int inc = s4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
       const int u = __shfl_up(inc, dd, 64);
       if (lane >= dd) inc += u;
     }
+    __syncthreads();  // (wsum2 was last read before the bh_last_block barrier; kept for clarity)
     if (lane == 63) wsum2[wv] = inc;
     __syncthreads();
-    int pre = inc - s4;
-    for (int k = 0; k < wv; k++) pre += wsum2[k];
-    if (f0) lpos[e0 + t4] = pre;
-    if (f1) lpos[e0 + t4 + 1] = pre + f0;
-    if (f2) lpos[e0 + t4 + 2] = pre + f0 + f1;
-    if (f3) lpos[e0 + t4 + 3] = pre + f0 + f1 + f2;
+    for (int k = 0; k < wv; k++) inc += wsum2[k];
   }
-  if (threadIdx.x == 0) {
-    bh_publish_i32(bcnt + blockIdx.x, wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3]);
-    bh_published();
-    s_last = bh_last_block(done, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __shared__ int carry2;
-  int* part = cidx;  // (the candidate arrays are free now) 256 entries
-  if (threadIdx.x == 0) carry2 = 0;
-  __syncthreads();
-  const int nb = (int)gridDim.x;
-  for (int c0 = 0; c0 < nb; c0 += 256) {
-    const int b = c0 + (int)threadIdx.x;
-    const int v = b < nb ? bh_collect_i32(bcnt + b) : 0;
-    part[threadIdx.x] = v;
-    __syncthreads();
-    for (int dd = 1; dd < 256; dd <<= 1) {
-      const int u = (int)threadIdx.x >= dd ? part[threadIdx.x - dd] : 0;
-      __syncthreads();
-      part[threadIdx.x] += u;
-      __syncthreads();
+  int run = inc - sum;
+  for (int k = 0; k < per; k++)
+    if (c0 + k < used) {
+      bbase[c0 + k] = run;
+      run += bh_collect_i32(bcnt + c0 + k);
     }
-    if (b < nb) bbase[b] = carry2 + part[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry2 += part[255];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) bbase[nb] = carry2;
+  if (threadIdx.x == 255) bbase[nchunks] = inc;  // list length
+  DT_SET(6, DT_NOW())
 }
 
 __device__ __forceinline__ bh_frec reloc(bh_frec fr, int c, const int* __restrict__ w,
@@ -1003,10 +1045,11 @@ __global__ __launch_bounds__(256) void dd_let_list_kernel(const int* __restrict_
                                                           int* __restrict__ lpos, const int* __restrict__ bbase,
                                                           int nblocks, int rec_cap, int lcap,
                                                           int* __restrict__ list_e, int* __restrict__ list_w,
-                                                          unsigned* __restrict__ list_m) {
+                                                          unsigned* __restrict__ list_m,
+                                                          const bh_devinfo* __restrict__ info) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e == 0) lpos[rec_cap] = bbase[nblocks];  // list length (read by the kernels that follow)
-  if (e >= rec_cap || w[e] <= 0) return;
+  if (e >= min(info->n_entries, rec_cap) || w[e] <= 0) return;  // (dd_mark_kernel wrote w below the last record only)
   const int i = bbase[e / kMarkChunk] + lpos[e];  // block base + position inside dd_mark_kernel's block
   lpos[e] = i;                                    // from here on: the cell's position in the list
   if (i >= lcap) return;
@@ -1161,56 +1204,66 @@ __global__ __launch_bounds__(256) void dd_export_pd_kernel(const bh_frec* __rest
   __shared__ int s_tot[64];
   if (threadIdx.x < 64) s_tot[threadIdx.x] = (int)threadIdx.x < world ? dtot[threadIdx.x] : 0;
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int Ln = lpos[rec_cap];
-  if (i >= Ln || Ln > lcap) return;
-  const int e = list_e[i];
-  const int wv = w[e];
-  // destinations that get this block: may open the cell, are not this rank, and their segment fits (else it is
-  // sent closed) and has room for the block
-  unsigned mask = wmask[e] & ~(1u << me);
-  for (unsigned m = mask; m; m &= m - 1) {
-    const int q = __ffs(m) - 1;
-    if (kSegBlocks0 + s_tot[q] > stride || kSegBlocks0 + dstd[(size_t)q * lcap + i] + wv > stride) mask &= ~(1u << q);
-  }
-  if (!mask) return;
-  const bh_frec fr = frec_get(frec, e);
+  if (Ln > lcap) return;
   const int blocks0 = seg0 + kSegBlocks0;
-  // children of a cell, or the body digests of an unsplit multi-body cell: one kind of block.  A child's own
-  // export data is fetched once, then relocated per destination.
-  for (int k = 0; k < wv; k++) {
-    const int c = fr.first + k;
-    const bh_frec cr = frec_get(frec, c);
-    int wc = 0, ci = lcap;
-    unsigned cm = 0u;
-    if (c < rec_cap) {
-      wc = w[c];
-      if (wc > 0) {
-        ci = lpos[c];
-        cm = wmask[c];
-      }
-    }
+  // one work item per (exporting cell, child slot 0..7): a thread that wrote all eight children of its cell to up to
+  // seven destinations was a chain of ~60 dependent loads and stores (48 us per rank-step at 8 x 1M; grid-stride:
+  // the list length is only known on the device)
+  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < 8ll * Ln;
+       it += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(it >> 3), k0 = (int)(it & 7);
+    const int e = list_e[i];
+    const int wv = w[e];  // (an unsplit cell of many bodies has more than eight: slot k0 takes k0, k0 + 8, ...)
+    if (k0 > wv || (k0 == wv && !(wv & 1))) continue;  // slot wv of an odd block: the null digest that ends it
+    // destinations that get this block: may open the cell, are not this rank, and their segment fits (else it is
+    // sent closed) and has room for the block
+    unsigned mask = wmask[e] & ~(1u << me);
     for (unsigned m = mask; m; m &= m - 1) {
       const int q = __ffs(m) - 1;
-      bh_frec o = cr;
+      if (kSegBlocks0 + s_tot[q] > stride || kSegBlocks0 + dstd[(size_t)q * lcap + i] + wv > stride) mask &= ~(1u << q);
+    }
+    if (!mask) continue;
+    const int first = frec_get(frec, e).first;
+    for (int k = k0; k <= wv; k += 8) {
+      if (k == wv) {
+        if (wv & 1)
+          for (unsigned m = mask; m; m &= m - 1) {
+            const int q = __ffs(m) - 1;
+            const int off = kSegBlocks0 + dstd[(size_t)q * lcap + i];
+            if (off + wv < stride) frec_put(send + (size_t)q * stride, off + wv, frec_null());
+          }
+        break;
+      }
+      // a child of the cell, or a body digest of an unsplit multi-body cell: one kind of block.  The child's own
+      // export data is fetched once, then relocated per destination.
+      const int c = first + k;
+      const bh_frec cr = frec_get(frec, c);
+      int wc = 0, ci = lcap;
+      unsigned cm = 0u;
       if (c < rec_cap) {
-        if (wc > 0 && ci < lcap && ((cm >> q) & 1u)) {
-          o.first = blocks0 + dstd[(size_t)q * lcap + ci];
-          o.meta = wc;
-        } else if (o.thr2 >= 0.0f) {  // no body of rank q can open this child: its copy there is closed
-          o.first = 0;
-          o.thr2 = -1.0f;
+        wc = w[c];
+        if (wc > 0) {
+          ci = lpos[c];
+          cm = wmask[c];
         }
       }
-      frec_put(send + (size_t)q * stride, kSegBlocks0 + dstd[(size_t)q * lcap + i] + k, o);
+      for (unsigned m = mask; m; m &= m - 1) {
+        const int q = __ffs(m) - 1;
+        bh_frec o = cr;
+        if (c < rec_cap) {
+          if (wc > 0 && ci < lcap && ((cm >> q) & 1u)) {
+            o.first = blocks0 + dstd[(size_t)q * lcap + ci];
+            o.meta = wc;
+          } else if (o.thr2 >= 0.0f) {  // no body of rank q can open this child: its copy there is closed
+            o.first = 0;
+            o.thr2 = -1.0f;
+          }
+        }
+        frec_put(send + (size_t)q * stride, kSegBlocks0 + dstd[(size_t)q * lcap + i] + k, o);
+      }
     }
   }
-  if (wv & 1)
-    for (unsigned m = mask; m; m &= m - 1) {
-      const int q = __ffs(m) - 1;
-      const int off = kSegBlocks0 + dstd[(size_t)q * lcap + i];
-      if (off + wv < stride) frec_put(send + (size_t)q * stride, off + wv, frec_null());
-    }
 }
 
 // Gathered LET segments are records written by OTHER ranks: before any wave walks them, every openable record
@@ -1907,15 +1960,15 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
                                                    d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;
   const int mark_blocks = (c->rec_cap + kMarkChunk) / kMarkChunk;
-  dd_mark_kernel<<<mark_blocks, 256, 0, c->stream>>>(
+  dd_mark_kernel<<<mark_blocks < 6 * c->num_cus ? mark_blocks : 6 * c->num_cus, 256, 0, c->stream>>>(
       c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w,
-      d->let_mode == 1 ? d->wmask : nullptr, d->dst, d->mark_cnt, d->mark_cnt + mark_blocks + 1, d->mark_done);
+      d->let_mode == 1 ? d->wmask : nullptr, d->dst, d->mark_cnt, d->mark_cnt + mark_blocks + 1, d->mark_done, mark_blocks);
   BH_HIP(c, hipGetLastError());
   if (d->let_mode == 1) {  // `send_x4` holds world segments of `stride` records, exchanged with an all-to-all
     const int n_cap = (c->rec_cap - 8) / 3;
     // dst = lpos: list position of every exporting cell (dd_mark_kernel compacted them block by block)
     dd_let_list_kernel<<<blocks, 256, 0, c->stream>>>(d->w, d->wmask, d->dst, d->mark_cnt + mark_blocks + 1, mark_blocks,
-                                                      c->rec_cap, n_cap, d->list_e, d->list_w, d->list_m);
+                                                      c->rec_cap, n_cap, d->list_e, d->list_w, d->list_m, c->info);
     {
       const int nch = (n_cap + kLetChunk - 1) / kLetChunk;
       const dim3 grid((unsigned)nch, (unsigned)d->world);
@@ -1927,7 +1980,7 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
     dd_export_pd_head_kernel<<<d->world, BH_DD_PIECE_CAP, 0, c->stream>>>(
         c->frec, c->rec_cap, d->w, d->wmask, d->dst, d->dstd, d->dtot, n_cap, d->piece_idx, d->ddi, seg0, stride,
         d->world, d->rank, (bh_frec*)send_x4);
-    dd_export_pd_kernel<<<(n_cap + 255) / 256, 256, 0, c->stream>>>(c->frec, c->rec_cap, d->w, d->wmask, d->dst,
+    dd_export_pd_kernel<<<(int)((8ll * n_cap + 255) / 256 < 4096 ? (8ll * n_cap + 255) / 256 : 4096), 256, 0, c->stream>>>(c->frec, c->rec_cap, d->w, d->wmask, d->dst,
                                                                    d->list_e, d->dstd, d->dtot, n_cap, seg0, stride,
                                                                    d->world, d->rank, (bh_frec*)send_x4);
     BH_HIP(c, hipGetLastError());

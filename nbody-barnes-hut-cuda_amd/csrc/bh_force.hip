@@ -1196,12 +1196,12 @@ template <bool FUSE, int SUBSH, bool TRACE = false>
 __global__ __launch_bounds__(512) BH_WALK_SGPRS void force_coop_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                          float4* __restrict__ acc, int lo, int hi, float eps2,
                                                          int xcd_mode, bh_devinfo* __restrict__ info, int group,
-                                                         bh_fuse_args fz) {
+                                                         bh_fuse_args fz, int root = 0) {
   extern __shared__ __attribute__((aligned(16))) u32 coop_lds[];
   const int K = (int)(blockDim.x >> 6);
   const int g = block_chunk(xcd_mode);  // one group per workgroup
   coop_group<FUSE, SUBSH, TRACE>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, lo, hi,
-                                 eps2, info, g, group, fz, g * K);
+                                 eps2, info, g, group, fz, g * K, root);
 }
 
 // A launch that fills the GPU many times over still ends with one wave lifetime (~0.35 ms at 1M bodies) in which no
@@ -1696,6 +1696,30 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
     }
     force_mixed_kernel<false, 11, true><<<nbulk + tail, 256, 0, stream>>>(
         (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, bh_fuse_args{}, root);
+    return hipGetLastError();
+  }
+  // ... and a pass that would not fill the GPU is cooperative throughout (force_coop_kernel from the top-tree root:
+  // the strong-scaling sizes, 1M bodies over 8 ranks = 125,000 per rank), K as in bh_step
+  if (c->p.force_variant == 0 && c->p.force_coop != 1 && lo == 0 && (c->p.force_group == 0 || c->p.force_group == 64)) {
+    const long long G = ((long long)hi + 63) / 64;
+    const int K = c->p.force_coop >= 2 && c->p.force_coop <= kCoopMaxK
+                      ? c->p.force_coop
+                      : (G * kCoopMaxK <= (long long)c->num_cus * 4 * kWalkWaves ? kCoopMaxK : 4);
+    const int cmode = resolve_xcd_mode(c, hi, 64);
+    int gc = (int)G;
+    if (cmode == 2) gc = (gc + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
+    if (fuse && fused && hi == c->n && (int)G <= c->fuse_waves) {
+      bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
+                      c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->dd_minmax, (int)G};
+      fz.acc_add = fuse_add;
+      fz.raw = 1;
+      force_coop_kernel<true, 11><<<gc, K * 64, coop_lds_bytes(K, 11), stream>>>(
+          (const float*)c->frec, c->posm[c->cur], acc, 0, hi, c->p.eps2, cmode, c->info, 64, fz, root);
+      *fused = true;
+      return hipGetLastError();
+    }
+    force_coop_kernel<false, 11><<<gc, K * 64, coop_lds_bytes(K, 11), stream>>>(
+        (const float*)c->frec, c->posm[c->cur], acc, 0, hi, c->p.eps2, cmode, c->info, 64, bh_fuse_args{}, root);
     return hipGetLastError();
   }
   if (c->p.force_variant == 1)

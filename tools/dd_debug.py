@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="one force pass after X4 instead of own + remote passes")
     ap.add_argument("--let-mode", type=int, default=None, help="X4: 0 all-gather of the union, 1 per-destination all-to-all (default: the stepper's)")
+    ap.add_argument("--force-coop", type=int, default=0, help="bh_params.force_coop (1 = one wave per group)")
     args = ap.parse_args()
     import torch
     pkg = bhpkg.load()
@@ -53,7 +54,7 @@ def main():
             torch.cuda.set_device(0)
             st = bhdist.DomainStepper(pkg, ic, bhdist.LocalComm(group, r), 0, stream=stream, order=order,
                                       mig_frac=args.mig_frac, split=not args.no_split, theta=args.theta,
-                                      let_mode=args.let_mode)
+                                      let_mode=args.let_mode, force_coop=args.force_coop)
             steppers[r] = st
             group.barrier.wait()
             for s in range(args.steps):
