@@ -800,6 +800,7 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
                                                       int* __restrict__ lpos, int* __restrict__ bcnt,
                                                       int* __restrict__ bbase, u32* __restrict__ done, int nchunks) {
   __shared__ float4 sb[kMarkBoxes];
+  __shared__ float4 clo[kMarkBoxes / 8], chi[kMarkBoxes / 8];  // bounding boxes of 8 consecutive piece boxes each
   __shared__ float4 srb[128];
   __shared__ float4 cxyz[kMarkChunk];     // candidate: com, threshold
   __shared__ int cidx[kMarkChunk];        // candidate: record index
@@ -815,6 +816,17 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
   const int used = wmask ? min(nchunks, (E + kMarkChunk - 1) / kMarkChunk) : nchunks;
   for (int i = threadIdx.x; i < 2 * world; i += 256) srb[i] = rbox[i];
   for (int i = threadIdx.x; i < min(NB, kMarkBoxes); i += 256) sb[i] = boxes[i];
+  __syncthreads();
+  for (int cl = threadIdx.x; 8 * cl < min(NB, kMarkBoxes); cl += 256) {
+    float4 lo = make_float4(1e30f, 1e30f, 1e30f, 0.f), hi = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
+    for (int i = 8 * cl; i < min(min(NB, kMarkBoxes), 8 * cl + 8); i++) {
+      const float4 b = sb[i];
+      lo.x = fminf(lo.x, b.x); lo.y = fminf(lo.y, b.y); lo.z = fminf(lo.z, b.z);
+      hi.x = fmaxf(hi.x, b.x + b.w); hi.y = fmaxf(hi.y, b.y + b.w); hi.z = fmaxf(hi.z, b.z + b.w);
+    }
+    clo[cl] = lo;
+    chi[cl] = hi;
+  }
   DT_SET(0, DT_NOW())
   unsigned long long dt_a = 0, dt_b = 0, dt_c = 0, dt_n = 0, dt_t = 0;
   (void)dt_a; (void)dt_b; (void)dt_c; (void)dt_n; (void)dt_t;
@@ -879,18 +891,21 @@ __global__ __launch_bounds__(256) void dd_mark_kernel(const bh_frec* __restrict_
         const int r = __ffs(rm) - 1;
         const int b0 = __float_as_int(srb[2 * r].w), b1 = __float_as_int(srb[2 * r + 1].w);
         bool hit = false;
-        for (int i0 = b0 + tl; i0 < b1 + tl && !hit; i0 += 32) {
-          bool h = false;
-          float4 bx[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int i = min(i0 + 8 * u, b1 - 1);  // (a repeated box changes nothing)
-            bx[u] = i < kMarkBoxes ? sb[i] : boxes[i];
+        // clusters of eight consecutive boxes first (the pieces are in curve order: a cluster is compact), one per
+        // lane and step; then the eight pieces of a cluster that is near, one per lane
+        for (int k0 = b0 >> 3; k0 <= (b1 - 1) >> 3 && !hit; k0 += 8) {
+          const int k = k0 + tl;
+          bool nearc = false;
+          if (k <= (b1 - 1) >> 3) nearc = 8 * k + 8 > kMarkBoxes || !box_too_far(clo[k], chi[k], q, eps2);
+          for (unsigned cm = (unsigned)(__ballot(nearc) >> tshift) & 0xffu; cm && !hit; cm &= cm - 1) {
+            const int i = 8 * (k0 + __ffs(cm) - 1) + tl;
+            bool h = false;
+            if (i >= b0 && i < b1) {  // (a cluster may reach into the neighbouring ranks' boxes)
+              const float4 bx = i < kMarkBoxes ? sb[i] : boxes[i];
+              h = !box_too_far(bx, make_float4(bx.x + bx.w, bx.y + bx.w, bx.z + bx.w, 0.f), q, eps2);
+            }
+            hit = ((unsigned)(__ballot(h) >> tshift) & 0xffu) != 0u;
           }
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            h = h || !box_too_far(bx[u], make_float4(bx[u].x + bx[u].w, bx[u].y + bx[u].w, bx[u].z + bx[u].w, 0.f), q, eps2);
-          hit = ((unsigned)(__ballot(h) >> tshift) & 0xffu) != 0u;
         }
         if (hit) mask |= 1u << r;
         if (hit && !wmask) break;  // union mode: the first rank that opens settles it
@@ -1960,7 +1975,7 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
                                                    d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;
   const int mark_blocks = (c->rec_cap + kMarkChunk) / kMarkChunk;
-  dd_mark_kernel<<<mark_blocks < 6 * c->num_cus ? mark_blocks : 6 * c->num_cus, 256, 0, c->stream>>>(
+  dd_mark_kernel<<<mark_blocks < 4 * c->num_cus ? mark_blocks : 4 * c->num_cus, 256, 0, c->stream>>>(
       c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w,
       d->let_mode == 1 ? d->wmask : nullptr, d->dst, d->mark_cnt, d->mark_cnt + mark_blocks + 1, d->mark_done, mark_blocks);
   BH_HIP(c, hipGetLastError());
