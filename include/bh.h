@@ -98,7 +98,8 @@ typedef struct bh_params {
                             short jobs fill the wave slots the long ones leave: DESIGN.md §4) —, 1 = one wave per
                             group throughout (the depth-first walk), 2..8 = that many for every group.  Results are
                             reproducible bit for bit for a given body count and value; different values differ in
-                            the association of the fp32 sums only                                            */
+                            the association of the fp32 sums only.  The passes of the domain-decomposed step
+                            (bh_dd_*) follow the same rule with the rank's body count                        */
 } bh_params;
 
 /* One 32-byte octree record ("entry").  The tree is an array of entries:
