@@ -526,17 +526,19 @@ static int step_launch(bh_ctx* c) {
   BH_MARK(3);
   // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan on the side
   // stream while the main stream builds the tree (both are small, latency-bound grids).  Each event hand-over
-  // costs the streams ~7 us (seen as gaps in the kernel trace), so below BH_FORK_MIN_N bodies — where gather +
-  // scan are ~20 us — everything stays on the main stream.
+  // costs the streams ~7 us (seen as gaps in the kernel trace), so below BH_FORK_MIN_N bodies everything stays on
+  // the main stream and the scan's tiles ride in the build's own launches (bhk_build pm_scan).
   const bool fork = c->n >= BH_FORK_MIN_N;
   if (fork) {
     BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
     BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
   }
   BH_HIP(c, bhk_gather_bodies(c, fork ? c->stream2 : c->stream));  // splitter sort: the bodies follow the keys here
-  BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, fork));
+  // (one stream: the scan's tiles ride in the build's launches, two launches less — bhk_build)
+  const bool ride = !fork;
+  if (!ride) BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, fork));
   if (fork) BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
-  BH_HIP(c, bhk_build(c));                     // ref:266-275
+  BH_HIP(c, bhk_build(c, ride));               // ref:266-275
   BH_MARK(4);
   if (fork) BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
   // digests only unless something reads the canonical records after this step (strict / literal kernels)

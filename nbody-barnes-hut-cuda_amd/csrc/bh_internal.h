@@ -222,7 +222,12 @@ struct bh_ctx {
 #define BH_INT_SMALL_N 163840  // bodies up to which integrate_kernel<true> uses 1024-body blocks
 #endif
 #ifndef BH_FORK_MIN_N
-#define BH_FORK_MIN_N 163840  // bodies from which bh_step runs body gather + COM prefix scan on the second stream
+#define BH_FORK_MIN_N 800000  // bodies from which bh_step runs body gather + COM prefix scan on the second stream; below,
+                              // the bucket sort gathers the bodies and the scan's tiles ride in the build's launches
+                              // (bhk_build pm_scan).  Round 4, ms/step one stream / two: 163,840 bodies 0.332 / 0.343,
+                              // 250,000 0.449 / 0.459, 500,000 0.744 / 0.751, 700,000 0.965 / 0.968, 1M 1.291 / 1.290,
+                              // 1.5M 1.929 / 1.919, 4M 5.39 / 5.37 (tools/fork_sweep.sh; before the scan rode along the
+                              // second stream paid from 163,840)
 #endif
 #define BH_BLKDONE_STRIDE(n) ((size_t)(n) / 8192 + 4)  // one counter per 32 tiles of >= 256 pairs
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
@@ -302,7 +307,7 @@ bool bhk_sort_split_eligible(const bh_ctx* c);        // splitter sort: keys + b
 hipError_t bhk_keys_split(bh_ctx* c);
 hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather);
 hipError_t bhk_gather_bodies(bh_ctx* c, hipStream_t stream);  // no-op unless a gather is pending
-hipError_t bhk_build(bh_ctx* c);
+hipError_t bhk_build(bh_ctx* c, bool pm_scan = false);  // pm_scan: + the COM prefix scan (small steps, bh_tree.hip)
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate = false, bool* fused = nullptr);
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream, float4* acc,

@@ -17,6 +17,7 @@
 //             a cell's sums are P[hi] - P[lo], rounded once to fp32.  Deterministic, no atomics,
 //             more accurate than any fp32 summation order (the reference's is non-deterministic).
 #include "bh_internal.h"
+#include "bh_scan_body.h"
 #include "bh_keys.h"
 
 namespace {
@@ -323,10 +324,10 @@ __device__ __forceinline__ void child_bounds(const u64* __restrict__ k, int a, i
 
 // d[j] = leading octal digits shared by keys j-1 and j (0..B); d[0] = d[n] = -1 (sentinels);
 // samp[] = every 2^ss-th key (bisection seeds of the wide-cell searches)
-__global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int n, int B,
-                                                  signed char* __restrict__ d, int ss, u64* __restrict__ samp,
-                                                  bh_devinfo* __restrict__ info) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void lcp_body(const int bid, const u64* __restrict__ k, int n, int B,
+                                         signed char* __restrict__ d, int ss, u64* __restrict__ samp,
+                                         bh_devinfo* __restrict__ info) {
+  const int j = bid * 256 + (int)threadIdx.x;
   if (j == 0) {  // first kernel of the build: tree statistics restart; the sticky flags (4th word) survive
     info->n_internal = 0;
     info->n_entries = 0;
@@ -336,6 +337,28 @@ __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int
   const u64 kj = (j < n) ? k[j] : 0ull;
   if (j < n && (j & ((1 << ss) - 1)) == 0) samp[j >> ss] = kj;
   d[j] = (j == 0 || j == n) ? (signed char)-1 : (signed char)common_digits(k[j - 1], kj, B);
+}
+__global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int n, int B,
+                                                  signed char* __restrict__ d, int ss, u64* __restrict__ samp,
+                                                  bh_devinfo* __restrict__ info) {
+  lcp_body((int)blockIdx.x, k, n, B, d, ss, samp, info);
+}
+// A step of fewer than BH_FORK_MIN_N bodies has no second stream for the COM prefix scan (the hand-over costs ~13 us
+// of gaps), and its kernels are latency-bound launches: the scan's tiles ride in the build's launches instead —
+// tile sums beside the lcp blocks here, the prefixes beside the pairs blocks (pairs_scan_apply_kernel): two
+// launches less on the only stream (65,536 bodies: 0.217 -> 0.205 ms/step, 16,384: 0.145 -> 0.138; with it one
+// stream is the faster arrangement up to ~1M bodies: BH_FORK_MIN_N).
+__global__ __launch_bounds__(256) void lcp_scan_reduce_kernel(const u64* __restrict__ k, int n, int B,
+                                                              signed char* __restrict__ d, int ss,
+                                                              u64* __restrict__ samp, bh_devinfo* __restrict__ info,
+                                                              int lcp_blocks, const float4* __restrict__ posm,
+                                                              int scan_tiles, bh_d4* tile_sums,
+                                                              u32* __restrict__ done) {
+  if ((int)blockIdx.x < lcp_blocks)
+    lcp_body((int)blockIdx.x, k, n, B, d, ss, samp, info);
+  else
+    bhscan::reduce_body<bhscan::OpD4, bhscan::LoadPM>((int)blockIdx.x - lcp_blocks, scan_tiles, bhscan::LoadPM{posm}, n,
+                                                      nullptr, tile_sums, done);
 }
 
 // Cell of pair j at level L = d[j]:   start a = nearest i < j with d[i] < L,
@@ -525,19 +548,19 @@ __device__ __forceinline__ void build_window(const signed char* __restrict__ d, 
 }
 
 template <int TILE>
-__global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
-                                                    const signed char* __restrict__ d, int n, int B, int D,
-                                                    int cap, const u64* __restrict__ ksamp, int ns, int ss,
-                                                    int* __restrict__ pa, int* __restrict__ pb,
-                                                    int* __restrict__ pn, int* __restrict__ cb,
-                                                    int* __restrict__ ttot, int tp_off,
-                                                    u32* __restrict__ done_count,
-                                                    bh_devinfo* __restrict__ info) {
+__device__ __forceinline__ void pairs_body(const int bid, const int nblk, const u64* __restrict__ k,
+                                           const signed char* __restrict__ d, int n, int B, int D,
+                                           int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                           int* __restrict__ pa, int* __restrict__ pb,
+                                           int* __restrict__ pn, int* __restrict__ cb,
+                                           int* __restrict__ ttot, int tp_off,
+                                           u32* __restrict__ done_count,
+                                           bh_devinfo* __restrict__ info) {
   __shared__ u64 s_samp[kSampMax];
   __shared__ __attribute__((aligned(16))) int pnl[TILE];  // child counts of the tile's pairs
   __shared__ u64 m[kPairLevels][kPairWords];
   __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
-  const int t0 = blockIdx.x * TILE;
+  const int t0 = bid * TILE;
   const int base = t0 - kHalo;  // global position of window slot 0
   const int lane = threadIdx.x & 63;
   TT_STAMP(0, 0)
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   __syncthreads();
   TT_STAMP(0, 2)
 #ifdef BH_TREE_TRACE
-  if (threadIdx.x == 0 && blockIdx.x < 8192) g_tree_trace[0][blockIdx.x][6] = (unsigned long long)nwide;
+  if (threadIdx.x == 0 && bid < 8192) g_tree_trace[0][bid][6] = (unsigned long long)nwide;
 #endif
   // phase 2: wide cells by key search, 16 lanes per pair: lane v = 0..8 finds the first key whose (L+1)-digit
   // prefix is >= pj*8 + v — v = 0 is the cell's start a, v = 8 its end b, 1..7 the octant boundaries — so all
@@ -673,7 +696,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
       if (j0 + q < n) cb[j0 + q] = run;
       run += v[q];
     }
-    if (threadIdx.x == 255) bh_publish_i32(ttot + blockIdx.x, ex + sum);
+    if (threadIdx.x == 255) bh_publish_i32(ttot + bid, ex + sum);
   }
   // tree statistics: reduce in LDS, then ONE pair of global atomics per block (a global atomic per
   // thread put ~31K same-address atomics in a row: 90 of this kernel's 116 us at 1M bodies).
@@ -701,11 +724,11 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   TT_STAMP(0, 4)
   if (threadIdx.x == 255) {
     bh_published();
-    s_last = bh_last_block(done_count, (int)blockIdx.x, (int)gridDim.x) ? 1 : 0;
+    s_last = bh_last_block(done_count, bid, nblk) ? 1 : 0;
   }
   __syncthreads();
   if (s_last) {
-    const int ntiles = (int)gridDim.x;
+    const int ntiles = nblk;
     int* tpre = ttot + tp_off;
     int carry = 0;
     // this is a serial tail of the kernel: eight totals per thread, loaded together (one agent-scope round trip
@@ -739,6 +762,39 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
     }
     if (threadIdx.x == 0) tpre[ntiles] = carry;
   }
+}
+
+template <int TILE>
+__global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
+                                                    const signed char* __restrict__ d, int n, int B, int D,
+                                                    int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                                    int* __restrict__ pa, int* __restrict__ pb,
+                                                    int* __restrict__ pn, int* __restrict__ cb,
+                                                    int* __restrict__ ttot, int tp_off,
+                                                    u32* __restrict__ done_count,
+                                                    bh_devinfo* __restrict__ info) {
+  pairs_body<TILE>((int)blockIdx.x, (int)gridDim.x, k, d, n, B, D, cap, ksamp, ns, ss, pa, pb, pn, cb, ttot, tp_off,
+                   done_count, info);
+}
+// (see lcp_scan_reduce_kernel) blocks [0, pair_blocks): the pairs; the rest: the COM prefix scan's second pass
+template <int TILE>
+__global__ __launch_bounds__(256) void pairs_scan_apply_kernel(const u64* __restrict__ k,
+                                                               const signed char* __restrict__ d, int n, int B, int D,
+                                                               int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                                               int* __restrict__ pa, int* __restrict__ pb,
+                                                               int* __restrict__ pn, int* __restrict__ cb,
+                                                               int* __restrict__ ttot, int tp_off,
+                                                               u32* __restrict__ done_count,
+                                                               bh_devinfo* __restrict__ info, int pair_blocks,
+                                                               const float4* __restrict__ posm, int scan_tiles,
+                                                               const bh_d4* __restrict__ tile_sums,
+                                                               bh_d4* __restrict__ P) {
+  if ((int)blockIdx.x < pair_blocks)
+    pairs_body<TILE>((int)blockIdx.x, pair_blocks, k, d, n, B, D, cap, ksamp, ns, ss, pa, pb, pn, cb, ttot, tp_off,
+                     done_count, info);
+  else
+    bhscan::apply_body<bhscan::OpD4, bhscan::LoadPM>((int)blockIdx.x - pair_blocks, bhscan::LoadPM{posm}, n, nullptr,
+                                                     tile_sums, scan_tiles, P);
 }
 
 // entry offset of the child block of the cell whose representative pair is j
@@ -1289,8 +1345,11 @@ extern "C" int bh_debug_tree_trace(void* out) {
 }
 #endif
 
-hipError_t bhk_build(bh_ctx* c) {
+// pm_scan: also the fp64 prefix sums of (m, m x, m y, m z) over the sorted bodies (what bhk_scan_pm writes into c->P
+// for the COM stage), their tiles riding in the lcp / pairs launches (small steps: lcp_scan_reduce_kernel)
+hipError_t bhk_build(bh_ctx* c, bool pm_scan) {
   const int n = c->n;
+
   c->rec_proto = true;  // records carry their body range in x / y until the (canonical) COM stage has run
   c->com_digests = false;
   const u64* k = c->keys[c->key_buf];
@@ -1298,7 +1357,16 @@ hipError_t bhk_build(bh_ctx* c) {
   int ss = 12;
   while (((n + (1 << ss) - 1) >> ss) > kSampMax) ss++;
   const int ns = (n + (1 << ss) - 1) >> ss;
-  lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info);
+  const int lcp_blocks = (n + 1 + 255) / 256;
+  const int scan_tiles = (n + BH_SCAN_TILE - 1) / BH_SCAN_TILE;
+  bh_d4* const tile_sums = reinterpret_cast<bh_d4*>(c->scan_tmp2);  // (the side stream's scratch: idle in such a step)
+  u32* const scan_done = reinterpret_cast<u32*>(reinterpret_cast<char*>(c->scan_tmp2) + c->scan_cnt_off);
+  if (pm_scan)
+    lcp_scan_reduce_kernel<<<lcp_blocks + scan_tiles, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info,
+                                                                          lcp_blocks, c->posm[c->cur], scan_tiles,
+                                                                          tile_sums, scan_done);
+  else
+    lcp_kernel<<<lcp_blocks, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info);
   // 1024 pairs per block; 256 up to 163,840 bodies, where n / 1024 blocks leave most of the 256 CUs idle and a
   // block's four rounds are pure latency (65,536 bodies: pairs 22 -> 13 us, emit 28 -> 15 us); the halo stays 1024
   const int tile = (n <= BH_PAIR_SMALL_N) ? 256 : kPairTile;
@@ -1306,15 +1374,25 @@ hipError_t bhk_build(bh_ctx* c) {
   const int tp_off = n / tile + 2;
   // child-block offsets = tile base (ttot[tp_off ..]) + offset in the tile (cb[]), both written by pairs_kernel
   if (tile == 256) {
-    pairs_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
-                                                     c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done, c->info);
+    if (pm_scan)
+      pairs_scan_apply_kernel<256><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
+          k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
+          c->info, ntiles, c->posm[c->cur], scan_tiles, tile_sums, c->P);
+    else
+      pairs_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
+                                                       c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done, c->info);
     emit_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
                                                     c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds, c->rec,
                                                     c->er_lo, c->er_hi, c->rec_cap, c->info);
   } else {
-    pairs_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
-                                                           c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
-                                                           c->info);
+    if (pm_scan)
+      pairs_scan_apply_kernel<kPairTile><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
+          k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
+          c->info, ntiles, c->posm[c->cur], scan_tiles, tile_sums, c->P);
+    else
+      pairs_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
+                                                             c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
+                                                             c->info);
     emit_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
                                                           c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds,
                                                           c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
