@@ -99,9 +99,6 @@ static void free_all(bh_ctx* c) {
   drop_graphs(c);
   if (c->scan_tmp2) (void)hipFree(c->scan_tmp2);
   if (c->host_flags) (void)hipHostFree(c->host_flags);
-  if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
-  if (c->ev_pscan) (void)hipEventDestroy(c->ev_pscan);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -211,9 +208,6 @@ int bh_create_on_stream(bh_ctx** out, int n, const bh_params* pin, int device, v
   ok = ok && hipMalloc(&c->scan_tmp2, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipMemset(c->scan_tmp, 0, c->scan_tmp_bytes) == hipSuccess;
   ok = ok && hipMemset(c->scan_tmp2, 0, c->scan_tmp_bytes) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->ev_pscan, hipEventDisableTiming) == hipSuccess;
   ok = ok && dalloc(&c->cV, N) == hipSuccess && dalloc(&c->cO, N) == hipSuccess &&
        dalloc(&c->cP, N) == hipSuccess;
   if (!ok) {
@@ -240,7 +234,6 @@ void bh_destroy(bh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   free_all(c);
 }
 
@@ -520,27 +513,14 @@ static int step_launch(bh_ctx* c) {
   BH_HIP(c, bhk_keys(c));                      // ref:260
   c->key_buf = 0;
   BH_MARK(2);
-  // (the body gather is left pending for the second stream — where there is one: below BH_FORK_MIN_N bodies the
-  // bucket sort gathers the bodies itself, one launch less on the only stream)
-  BH_HIP(c, bhk_sort(c, c->n >= BH_FORK_MIN_N));  // ref:262-264
+  BH_HIP(c, bhk_sort(c));                      // ref:262-264
   BH_MARK(3);
-  // the COM prefix scan needs only the sorted bodies, the build only the sorted keys: run the scan on the side
-  // stream while the main stream builds the tree (both are small, latency-bound grids).  Each event hand-over
-  // costs the streams ~7 us (seen as gaps in the kernel trace), so below BH_FORK_MIN_N bodies everything stays on
-  // the main stream and the scan's tiles ride in the build's own launches (bhk_build pm_scan).
-  const bool fork = c->n >= BH_FORK_MIN_N;
-  if (fork) {
-    BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
-    BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
-  }
-  BH_HIP(c, bhk_gather_bodies(c, fork ? c->stream2 : c->stream));  // splitter sort: the bodies follow the keys here
-  // (one stream: the scan's tiles ride in the build's launches, two launches less — bhk_build)
-  const bool ride = !fork;
-  if (!ride) BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, fork));
-  if (fork) BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
-  BH_HIP(c, bhk_build(c, ride));               // ref:266-275
+  // One stream: the COM prefix scan (which needs only the sorted bodies) rides in the launches of the tree build
+  // (which needs only the sorted keys) — bhk_build pm_scan.  Rounds 2-4 ran body gather + scan on a second stream
+  // beside the build; each hand-over between the streams cost ~7 us of gaps, and with the scan's tiles in the pairs
+  // / emit launches one stream measures faster at every size (tools/fork_sweep.sh).
+  BH_HIP(c, bhk_build(c, true));               // ref:266-275
   BH_MARK(4);
-  if (fork) BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
   // digests only unless something reads the canonical records after this step (strict / literal kernels)
   BH_HIP(c, bhk_com_records(c, c->p.strict_fp || c->p.literal_force || c->dd));  // ref:279-280
   BH_MARK(5);
@@ -569,8 +549,8 @@ static void drop_graphs(bh_ctx* c) {
     }
 }
 
-// The reference's step is one function with one synchronisation (ref:255-283); here it is 12 kernels on two
-// streams whose arguments never change from step to step except for the ping-pong parity of the body arrays
+// The reference's step is one function with one synchronisation (ref:255-283); here it is 8 kernels on one
+// stream whose arguments never change from step to step except for the ping-pong parity of the body arrays
 // (the sort gathers cur -> cur^1): one HIP graph per parity, captured the first time that parity is stepped
 // and replayed afterwards.  Not used while per-stage timing is on (event records between the stages), in
 // domain-decomposed mode (body count changes) (design-study builds, -DBH_STUDY, also honour BH_NO_GRAPH).  OPT-IN (bh_params.step_graph = 1):

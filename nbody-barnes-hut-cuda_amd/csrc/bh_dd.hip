@@ -1943,23 +1943,8 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
   bh_dd_state* d = c->dd;
   BH_HIP(c, bhk_keys(c));
   c->key_buf = 0;
-  // as in bh_step: the body gather (if the splitter sort left it pending) and the fp64 COM prefix scan need only
-  // the sorted order, the build only the sorted keys — second stream beside the build from BH_FORK_MIN_N bodies,
-  // below that the scan's tiles ride in the build's launches on the one stream
-  const bool fork = c->n >= BH_FORK_MIN_N;
-  BH_HIP(c, bhk_sort(c, fork));
-  if (fork) {
-    BH_HIP(c, hipEventRecord(c->ev_sorted, c->stream));
-    BH_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_sorted, 0));
-    BH_HIP(c, bhk_gather_bodies(c, c->stream2));
-    BH_HIP(c, bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, true));
-    BH_HIP(c, hipEventRecord(c->ev_pscan, c->stream2));
-    BH_HIP(c, bhk_build(c));
-    BH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pscan, 0));
-  } else {
-    BH_HIP(c, bhk_gather_bodies(c, c->stream));
-    BH_HIP(c, bhk_build(c, true));
-  }
+  BH_HIP(c, bhk_sort(c));
+  BH_HIP(c, bhk_build(c, true));  // (+ the fp64 COM prefix scan, riding in the build's launches: as bh_step)
   BH_HIP(c, bhk_com_records(c, false));  // digests only (the walk's records); the piece kernels read the proto records
   dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->info, c->rec_cap, c->n, d->piece_tmp,
                                                                    d->ddi);

@@ -127,7 +127,6 @@ struct bh_ctx {
   u64* sp_keys;     // [256] sorted splitters, padded with ~0
   u32* sp_count;    // [2][256] bucket sizes, double-buffered by call parity (the sort clears the other half)
   int sp_par;
-  bool gather_pending;  // bhk_sort_split left the body gather to bhk_gather_bodies
   bool keys_split;  // keys[0] and sp_count[sp_par] come from keys_split_kernel and no sort has consumed them
   bool order_hint;  // the bodies are stored in the key order of an earlier sort (set by every sort, cleared by
                     // uploads): what makes evenly spaced bodies good splitters
@@ -171,10 +170,7 @@ struct bh_ctx {
   void* scan_tmp;
   size_t scan_cnt_off;  // byte offset of the bh_last_block counters inside scan_tmp / scan_tmp2
   size_t scan_tmp_bytes;
-  // side stream: bh_step runs the COM prefix scan here, concurrently with the tree build
-  hipStream_t stream2;
-  hipEvent_t ev_sorted, ev_pscan;
-  void* scan_tmp2;
+  void* scan_tmp2;  // scratch of the COM prefix scan that rides in the build's launches (bhk_build pm_scan)
 
   // domain-decomposed stepping (bh_dd.hip); null until bh_dd_init
   struct bh_dd_state* dd;
@@ -220,14 +216,6 @@ struct bh_ctx {
 #endif
 #ifndef BH_INT_SMALL_N
 #define BH_INT_SMALL_N 163840  // bodies up to which integrate_kernel<true> uses 1024-body blocks
-#endif
-#ifndef BH_FORK_MIN_N
-#define BH_FORK_MIN_N 800000  // bodies from which bh_step runs body gather + COM prefix scan on the second stream; below,
-                              // the bucket sort gathers the bodies and the scan's tiles ride in the build's launches
-                              // (bhk_build pm_scan).  Round 4, ms/step one stream / two: 163,840 bodies 0.332 / 0.343,
-                              // 250,000 0.449 / 0.459, 500,000 0.744 / 0.751, 700,000 0.965 / 0.968, 1M 1.291 / 1.290,
-                              // 1.5M 1.929 / 1.919, 4M 5.39 / 5.37 (tools/fork_sweep.sh; before the scan rode along the
-                              // second stream paid from 163,840)
 #endif
 #define BH_BLKDONE_STRIDE(n) ((size_t)(n) / 8192 + 4)  // one counter per 32 tiles of >= 256 pairs
 #define BH_SCAN_TILE 2048  // 256 threads x 8 items
@@ -301,12 +289,11 @@ hipError_t bhk_bbox(bh_ctx* c);
 hipError_t bhk_bbox_raw(bh_ctx* c, float* out6);  // local min/max only
 hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int stride_floats);
 hipError_t bhk_keys(bh_ctx* c, bool for_sort = true);
-hipError_t bhk_sort(bh_ctx* c, bool defer_gather = false);  // sort + gather (deferred: see bhk_sort_split)
+hipError_t bhk_sort(bh_ctx* c);  // sort + gather
 hipError_t bhk_sort_onesweep(bh_ctx* c);              // radix implementation (bh_sort_onesweep.hip)
 bool bhk_sort_split_eligible(const bh_ctx* c);        // splitter sort: keys + bucket counts, then partition + local sort
 hipError_t bhk_keys_split(bh_ctx* c);
-hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather);
-hipError_t bhk_gather_bodies(bh_ctx* c, hipStream_t stream);  // no-op unless a gather is pending
+hipError_t bhk_sort_split(bh_ctx* c);
 hipError_t bhk_build(bh_ctx* c, bool pm_scan = false);  // pm_scan: + the COM prefix scan (small steps, bh_tree.hip)
 hipError_t bhk_com(bh_ctx* c);
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate = false, bool* fused = nullptr);
@@ -323,7 +310,7 @@ void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 // device-wide scans (bh_scan.hip)
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);
 hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out /* n+1 */, int n);  // of (in[i]+1)&~1
-hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n, bool side);
+hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n);
 hipError_t bhk_com_records(bh_ctx* c, bool canonical);  // second half of bhk_com: records from the prefix sums
 hipError_t bhk_canonical_records(bh_ctx* c);  // proto records -> canonical, after a digest-only COM stage
 size_t bhk_scan_tmp_bytes(int n);

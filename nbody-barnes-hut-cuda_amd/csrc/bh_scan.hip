@@ -64,9 +64,6 @@ hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out, int n) {
   return run_scan<OpI32>(c->stream, c->scan_tmp, c->scan_cnt_off, LoadI32Even{in}, out, n, nullptr);
 }
 
-// side = true: run on the context's side stream with its own scratch (bh_step overlaps this scan,
-// which needs only the sorted bodies, with the tree build, which needs only the sorted keys)
-hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out, int n, bool side) {
-  return run_scan<OpD4>(side ? c->stream2 : c->stream, side ? c->scan_tmp2 : c->scan_tmp, c->scan_cnt_off,
-                        LoadPM{posm}, out, n, nullptr);
+hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out, int n) {
+  return run_scan<OpD4>(c->stream, c->scan_tmp, c->scan_cnt_off, LoadPM{posm}, out, n, nullptr);
 }

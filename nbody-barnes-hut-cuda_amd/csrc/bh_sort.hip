@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const u32* __restrict__ per
 
 }  // namespace
 
-hipError_t bhk_sort(bh_ctx* c, bool defer_gather) {
+hipError_t bhk_sort(bh_ctx* c) {
   c->order_hint = true;  // the bodies leave every sort in key order
-  if (c->keys_split) return bhk_sort_split(c, defer_gather);  // the keys came with splitters and bucket counts
+  if (c->keys_split) return bhk_sort_split(c);  // the keys came with splitters and bucket counts
   if (c->p.sort_variant != 1) return bhk_sort_onesweep(c);
   const int n = c->n;
   const int ntiles = c->sort_tiles;

@@ -399,18 +399,6 @@ __global__ __launch_bounds__(kThreads) void onesweep_pass_kernel(
 #undef OS_DIGIT
 }
 
-__global__ __launch_bounds__(256) void gather_only_kernel(const u32* __restrict__ perm,
-                                                          const float4* __restrict__ posm_in,
-                                                          const float4* __restrict__ velid_in,
-                                                          float4* __restrict__ posm_out,
-                                                          float4* __restrict__ velid_out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u32 j = perm[i];
-  posm_out[i] = posm_in[j];
-  velid_out[i] = velid_in[j];
-}
-
 __global__ __launch_bounds__(256) void gather2_kernel(const u32* __restrict__ perm,
                                                       const float4* __restrict__ posm_in,
                                                       const float4* __restrict__ velid_in,
@@ -582,7 +570,7 @@ __device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __re
                                                u64* __restrict__ s_diff, const u64* kbuf, const u32* vbuf,
                                                u64* kout, u32* vout, const float4* __restrict__ posm_in,
                                                const float4* __restrict__ velid_in, float4* __restrict__ posm_out,
-                                               float4* __restrict__ velid_out, int gather, int start, int size,
+                                               float4* __restrict__ velid_out, int start, int size,
                                                int tid, int lane, int w, int b, u64 lt) {
     // ---- the bucket in registers, blocked by wave: wave w owns positions [w chunk, (w+1) chunk)
     const int chunk = ((size + kLsThreads - 1) / kLsThreads) * 64;
@@ -796,10 +784,8 @@ __device__ __forceinline__ void ls_sort_in_lds(u64* __restrict__ skey, u32* __re
           const u32 v = val[r];
           kout[start + idx] = key[r];
           vout[start + idx] = v;
-          if (gather) {  // else: bhk_gather_bodies, beside the tree build (bh_step)
-            posm_out[start + idx] = posm_in[v];
-            velid_out[start + idx] = velid_in[v];
-          }
+          posm_out[start + idx] = posm_in[v];
+          velid_out[start + idx] = velid_in[v];
         }
       }
     }
@@ -811,7 +797,7 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
     u64* kout, u32* vout,    // sorted keys / permutation
     const u32* __restrict__ bcount, u32* __restrict__ bcount_next,
     const float4* __restrict__ posm_in, const float4* __restrict__ velid_in, float4* __restrict__ posm_out,
-    float4* __restrict__ velid_out, u32* __restrict__ sw_ticket, int gather, bh_devinfo* __restrict__ info) {
+    float4* __restrict__ velid_out, u32* __restrict__ sw_ticket, bh_devinfo* __restrict__ info) {
   __shared__ u64 skey[kLsCap];
   __shared__ u32 sval[kLsCap];
   __shared__ u32 wcnt[kLsWaves][256];
@@ -848,13 +834,13 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
   if (size <= kLsCap) {  // block-uniform
     if (size <= 8 * kLsThreads)
       ls_sort_in_lds<8>(skey, sval, wcnt, toff, dsum, s_diff, kbuf, vbuf, kout, vout, posm_in, velid_in, posm_out,
-                        velid_out, gather, start, size, tid, lane, w, b, lt);
+                        velid_out, start, size, tid, lane, w, b, lt);
     else if (size <= 16 * kLsThreads)
       ls_sort_in_lds<16>(skey, sval, wcnt, toff, dsum, s_diff, kbuf, vbuf, kout, vout, posm_in, velid_in, posm_out,
-                         velid_out, gather, start, size, tid, lane, w, b, lt);
+                         velid_out, start, size, tid, lane, w, b, lt);
     else
       ls_sort_in_lds<kLsItems>(skey, sval, wcnt, toff, dsum, s_diff, kbuf, vbuf, kout, vout, posm_in, velid_in,
-                               posm_out, velid_out, gather, start, size, tid, lane, w, b, lt);
+                               posm_out, velid_out, start, size, tid, lane, w, b, lt);
     return;
   }
 
@@ -930,10 +916,8 @@ __global__ __launch_bounds__(kLsThreads) void local_sort_kernel(
     const u32 v = sv[i];
     kout[start + i] = sk[i];
     vout[start + i] = v;
-    if (gather) {
-      posm_out[start + i] = posm_in[v];
-      velid_out[start + i] = velid_in[v];
-    }
+    posm_out[start + i] = posm_in[v];
+    velid_out[start + i] = velid_in[v];
   }
 }
 
@@ -998,9 +982,7 @@ hipError_t bhk_keys_split(bh_ctx* c) {
   return hipGetLastError();
 }
 
-// defer_gather: leave the physical body gather to bhk_gather_bodies (c->gather_pending); the tree build needs
-// only the sorted keys, so bh_step runs the gather on its second stream in front of the COM prefix scan
-hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather) {
+hipError_t bhk_sort_split(bh_ctx* c) {
   const int n = c->n;
   const int par = c->sp_par & 1;
   u32* bc = c->sp_count + 256 * par;
@@ -1010,22 +992,11 @@ hipError_t bhk_sort_split(bh_ctx* c, bool defer_gather) {
       c->info, c->sp_keys, (float)split_buckets(n) / (float)n);
   local_sort_kernel<<<split_buckets(n), kLsThreads, 0, c->stream>>>(
       c->keys[1], c->vals[1], c->keys[0], c->vals[0], bc, c->sp_count + 256 * (par ^ 1), c->posm[c->cur],
-      c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket, defer_gather ? 0 : 1, c->info);
-  c->gather_pending = defer_gather;
+      c->velid[c->cur], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1], c->sw_ticket, c->info);
   c->key_buf = 0;
   c->cur ^= 1;
   c->sp_par ^= 1;
   c->keys_split = false;
-  return hipGetLastError();
-}
-
-// the deferred body gather of bhk_sort_split: posm/velid[cur] <- [cur ^ 1] through the sorted permutation
-hipError_t bhk_gather_bodies(bh_ctx* c, hipStream_t stream) {
-  if (!c->gather_pending) return hipSuccess;
-  const int n = c->n;
-  gather_only_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c->vals[0], c->posm[c->cur ^ 1], c->velid[c->cur ^ 1],
-                                                          c->posm[c->cur], c->velid[c->cur], n);
-  c->gather_pending = false;
   return hipGetLastError();
 }
 

@@ -343,24 +343,6 @@ __global__ __launch_bounds__(256) void lcp_kernel(const u64* __restrict__ k, int
                                                   bh_devinfo* __restrict__ info) {
   lcp_body((int)blockIdx.x, k, n, B, d, ss, samp, info);
 }
-// A step of fewer than BH_FORK_MIN_N bodies has no second stream for the COM prefix scan (the hand-over costs ~13 us
-// of gaps), and its kernels are latency-bound launches: the scan's tiles ride in the build's launches instead —
-// tile sums beside the lcp blocks here, the prefixes beside the pairs blocks (pairs_scan_apply_kernel): two
-// launches less on the only stream (65,536 bodies: 0.217 -> 0.205 ms/step, 16,384: 0.145 -> 0.138; with it one
-// stream is the faster arrangement up to ~1M bodies: BH_FORK_MIN_N).
-__global__ __launch_bounds__(256) void lcp_scan_reduce_kernel(const u64* __restrict__ k, int n, int B,
-                                                              signed char* __restrict__ d, int ss,
-                                                              u64* __restrict__ samp, bh_devinfo* __restrict__ info,
-                                                              int lcp_blocks, const float4* __restrict__ posm,
-                                                              int scan_tiles, bh_d4* tile_sums,
-                                                              u32* __restrict__ done) {
-  if ((int)blockIdx.x < lcp_blocks)
-    lcp_body((int)blockIdx.x, k, n, B, d, ss, samp, info);
-  else
-    bhscan::reduce_body<bhscan::OpD4, bhscan::LoadPM>((int)blockIdx.x - lcp_blocks, scan_tiles, bhscan::LoadPM{posm}, n,
-                                                      nullptr, tile_sums, done);
-}
-
 // Cell of pair j at level L = d[j]:   start a = nearest i < j with d[i] < L,
 //                                     end   b = nearest i > j with d[i] < L,
 //   j is its first child boundary iff the nearest i < j with d[i] <= L already has d[i] < L,
@@ -776,25 +758,29 @@ __global__ __launch_bounds__(256) void pairs_kernel(const u64* __restrict__ k,
   pairs_body<TILE>((int)blockIdx.x, (int)gridDim.x, k, d, n, B, D, cap, ksamp, ns, ss, pa, pb, pn, cb, ttot, tp_off,
                    done_count, info);
 }
-// (see lcp_scan_reduce_kernel) blocks [0, pair_blocks): the pairs; the rest: the COM prefix scan's second pass
+// The COM prefix scan of a step (fp64 sums of (m, m x, m y, m z) over the sorted bodies) needs nothing the build
+// produces and the build nothing of it: the scan's tiles ride in the build's launches — tile sums in extra blocks of
+// the pairs launch (blocks [0, pair_blocks): the pairs), the prefixes in extra blocks of the emit launch
+// (emit_scan_apply_kernel).  Same tiles and association order as bhk_scan_pm: bit-identical sums.  Rounds 2-4 ran body
+// gather + scan on a second stream instead (two event hand-overs, ~13 us of gaps per step); riding along, one stream
+// measures faster at every size (65,536 bodies 0.217 -> 0.202 ms/step, 500,000 0.751 -> 0.737, 1M 1.294 -> 1.286).
 template <int TILE>
-__global__ __launch_bounds__(256) void pairs_scan_apply_kernel(const u64* __restrict__ k,
-                                                               const signed char* __restrict__ d, int n, int B, int D,
-                                                               int cap, const u64* __restrict__ ksamp, int ns, int ss,
-                                                               int* __restrict__ pa, int* __restrict__ pb,
-                                                               int* __restrict__ pn, int* __restrict__ cb,
-                                                               int* __restrict__ ttot, int tp_off,
-                                                               u32* __restrict__ done_count,
-                                                               bh_devinfo* __restrict__ info, int pair_blocks,
-                                                               const float4* __restrict__ posm, int scan_tiles,
-                                                               const bh_d4* __restrict__ tile_sums,
-                                                               bh_d4* __restrict__ P) {
+__global__ __launch_bounds__(256) void pairs_scan_reduce_kernel(const u64* __restrict__ k,
+                                                                const signed char* __restrict__ d, int n, int B, int D,
+                                                                int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                                                int* __restrict__ pa, int* __restrict__ pb,
+                                                                int* __restrict__ pn, int* __restrict__ cb,
+                                                                int* __restrict__ ttot, int tp_off,
+                                                                u32* __restrict__ done_count,
+                                                                bh_devinfo* __restrict__ info, int pair_blocks,
+                                                                const float4* __restrict__ posm, int scan_tiles,
+                                                                bh_d4* tile_sums, u32* __restrict__ scan_done) {
   if ((int)blockIdx.x < pair_blocks)
     pairs_body<TILE>((int)blockIdx.x, pair_blocks, k, d, n, B, D, cap, ksamp, ns, ss, pa, pb, pn, cb, ttot, tp_off,
                      done_count, info);
   else
-    bhscan::apply_body<bhscan::OpD4, bhscan::LoadPM>((int)blockIdx.x - pair_blocks, bhscan::LoadPM{posm}, n, nullptr,
-                                                     tile_sums, scan_tiles, P);
+    bhscan::reduce_body<bhscan::OpD4, bhscan::LoadPM>((int)blockIdx.x - pair_blocks, scan_tiles, bhscan::LoadPM{posm},
+                                                      n, nullptr, tile_sums, scan_done);
 }
 
 // entry offset of the child block of the cell whose representative pair is j
@@ -893,24 +879,24 @@ __device__ __forceinline__ bool parent_slot(u64 (*m)[kPairWords], const signed c
 // ttot[tp_off ..] = tile bases (exclusive scan of the per-tile child-entry totals, written by the last block of
 // pairs_kernel); tpre[ntiles] = all entries
 template <int TILE>
-__global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
-                                                   const signed char* __restrict__ d, int n, int B, int D,
-                                                   int cap, const u64* __restrict__ ksamp, int ns, int ss,
-                                                   const int* __restrict__ pa,
-                                                   const int* __restrict__ pb, const int* __restrict__ pn,
-                                                   const int* __restrict__ cb,
-                                                   const int* __restrict__ ttot, int ntiles, int tp_off,
-                                                   const float* __restrict__ bounds,
-                                                   bh_node* __restrict__ rec, int* __restrict__ er_lo,
-                                                   int* __restrict__ er_hi, int rec_cap,
-                                                   bh_devinfo* __restrict__ info) {
+__device__ __forceinline__ void emit_body(const int bid, const u64* __restrict__ k,
+                                          const signed char* __restrict__ d, int n, int B, int D,
+                                          int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                          const int* __restrict__ pa,
+                                          const int* __restrict__ pb, const int* __restrict__ pn,
+                                          const int* __restrict__ cb,
+                                          const int* __restrict__ ttot, int ntiles, int tp_off,
+                                          const float* __restrict__ bounds,
+                                          bh_node* __restrict__ rec, int* __restrict__ er_lo,
+                                          int* __restrict__ er_hi, int rec_cap,
+                                          bh_devinfo* __restrict__ info) {
   __shared__ u64 s_samp[kSampMax];
   __shared__ u64 m[kPairLevels][kPairWords];
   __shared__ __attribute__((aligned(16))) signed char dl[kPairWin];
   const int* __restrict__ tpre = ttot + tp_off;
   constexpr int tshift = (TILE == 1024) ? 10 : 8;
   static_assert(TILE == 1024 || TILE == 256, "tile shift");
-  const int t0 = blockIdx.x * TILE;
+  const int t0 = bid * TILE;
   const int base = t0 - kHalo;
   TT_STAMP(1, 0)
   build_window<TILE>(d, n, base, m, dl);
@@ -1094,7 +1080,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
   __syncthreads();
   TT_STAMP(1, 2)
 #ifdef BH_TREE_TRACE
-  if (threadIdx.x == 0 && blockIdx.x < 8192) g_tree_trace[1][blockIdx.x][6] = (unsigned long long)nwide;
+  if (threadIdx.x == 0 && bid < 8192) g_tree_trace[1][bid][6] = (unsigned long long)nwide;
 #endif
   // phase 2: wide cells, 8 lanes per cell, lane v emits the child in octant v (if non-empty)
   {
@@ -1134,6 +1120,44 @@ __global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
     }
   }
   TT_STAMP(1, 3)
+}
+template <int TILE>
+__global__ __launch_bounds__(256) void emit_kernel(const u64* __restrict__ k,
+                                                   const signed char* __restrict__ d, int n, int B, int D,
+                                                   int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                                   const int* __restrict__ pa,
+                                                   const int* __restrict__ pb, const int* __restrict__ pn,
+                                                   const int* __restrict__ cb,
+                                                   const int* __restrict__ ttot, int ntiles, int tp_off,
+                                                   const float* __restrict__ bounds,
+                                                   bh_node* __restrict__ rec, int* __restrict__ er_lo,
+                                                   int* __restrict__ er_hi, int rec_cap,
+                                                   bh_devinfo* __restrict__ info) {
+  emit_body<TILE>((int)blockIdx.x, k, d, n, B, D, cap, ksamp, ns, ss, pa, pb, pn, cb, ttot, ntiles, tp_off, bounds, rec,
+                  er_lo, er_hi, rec_cap, info);
+}
+// (see lcp_kernel: the COM prefix scan of a one-stream step) blocks [0, ntiles): emit; the rest: the scan's second pass
+template <int TILE>
+__global__ __launch_bounds__(256) void emit_scan_apply_kernel(const u64* __restrict__ k,
+                                                              const signed char* __restrict__ d, int n, int B, int D,
+                                                              int cap, const u64* __restrict__ ksamp, int ns, int ss,
+                                                              const int* __restrict__ pa,
+                                                              const int* __restrict__ pb, const int* __restrict__ pn,
+                                                              const int* __restrict__ cb,
+                                                              const int* __restrict__ ttot, int ntiles, int tp_off,
+                                                              const float* __restrict__ bounds,
+                                                              bh_node* __restrict__ rec, int* __restrict__ er_lo,
+                                                              int* __restrict__ er_hi, int rec_cap,
+                                                              bh_devinfo* __restrict__ info,
+                                                              const float4* __restrict__ posm, int scan_tiles,
+                                                              const bh_d4* __restrict__ tile_sums,
+                                                              bh_d4* __restrict__ P) {
+  if ((int)blockIdx.x < ntiles)
+    emit_body<TILE>((int)blockIdx.x, k, d, n, B, D, cap, ksamp, ns, ss, pa, pb, pn, cb, ttot, ntiles, tp_off, bounds,
+                    rec, er_lo, er_hi, rec_cap, info);
+  else
+    bhscan::apply_body<bhscan::OpD4, bhscan::LoadPM>((int)blockIdx.x - ntiles, bhscan::LoadPM{posm}, n, nullptr,
+                                                     tile_sums, scan_tiles, P);
 }
 
 // ------------------------------------------------------------------ COM
@@ -1346,7 +1370,7 @@ extern "C" int bh_debug_tree_trace(void* out) {
 #endif
 
 // pm_scan: also the fp64 prefix sums of (m, m x, m y, m z) over the sorted bodies (what bhk_scan_pm writes into c->P
-// for the COM stage), their tiles riding in the lcp / pairs launches (small steps: lcp_scan_reduce_kernel)
+// for the COM stage), their tiles riding in the pairs / emit launches (one-stream steps: pairs_scan_reduce_kernel)
 hipError_t bhk_build(bh_ctx* c, bool pm_scan) {
   const int n = c->n;
 
@@ -1357,16 +1381,10 @@ hipError_t bhk_build(bh_ctx* c, bool pm_scan) {
   int ss = 12;
   while (((n + (1 << ss) - 1) >> ss) > kSampMax) ss++;
   const int ns = (n + (1 << ss) - 1) >> ss;
-  const int lcp_blocks = (n + 1 + 255) / 256;
   const int scan_tiles = (n + BH_SCAN_TILE - 1) / BH_SCAN_TILE;
-  bh_d4* const tile_sums = reinterpret_cast<bh_d4*>(c->scan_tmp2);  // (the side stream's scratch: idle in such a step)
+  bh_d4* const tile_sums = reinterpret_cast<bh_d4*>(c->scan_tmp2);
   u32* const scan_done = reinterpret_cast<u32*>(reinterpret_cast<char*>(c->scan_tmp2) + c->scan_cnt_off);
-  if (pm_scan)
-    lcp_scan_reduce_kernel<<<lcp_blocks + scan_tiles, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info,
-                                                                          lcp_blocks, c->posm[c->cur], scan_tiles,
-                                                                          tile_sums, scan_done);
-  else
-    lcp_kernel<<<lcp_blocks, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info);
+  lcp_kernel<<<(n + 1 + 255) / 256, 256, 0, c->stream>>>(k, n, c->B, c->d8, ss, c->ksamp, c->info);
   // 1024 pairs per block; 256 up to 163,840 bodies, where n / 1024 blocks leave most of the 256 CUs idle and a
   // block's four rounds are pure latency (65,536 bodies: pairs 22 -> 13 us, emit 28 -> 15 us); the halo stays 1024
   const int tile = (n <= BH_PAIR_SMALL_N) ? 256 : kPairTile;
@@ -1375,33 +1393,43 @@ hipError_t bhk_build(bh_ctx* c, bool pm_scan) {
   // child-block offsets = tile base (ttot[tp_off ..]) + offset in the tile (cb[]), both written by pairs_kernel
   if (tile == 256) {
     if (pm_scan)
-      pairs_scan_apply_kernel<256><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
+      pairs_scan_reduce_kernel<256><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
           k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
-          c->info, ntiles, c->posm[c->cur], scan_tiles, tile_sums, c->P);
+          c->info, ntiles, c->posm[c->cur], scan_tiles, tile_sums, scan_done);
     else
       pairs_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
                                                        c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done, c->info);
-    emit_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
-                                                    c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds, c->rec,
-                                                    c->er_lo, c->er_hi, c->rec_cap, c->info);
+    if (pm_scan)
+      emit_scan_apply_kernel<256><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
+          k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off,
+          c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info, c->posm[c->cur], scan_tiles, tile_sums, c->P);
+    else
+      emit_kernel<256><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb,
+                                                      c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds, c->rec,
+                                                      c->er_lo, c->er_hi, c->rec_cap, c->info);
   } else {
     if (pm_scan)
-      pairs_scan_apply_kernel<kPairTile><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
+      pairs_scan_reduce_kernel<kPairTile><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
           k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
-          c->info, ntiles, c->posm[c->cur], scan_tiles, tile_sums, c->P);
+          c->info, ntiles, c->posm[c->cur], scan_tiles, tile_sums, scan_done);
     else
       pairs_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
                                                              c->pb, c->pn, c->cb, c->ttot, tp_off, c->blk_done,
                                                              c->info);
-    emit_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
-                                                          c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds,
-                                                          c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
+    if (pm_scan)
+      emit_scan_apply_kernel<kPairTile><<<ntiles + scan_tiles, 256, 0, c->stream>>>(
+          k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa, c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off,
+          c->bounds, c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info, c->posm[c->cur], scan_tiles, tile_sums, c->P);
+    else
+      emit_kernel<kPairTile><<<ntiles, 256, 0, c->stream>>>(k, c->d8, n, c->B, c->D, c->cap, c->ksamp, ns, ss, c->pa,
+                                                            c->pb, c->pn, c->cb, c->ttot, ntiles, tp_off, c->bounds,
+                                                            c->rec, c->er_lo, c->er_hi, c->rec_cap, c->info);
   }
   return hipGetLastError();
 }
 
 hipError_t bhk_com(bh_ctx* c) {
-  hipError_t e = bhk_scan_pm(c, c->posm[c->cur], c->P, c->n, false);
+  hipError_t e = bhk_scan_pm(c, c->posm[c->cur], c->P, c->n);
   if (e != hipSuccess) return e;
   return bhk_com_records(c, true);
 }
