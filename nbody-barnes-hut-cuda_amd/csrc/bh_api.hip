@@ -518,7 +518,7 @@ static int step_launch(bh_ctx* c) {
   // One stream: the COM prefix scan (which needs only the sorted bodies) rides in the launches of the tree build
   // (which needs only the sorted keys) — bhk_build pm_scan.  Rounds 2-4 ran body gather + scan on a second stream
   // beside the build; each hand-over between the streams cost ~7 us of gaps, and with the scan's tiles in the pairs
-  // / emit launches one stream measures faster at every size (tools/fork_sweep.sh).
+  // / emit launches one stream measures faster at every size (profiles/r04_final/fork_sweep.txt).
   BH_HIP(c, bhk_build(c, true));               // ref:266-275
   BH_MARK(4);
   // digests only unless something reads the canonical records after this step (strict / literal kernels)
