@@ -354,7 +354,10 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(const float4* __restri
   __shared__ u64 sk[64];
   __shared__ int wsum[4];
   __shared__ int s_last;
+  __shared__ u32 htab[kHilbertTabWords];  // (bh_keys.h: the Hilbert keys from the state table)
+  static_assert(kB == 21, "body_key21_fsm");
   if ((int)threadIdx.x < nsplit) sk[threadIdx.x] = skeys[threadIdx.x];
+  hilbert_stage(htab);
   __syncthreads();
   const float b0 = bounds[0], b1 = bounds[1], b2 = bounds[2], size = bounds[6];
   int gone = 0;
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(const float4* __restri
     const int i = blockIdx.x * kClsTile + r * 256 + (int)threadIdx.x;
     if (i < n) {
       const float4 p = posm[i];
-      const u64 key = body_key<kB>(curve, p.x, p.y, p.z, b0, b1, b2, size);
+      const u64 key = body_key21_fsm(htab, curve, p.x, p.y, p.z, b0, b1, b2, size);
       const int mine = owner_of(key, sk, nsplit) == me ? 1 : 0;
       kept[i] = (unsigned char)mine;
       gone += 1 - mine;
@@ -485,10 +488,12 @@ __global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __res
   __shared__ int cnt[64];
   __shared__ int wsum[4];
   __shared__ int s_last;
+  __shared__ u32 htab[kHilbertTabWords];
   const int nsplit = world - 1;
   const int tid = threadIdx.x;
   if (tid < nsplit) sk[tid] = skeys[tid];
   if (tid < 64) cnt[tid] = 0;
+  hilbert_stage(htab);
   __syncthreads();
   const int q = blockIdx.x / cpr, k0 = (blockIdx.x - q * cpr) * 1024;
   const int ne = min(reinterpret_cast<const int*>(g + (size_t)q * f4)[2], limit);
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __res
       int mine = 0;
       if (k < ne) {
         const float4 p = g[(size_t)q * f4 + 2 + 2 * (size_t)k];
-        const u64 key = body_key<kB>(curve, p.x, p.y, p.z, b0, b1, b2, size);
+        const u64 key = body_key21_fsm(htab, curve, p.x, p.y, p.z, b0, b1, b2, size);
         const int o = owner_of(key, sk, nsplit);
         atomicAdd(&cnt[o], 1);
         mine = (o == me && q != me) ? 1 : 0;

@@ -120,6 +120,58 @@ __device__ __forceinline__ u64 body_key(int curve, float px, float py, float pz,
   return (expand_bits21(x) << 2) | (expand_bits21(y) << 1) | expand_bits21(z);
 }
 
+// ---- the same Hilbert keys from a state table (round 4) ----
+// The bit algorithm above costs ~500 vector instructions per key (20 levels of masks and exchanges, three 21-bit
+// interleaves) and the kernels that key every body of a step are VALU-bound on it (keys_split_kernel 23 us at 1M
+// bodies, dd_classify_kernel 26).  The curve is a finite-state machine: 24 orientations; kHilbertTab (generated from
+// the bit algorithm by tools/hilbert_fsm.py, which also checks it on 2M coordinates at full depth) maps (state, two
+// bits of x, y, z) to six key bits and the next state.  Ten lookups + one for the last level, ~10 instructions each;
+// the table (3 KB) is staged in LDS by the block (hilbert_stage).  Bit-identical to hilbert_axes_to_transpose + the
+// interleave: the golden-fixture and oracle tests compare keys bit for bit.
+#include "bh_hilbert_tab.h"
+constexpr int kHilbertTabWords = kHilbertStates * 64 / 2;  // 32-bit words
+// stage the table: every thread of the block calls this, then __syncthreads()
+__device__ __forceinline__ void hilbert_stage(u32* lds_tab /* [kHilbertTabWords] */) {
+  const u32* g = reinterpret_cast<const u32*>(kHilbertTab);
+  for (int i = threadIdx.x; i < kHilbertTabWords; i += blockDim.x) lds_tab[i] = g[i];
+}
+template <int SH>
+__device__ __forceinline__ u32 hilbert_step(const unsigned char* tab, u32& st, u32 x, u32 y, u32 z) {
+  // byte offset of the entry: state (already << 7) + (xx << 5 | yy << 3 | zz << 1)
+  const u32 off = st + (((x >> SH) & 3u) << 5 | ((y >> SH) & 3u) << 3 | ((z >> SH) & 3u) << 1);
+  const u32 e = *reinterpret_cast<const unsigned short*>(tab + off);
+  st = e & 0xff80u;
+  return e & 63u;
+}
+__device__ __forceinline__ u64 hilbert_key_fsm(const u32* lds_tab, u32 x, u32 y, u32 z) {
+  const unsigned char* tab = reinterpret_cast<const unsigned char*>(lds_tab);
+  u32 st = 0u;
+  u32 hi = hilbert_step<19>(tab, st, x, y, z);
+  hi = hi << 6 | hilbert_step<17>(tab, st, x, y, z);
+  hi = hi << 6 | hilbert_step<15>(tab, st, x, y, z);
+  hi = hi << 6 | hilbert_step<13>(tab, st, x, y, z);
+  hi = hi << 6 | hilbert_step<11>(tab, st, x, y, z);
+  u32 lo = hilbert_step<9>(tab, st, x, y, z);
+  lo = lo << 6 | hilbert_step<7>(tab, st, x, y, z);
+  lo = lo << 6 | hilbert_step<5>(tab, st, x, y, z);
+  lo = lo << 6 | hilbert_step<3>(tab, st, x, y, z);
+  lo = lo << 6 | hilbert_step<1>(tab, st, x, y, z);
+  // the last level alone: its bit as the high bit of a pair, the upper three of the six key bits
+  const u32 off = st + ((x & 1u) << 6 | (y & 1u) << 4 | (z & 1u) << 2);
+  const u32 d = (*reinterpret_cast<const unsigned short*>(tab + off) >> 3) & 7u;
+  return (u64)hi << 33 | (u64)lo << 3 | (u64)d;
+}
+// body_key with the table (21 bits per axis): the same quantisation, Morton unchanged
+__device__ __forceinline__ u64 body_key21_fsm(const u32* lds_tab, int curve, float px, float py, float pz, float minX,
+                                              float minY, float minZ, float size) {
+  if (curve == 0) return morton_key<21>(px, py, pz, minX, minY, minZ, size);
+  constexpr u32 qmax = (1u << 21) - 1u;
+  const u32 x = min((u32)((px - minX) / size * 2097152.0f), qmax);
+  const u32 y = min((u32)((py - minY) / size * 2097152.0f), qmax);
+  const u32 z = min((u32)((pz - minZ) / size * 2097152.0f), qmax);
+  return hilbert_key_fsm(lds_tab, x, y, z);
+}
+
 // leading octal digits shared by two keys of B digits
 __device__ __forceinline__ int common_digits(u64 a, u64 b, int B) {
   const u64 x = a ^ b;

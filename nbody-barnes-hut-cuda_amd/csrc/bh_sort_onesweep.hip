@@ -463,16 +463,35 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
   const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
   const int tid = threadIdx.x, lane = tid & 63;
   KS_STAMP(0)
-  // the tile's own keys first (their loads overlap the splitter work)
+  // the tile's own bodies and the splitter candidates are loaded first; the Hilbert state table (bh_keys.h) is
+  // staged in LDS meanwhile
+  __shared__ u32 htab[B == 21 ? kHilbertTabWords : 1];
   const int base = blockIdx.x * TILE;
+  float4 own[TILE / kKsThreads];
+#pragma unroll
+  for (int r = 0; r < TILE / kKsThreads; r++) {
+    const int i = base + r * kKsThreads + tid;
+    own[r] = posm[min(i, n - 1)];
+  }
+  float4 cand = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 768 && (tid & 255) < nb - 1) {
+    const int pos = (int)(((u64)((tid & 255) + 1) * (u64)n) / (u64)nb) + (tid >> 8) - 1;  // n / nb >= 2: inside [0, n)
+    cand = posm[min(max(pos, 0), n - 1)];
+  }
+  if (B == 21) {
+    hilbert_stage(htab);
+    __syncthreads();
+  }
   u64 k[TILE / kKsThreads];
 #pragma unroll
   for (int r = 0; r < TILE / kKsThreads; r++) {
     const int i = base + r * kKsThreads + tid;
     k[r] = 0ull;
     if (i < n) {
-      const float4 q = posm[i];
-      k[r] = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
+      if constexpr (B == 21)
+        k[r] = body_key21_fsm(htab, curve, own[r].x, own[r].y, own[r].z, minX, minY, minZ, size);
+      else
+        k[r] = body_key<B>(curve, own[r].x, own[r].y, own[r].z, minX, minY, minZ, size);
       keys[i] = k[r];
     }
   }
@@ -487,9 +506,10 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
     const int t = tid & 255, j = tid >> 8;
     u64 sk3 = ~0ull;
     if (t < nb - 1) {
-      const int pos = (int)(((u64)(t + 1) * (u64)n) / (u64)nb) + j - 1;  // n / nb >= 2: inside [0, n)
-      const float4 q = posm[min(max(pos, 0), n - 1)];
-      sk3 = body_key<B>(curve, q.x, q.y, q.z, minX, minY, minZ, size);
+      if constexpr (B == 21)
+        sk3 = body_key21_fsm(htab, curve, cand.x, cand.y, cand.z, minX, minY, minZ, size);
+      else
+        sk3 = body_key<B>(curve, cand.x, cand.y, cand.z, minX, minY, minZ, size);
     }
     raw3[j][t] = sk3;
   }
