@@ -614,31 +614,6 @@ __global__ __launch_bounds__(256) void dd_absorb_copy_kernel(const float4* __res
 // in the bit patterns of its x / y, where the build left it — put_rec, bh_tree.hip)
 __device__ __forceinline__ int rec_lo(const bh_node& r) { return __float_as_int(r.x); }
 __device__ __forceinline__ int rec_hi(const bh_node& r) { return __float_as_int(r.y); }
-__device__ __forceinline__ bool is_spine(const bh_node* __restrict__ rec, int e, int n) {
-  const bh_node r = rec[e];
-  return r.kind == BH_KIND_INTERNAL && (rec_lo(r) == 0 || rec_hi(r) == n);
-}
-
-__global__ __launch_bounds__(256) void dd_spine_kernel(const bh_node* __restrict__ rec,
-                                                       const bh_devinfo* __restrict__ info, int rec_cap, int n,
-                                                       int* __restrict__ piece_tmp, int* __restrict__ ddi) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int E = min(info->n_entries, rec_cap);
-  if (e >= E) return;
-  if (e == 0 && rec[0].kind != BH_KIND_INTERNAL) {  // the whole rank is one body / one unsplit cell
-    piece_tmp[atomicAdd(&ddi[0], 1)] = 0;
-    return;
-  }
-  if (!is_spine(rec, e, n)) return;
-  const bh_node r = rec[e];
-  for (int k = 0; k < r.count; k++) {
-    const int c = r.first + k;
-    if (!is_spine(rec, c, n)) {
-      const int idx = atomicAdd(&ddi[0], 1);  // order fixed below by the body range
-      if (idx < BH_DD_PIECE_CAP) piece_tmp[idx] = c;
-    }
-  }
-}
 
 __global__ __launch_bounds__(BH_DD_PIECE_CAP) void dd_describe_kernel(
     const int* __restrict__ piece_tmp, const int* ddi, int* ddi_w, const bh_node* __restrict__ rec,
@@ -1950,9 +1925,9 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
   c->key_buf = 0;
   BH_HIP(c, bhk_sort(c));
   BH_HIP(c, bhk_build(c, true));  // (+ the fp64 COM prefix scan, riding in the build's launches: as bh_step)
-  BH_HIP(c, bhk_com_records(c, false));  // digests only (the walk's records); the piece kernels read the proto records
-  dd_spine_kernel<<<(c->rec_cap + 255) / 256, 256, 0, c->stream>>>(c->rec, c->info, c->rec_cap, c->n, d->piece_tmp,
-                                                                   d->ddi);
+  // digests only (the walk's records) + the list of this rank's pieces (com_kernel); the piece kernels read the proto
+  // records
+  BH_HIP(c, bhk_com_records(c, false, d->piece_tmp, d->ddi));
   dd_describe_kernel<<<1, BH_DD_PIECE_CAP, 0, c->stream>>>(d->piece_tmp, d->ddi, d->ddi, c->rec,
                                                            c->keys[c->key_buf], c->P, c->posm[c->cur], c->bounds,
                                                            c->p.key_curve, d->rank, c->n, (bh_dd_piece*)send_x3,

@@ -311,7 +311,9 @@ void bh_dd_free(bh_ctx* c);  // bh_dd.hip
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);
 hipError_t bhk_scan_i32_even(bh_ctx* c, const int* in, int* out /* n+1 */, int n);  // of (in[i]+1)&~1
 hipError_t bhk_scan_pm(bh_ctx* c, const float4* posm, bh_d4* out /* n+1 */, int n);
-hipError_t bhk_com_records(bh_ctx* c, bool canonical);  // second half of bhk_com: records from the prefix sums
+hipError_t bhk_com_records(bh_ctx* c, bool canonical, int* spine_pieces = nullptr, int* spine_count = nullptr);
+                           // canonical = false: digests only; spine_pieces (digest-only pass of the decomposed step):
+                           // also lists the rank's pieces (com_kernel)
 hipError_t bhk_canonical_records(bh_ctx* c);  // proto records -> canonical, after a digest-only COM stage
 size_t bhk_scan_tmp_bytes(int n);
 size_t bhk_scan_cnt_offset(int n);

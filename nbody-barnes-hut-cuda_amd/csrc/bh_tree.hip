@@ -1171,7 +1171,9 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
                                                   int* __restrict__ er_hi,
                                                   const bh_devinfo* __restrict__ info, int rec_cap,
                                                   const float4* __restrict__ posm,
-                                                  const bh_d4* __restrict__ P, int proto) {
+                                                  const bh_d4* __restrict__ P, int proto,
+                                                  int* __restrict__ spine_pieces, int* __restrict__ spine_count,
+                                                  int n_bodies) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int E = min(info->n_entries, rec_cap);  // even: root + padding + blocks of even length
   if ((e & ~63) >= E) return;                   // whole wave beyond the tree
@@ -1187,6 +1189,25 @@ __global__ __launch_bounds__(256) void com_kernel(bh_node* __restrict__ rec, bh_
       er_lo[e] = lo;
       er_hi[e] = hi;
       if (r.kind == BH_KIND_PAD) *reinterpret_cast<float4*>(&rec[e]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!CANON && spine_pieces) {
+      // Domain-decomposed step (bh_dd.hip): the PIECES of this rank's tree are the children of its two spines (the
+      // cells that contain the rank's first or last body: their extent is shared with the neighbouring ranks) that
+      // are not on a spine themselves.  The few dozen spine cells list them here — this pass has the body ranges in
+      // hand (proto records are not modified by a digest-only pass) — instead of a pass of its own over all records.
+      if (e == 0 && r.kind != BH_KIND_INTERNAL) {  // the whole rank is one body / one unsplit cell
+        spine_pieces[atomicAdd(spine_count, 1)] = 0;
+      } else if (r.kind == BH_KIND_INTERNAL && (lo == 0 || hi == n_bodies)) {
+        for (int k = 0; k < r.count; k++) {
+          const int c = r.first + k;
+          const bh_node rc = rec[c];
+          const int clo = proto ? __float_as_int(rc.x) : er_lo[c], chi = proto ? __float_as_int(rc.y) : er_hi[c];
+          if (!(rc.kind == BH_KIND_INTERNAL && (clo == 0 || chi == n_bodies))) {
+            const int idx = atomicAdd(spine_count, 1);  // (the order is fixed later, by body range: dd_describe_kernel)
+            if (idx < BH_DD_PIECE_CAP) spine_pieces[idx] = c;
+          }
+        }
+      }
     }
     if (r.kind != BH_KIND_PAD) {
       float4 o;
@@ -1436,16 +1457,17 @@ hipError_t bhk_com(bh_ctx* c) {
 
 // canonical = false: digests only (bh_step of the default engine); the canonical records then stay in the
 // build's form (body range in x / y) until a stage call (bh_com) or a canonical step rewrites them
-hipError_t bhk_com_records(bh_ctx* c, bool canonical) {
+hipError_t bhk_com_records(bh_ctx* c, bool canonical, int* spine_pieces, int* spine_count) {
   const int blocks = (c->rec_cap + 255) / 256;
   // (a digest-only pass on records that are already canonical cannot happen: every caller builds first)
   const int proto = c->rec_proto ? 1 : 0;
   if (canonical)
     com_kernel<true><<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info,
-                                                    c->rec_cap, c->posm[c->cur], c->P, proto);
+                                                    c->rec_cap, c->posm[c->cur], c->P, proto, nullptr, nullptr, 0);
   else
     com_kernel<false><<<blocks, 256, 0, c->stream>>>(c->rec, c->frec, c->p.G, c->p.theta, c->er_lo, c->er_hi, c->info,
-                                                     c->rec_cap, c->posm[c->cur], c->P, proto);
+                                                     c->rec_cap, c->posm[c->cur], c->P, proto, spine_pieces,
+                                                     spine_count, c->n);
   if (canonical) c->rec_proto = false;
   c->com_digests = true;
   return hipGetLastError();
