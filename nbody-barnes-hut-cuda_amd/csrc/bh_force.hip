@@ -1215,6 +1215,10 @@ constexpr int kMixedK = 4;
 constexpr int kMixedRun = 16;  // chunks (workgroups of four groups) per XCD run: 64 groups, as in the one-wave launch —
                                // a run of 64 such chunks is 143 us of one XCD's time at 1M bodies, and the XCD that
                                // holds one run more than the others ends the launch that much later
+#ifndef BH_TAIL_RUN
+#define BH_TAIL_RUN 16
+#endif
+constexpr int kTailRun = BH_TAIL_RUN;  // groups of the cooperative tail per XCD run
 template <bool FUSE, int SUBSH, bool BUDGET = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                           float4* __restrict__ acc, int hi, float eps2, int xcd_mode,
@@ -1224,7 +1228,9 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
   const int lane = threadIdx.x & 63;
   const int wib = rfl((int)(threadIdx.x >> 6));
   if ((int)blockIdx.x >= nbulk) {
-    const int t = (int)blockIdx.x - nbulk;
+    // (XCD placement of the tail as of the bulk: runs of kTailRun consecutive groups per XCD; nbulk is a multiple of
+    // eight in mode 2, so a workgroup's XCD is also that of its index in the tail)
+    const int t = block_chunk_of<kTailRun>(xcd_mode == 2 ? 2 : 1, (int)blockIdx.x - nbulk, 0);
     coop_group<FUSE, SUBSH, TRACE>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
                                    gb + t * kMixedK, root);
     return;
@@ -1458,6 +1464,11 @@ static int resolve_xcd_mode(const bh_ctx* c, int bodies, int group) {
   return waves > (long long)c->num_cus * 32 ? 2 : 0;
 }
 
+// workgroups of the cooperative tail of a mixed launch: whole XCD runs in mode 2 (the surplus groups hold no body)
+static int mixed_tail_grid(int mmode, int tail) {
+  return mmode == 2 ? (tail + 8 * kTailRun - 1) / (8 * kTailRun) * (8 * kTailRun) : tail;
+}
+
 // fuse_integrate (bh_step): the launch may also integrate the bodies and fold the next step's cube into
 // c->bounds_next (force_fast_kernel FUSE); *fused tells whether it did (only the hand-scheduled walk over all bodies)
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate, bool* fused) {
@@ -1517,7 +1528,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate,
         int nbulk = gb / 4;
         if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
 #define BH_MIXED(F, S)                                                                                        \
-  force_mixed_kernel<F, S><<<nbulk + tail, 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2, mmode, \
+  force_mixed_kernel<F, S><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, c->stream>>>((const float*)c->frec, posm, c->acc, hi, e2, mmode, \
                                                                 c->info, nbulk, gb, F ? fz : bh_fuse_args{})
 #ifdef BH_STUDY
         if (fuse) {
@@ -1605,7 +1616,7 @@ hipError_t bhk_force_trace(bh_ctx* c, u32* trace, int cap_rows, int* rows) {
     const int mmode = resolve_xcd_mode(c, bulk, 64);
     int nbulk = gb / 4;
     if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
-    force_mixed_kernel<false, 11, false, true><<<nbulk + tail, 256, 0, c->stream>>>(
+    force_mixed_kernel<false, 11, false, true><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, c->stream>>>(
         (const float*)c->frec, posm, c->acc, n, c->p.eps2, mmode, c->info, nbulk, gb, fz);
     *rows = gb + kMixedK * tail;
   } else if (bulk == 0) {
@@ -1689,12 +1700,12 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
                       c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->dd_minmax, (int)G};
       fz.acc_add = fuse_add;
       fz.raw = 1;
-      force_mixed_kernel<true, 11, true><<<nbulk + tail, 256, 0, stream>>>(
+      force_mixed_kernel<true, 11, true><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, stream>>>(
           (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, fz, root);
       *fused = true;
       return hipGetLastError();
     }
-    force_mixed_kernel<false, 11, true><<<nbulk + tail, 256, 0, stream>>>(
+    force_mixed_kernel<false, 11, true><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, stream>>>(
         (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, bh_fuse_args{}, root);
     return hipGetLastError();
   }
