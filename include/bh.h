@@ -269,7 +269,9 @@ int bh_n(const bh_ctx* c);
  * piece descriptors, so the stitched tree is the same octree a single GPU builds and forces agree
  * with the 1-rank run up to summation order (cell sums: fp64, differently associated).
  * A LET segment holds the child blocks of every local cell that some body of another rank could
- * open (conservative box test against the remote pieces).  Requires key_bits 63 and leaf_cap 1. */
+ * open (conservative box test against the remote pieces).  Requires key_bits 63, leaf_cap 1 and max_depth 21
+ * (the default: unsplit cells then hold coincident bodies only and are far too small for a remote body to open;
+ * bh_dd_init returns BH_ERR_BAD_ARG otherwise). */
 #define BH_DD_PIECE_CAP 512          /* pieces per rank: <= 2 spines x 21 levels x 7 = 294      */
 #define BH_FLAG_DD_BODIES 16         /* local body count exceeded the context's capacity         */
 #define BH_FLAG_DD_PIECES 32         /* more than BH_DD_PIECE_CAP pieces                          */

@@ -1684,7 +1684,11 @@ int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) 
 int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int let_cap, void* pool,
                int64_t pool_records) {
   if (!c || !pool || rank < 0 || rank >= world || c->dd) return BH_ERR_BAD_ARG;
-  if (c->p.key_bits != 63 || c->p.leaf_cap != 1 || c->p.strict_fp || c->p.literal_force) return BH_ERR_BAD_ARG;
+  // (a depth cap leaves unsplit cells of many bodies that remote bodies can open: their child blocks have more than
+  // the 8 records dd_validate_kernel accepts from another rank — the bound that keeps a walk over a malformed segment
+  // short)
+  if (c->p.key_bits != 63 || c->p.leaf_cap != 1 || c->D != 21 || c->p.strict_fp || c->p.literal_force)
+    return BH_ERR_BAD_ARG;
   bh_dd_sizes sz;
   // the context was created with n = body capacity
   const int n_cap = c->n;

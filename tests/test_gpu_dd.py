@@ -61,10 +61,10 @@ def merge(out, n):
     return pos, vel, acc
 
 
-def single(ic, steps):
+def single(ic, steps, **kw):
     pkg = bhpkg.load()
     n = len(ic[0])
-    with pkg.Engine(n) as e:
+    with pkg.Engine(n, **kw) as e:
         e.upload(*ic)
         e.step(steps)
         x, y, z, vx, vy, vz = e.download()
@@ -187,10 +187,10 @@ def test_dd_boundaries_persist_and_rebalance():
     assert np.median(e) < 1e-3, np.median(e)
 
 
-def _check(ic, world, steps, tol_pos=5e-2, tol_med=1e-4):
+def _check(ic, world, steps, tol_pos=5e-2, tol_med=1e-4, **kw):
     n = len(ic[0])
-    p1, v1, a1 = single(ic, steps)
-    out = run_ranks(world, ic, steps)
+    p1, v1, a1 = single(ic, steps, **kw)
+    out = run_ranks(world, ic, steps, **kw)
     p, v, a = merge(out, n)
     assert np.abs(p - p1).max() < tol_pos, np.abs(p - p1).max()
     e = rel(a, a1)
@@ -318,7 +318,7 @@ def test_dd_abi_argument_and_order_checks():
     assert sz.seg_base > sz.top_base > 2 * 50000 and sz.pool_records > sz.seg_base + 4 * 60000
     pool = torch.zeros(sz.pool_records * 32, dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
-    for bad in (dict(leaf_cap=4), dict(key_bits=30, max_depth=10), dict(strict_fp=1)):
+    for bad in (dict(leaf_cap=4), dict(key_bits=30, max_depth=10), dict(strict_fp=1), dict(max_depth=6)):
         with pkg.Engine(50000, **bad) as e:                                 # needs 63-bit keys, leaf_cap 1, fast kernel
             with pytest.raises(BhError):
                 e.dd_init(4, 0, 200000, 4096, 60000, pool.data_ptr(), sz.pool_records)
