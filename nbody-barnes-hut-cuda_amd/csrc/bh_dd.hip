@@ -742,7 +742,10 @@ __global__ __launch_bounds__(256) void dd_boxes_kernel(const bh_dd_piece* __rest
 // records: every thread tests its records against the ranks' bounding boxes; the cells that are near some rank are
 // compacted in LDS and tested against those ranks' piece boxes by eight lanes each.
 constexpr int kMarkChunk = 512;
-constexpr int kMarkBoxes = 512;  // remote boxes staged in LDS (more are read from memory)
+#ifndef BH_MARK_BOXES
+#define BH_MARK_BOXES 512  // (a test build with 64 drives the memory path: tools/mkvariant.sh markboxes64 -DBH_MARK_BOXES=64)
+#endif
+constexpr int kMarkBoxes = BH_MARK_BOXES;  // remote boxes staged in LDS (more are read from memory)
 constexpr int kMarkPer = kMarkChunk / 256;
 // no point of the box [lo, hi] can open the candidate q = (com, threshold): |com - box|^2 + eps2 > thr2, with slack
 __device__ __forceinline__ bool box_too_far(const float4 lo, const float4 hi, const float4 q, float eps2) {
