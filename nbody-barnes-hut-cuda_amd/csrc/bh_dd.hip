@@ -224,10 +224,12 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
   __shared__ int nvalid;
   __shared__ float cube[8];
   __shared__ int s_mode;  // 0: keep, 1: the ranks' proposals, 2: sample quantiles
+  __shared__ int s_need2;
   __shared__ float4 prop[64];
   const int tid = threadIdx.x;
   if (tid == 0) {
     nvalid = 0;
+    s_need2 = 0;
     float mn[3] = {1e10f, 1e10f, 1e10f}, mx[3] = {-1e10f, -1e10f, -1e10f};  // sentinels ref:138
     for (int r = 0; r < world; r++) {
       const float* o = g + (size_t)r * xf;
@@ -240,61 +242,31 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
     cube[6] = fmaxf(cube[3] - cube[0], 1.0f);                                 // root edge s0, ref:55
     cube[7] = 0.0f;
     for (int q = 0; q < 8; q++) bounds[q] = cube[q];
-    // what to do with the boundaries
+    // what to do with the boundaries: keep them, unless some rank's count has left n / P by more than tol
     int mode = 0;
     if (world > 1) {
       if (!ddi[10]) {
         mode = 2;
       } else {
         const double fair = (double)n_total / (double)world;
-        bool out = false;
         for (int r = 0; r < world; r++) {
           const double nr = (double)__float_as_int(g[(size_t)r * xf + 6]);
-          if (fabs(nr - fair) > (double)tol * fair) out = true;
-        }
-        if (out) {
-          mode = 1;
-          long long before = 0;
-          for (int q = 0; q + 1 < world; q++) {
-            before += __float_as_int(g[(size_t)q * xf + 6]);
-            const long long want = (long long)(q + 1) * n_total / world;
-            const float4 up = reinterpret_cast<const float4*>(g + (size_t)(q + 1) * xf + 8)[0];  // rank q+1, lower end
-            const float4 dn = reinterpret_cast<const float4*>(g + (size_t)q * xf + 8)[1];        // rank q, upper end
-            // A proposal is a body picked by its place in the PREVIOUS step's key order; its key under the new cube
-            // must still lie in the range of the rank that proposed it (between this boundary's old key and that
-            // rank's other boundary).  A body that one of the cube's coarse planes has just passed has jumped by
-            // octants along the curve: taking it would hand a whole stretch of the curve to the wrong rank (a
-            // 300-step soak of 8 x 500k met one in its 16th rebalance and overflowed a rank).  Such a boundary stays
-            // where it is for this step; the next step proposes another body.
-            float4 take = make_float4(0.f, 0.f, 0.f, 0.f);  // (w = 0: this boundary stays)
-            if (want > before && up.w > 0.5f) {
-              const u64 kc = body_key<kB>(curve, up.x, up.y, up.z, cube[0], cube[1], cube[2], cube[6]);
-              if (kc >= skeys[q] && (q + 2 >= world || kc < skeys[q + 1])) take = up;
-            } else if (want < before && dn.w > 0.5f) {
-              const u64 kc = body_key<kB>(curve, dn.x, dn.y, dn.z, cube[0], cube[1], cube[2], cube[6]);
-              if (kc < skeys[q] && (q == 0 || kc >= skeys[q - 1])) take = dn;
-            } else if (want != before) {
-              mode = 2;
-            }
-            prop[q] = take;
-          }
+          if (fabs(nr - fair) > (double)tol * fair) mode = 1;
         }
       }
-      if (mode) ddi[9] += 1;
-      ddi[10] = 1;
     }
-    ddi[11] = mode;
     s_mode = mode;
   }
   __syncthreads();
-  const int mode = s_mode;
-  if (mode != 2) {  // 0: the keys stay; 1: the proposed positions, keyed under this step's cube
-    if (mode == 1 && tid < world - 1 && prop[tid].w > 0.5f) {
-      const float4 p = prop[tid];
-      skeys[tid] = body_key<kB>(curve, p.x, p.y, p.z, cube[0], cube[1], cube[2], cube[6]);
+  if (s_mode == 0) {
+    if (tid == 0) {
+      if (world > 1) ddi[10] = 1;
+      ddi[11] = 0;
     }
     return;
   }
+  // the keys of every rank's position samples under this step's cube: the sample quantiles (mode 2), and the yardstick
+  // a proposed boundary is held against (mode 1)
   int mine = 0;
   for (int i = tid; i < kSampTotal; i += 1024) {
     u64 key = ~0ull;
@@ -310,6 +282,68 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
   }
   if (mine) atomicAdd(&nvalid, mine);
   __syncthreads();
+  if (s_mode == 1 && tid < world - 1) {
+    // Boundary q goes to the exact quantile: the rank into whose range it must move by d bodies proposed its d-th
+    // body from that end (dd_x1_pack_kernel) — a body picked by its place in the PREVIOUS step's key order.  Under
+    // the new cube its key must (a) still lie in the range of the rank that proposed it, and (b) stand among that
+    // rank's position samples where its index says: about index / stride of them below it.  A body that one of the
+    // cube's coarse planes has just passed jumps by octants along the curve; taking it hands a stretch of the curve
+    // to the wrong rank.  (a) alone let a jump INSIDE the proposer's range through: a 1,000-step soak of 8 x 500k
+    // overflowed a rank in its 35th rebalance, step 608.  With (b) a boundary can land at most a few sample strides
+    // (a few per cent of a rank) from its quantile, far inside the capacity slack.  A boundary whose proposal fails
+    // stays where it is for this step; the next step proposes another body.
+    const int q = tid;
+    long long before = 0;
+    for (int r = 0; r <= q; r++) before += __float_as_int(g[(size_t)r * xf + 6]);
+    const long long want = (long long)(q + 1) * n_total / world;
+    const double stride = fmax(1.34 * (double)n_total / (double)kSampTotal, 1.0);  // (bh_dd_cube_pack)
+    const float4 up = reinterpret_cast<const float4*>(g + (size_t)(q + 1) * xf + 8)[0];  // rank q+1, lower end
+    const float4 dn = reinterpret_cast<const float4*>(g + (size_t)q * xf + 8)[1];        // rank q, upper end
+    float4 take = make_float4(0.f, 0.f, 0.f, 0.f);  // (w = 0: this boundary stays)
+    u64 kc = 0ull;
+    int pr = -1;          // the proposing rank
+    double index = 0.0;   // the proposed body's index among that rank's bodies
+    if (want > before && up.w > 0.5f) {
+      kc = body_key<kB>(curve, up.x, up.y, up.z, cube[0], cube[1], cube[2], cube[6]);
+      if (kc >= skeys[q] && (q + 2 >= world || kc < skeys[q + 1])) {
+        take = up;
+        pr = q + 1;
+        index = (double)(want - before);
+      }
+    } else if (want < before && dn.w > 0.5f) {
+      kc = body_key<kB>(curve, dn.x, dn.y, dn.z, cube[0], cube[1], cube[2], cube[6]);
+      if (kc < skeys[q] && (q == 0 || kc >= skeys[q - 1])) {
+        take = dn;
+        pr = q;
+        index = (double)__float_as_int(g[(size_t)q * xf + 6]) - (double)(before - want);
+      }
+    } else if (want != before) {
+      atomicOr(&s_need2, 1);  // a boundary would have to cross a whole rank: sample quantiles for all
+    }
+    if (pr >= 0) {
+      int below = 0;
+      for (int t = 0; t < samp_cap; t++) below += k[pr * samp_cap + t] < kc ? 1 : 0;
+      const double expect = index / stride - 0.5;  // samples sit at (t + 0.5) stride
+      if (fabs((double)below - expect) > 8.0 + expect / 32.0) take.w = 0.0f;
+    }
+    prop[q] = take;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int mode = s_mode == 1 && !s_need2 ? 1 : 2;
+    ddi[9] += 1;
+    ddi[10] = 1;
+    ddi[11] = mode;
+    s_mode = mode;
+  }
+  __syncthreads();
+  if (s_mode == 1) {  // the accepted proposals, keyed under this step's cube
+    if (tid < world - 1 && prop[tid].w > 0.5f) {
+      const float4 p = prop[tid];
+      skeys[tid] = body_key<kB>(curve, p.x, p.y, p.z, cube[0], cube[1], cube[2], cube[6]);
+    }
+    return;
+  }
   for (int size = 2; size <= kSampTotal; size <<= 1) {
     for (int j = size >> 1; j > 0; j >>= 1) {
       // kSampTotal / 2 compare-exchanges per stage, two per thread: pair p -> (i, i | j)

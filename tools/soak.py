@@ -53,6 +53,8 @@ else:
     group = bhdist.LocalGroup(P)
     stream = torch.cuda.Stream(0)
     errs, sts = [], [None] * P
+    log_from = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 30
+    hist = [[] for _ in range(P)]
     def work(r):
         try:
             torch.cuda.set_device(0)
@@ -60,7 +62,13 @@ else:
             sts[r] = st
             group.barrier.wait()
             for s in range(0, steps, 100):
-                st.step(min(100, steps - s))
+                if s >= log_from:   # (argv[5]: log every step from here on; printed when the run fails)
+                    for k in range(min(100, steps - s)):
+                        st.step(1)
+                        hist[r].append((s + k + 1, st.n_loc, st.e.dd_info(), st.mig_last, st.mig_stride_used, st.mig_rounds))
+                        del hist[r][:-14]
+                else:
+                    st.step(min(100, steps - s))
                 fl = st.e.stats().status_flags
                 assert fl == 0, (r, s, fl)
                 group.barrier.wait()
@@ -72,7 +80,11 @@ else:
             errs.append((r, ex)); print("rank", r, repr(ex), flush=True); group.barrier.abort()
     th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
     [t.start() for t in th]; [t.join() for t in th]
-    if errs: raise SystemExit(1)
+    if errs:
+        for r in range(P):
+            for h in hist[r]:
+                print(f"rank {r} step {h[0]}: n_loc {h[1]} info(bodies, emigrants, moves, mode) {h[2][:4]} emig_max {h[3]} stride {h[4]} rounds {h[5]}")
+        raise SystemExit(1)
     tot = sum(s.n_loc for s in sts)
     assert tot == n, tot
     print(f"dd {P} ranks x {n // P} x {steps} steps ok")
