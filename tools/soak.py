@@ -48,7 +48,14 @@ else:
     import torch
     from nbody_barnes_hut_cuda_amd import dist as bhdist
     P, n, steps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    ic = pkg.plummer(n, seed=17)
+    kind = sys.argv[6] if len(sys.argv) > 6 else "plummer"   # plummer | disc | stream (two halves passing through each
+    ic = [a.copy() for a in (pkg.disc if kind == "disc" else pkg.plummer)(n, seed=17)]   # other) | cold (collapse from rest)
+    if kind == "stream":
+        ic[3] += 400.0
+        ic[3][: n // 2] -= 800.0
+    if kind == "cold":
+        ic[3][:] = 0.0; ic[4][:] = 0.0; ic[5][:] = 0.0
+    ic = tuple(ic)
     order = bhdist.global_morton_order(pkg, ic, 0)
     group = bhdist.LocalGroup(P)
     stream = torch.cuda.Stream(0)
@@ -87,4 +94,4 @@ else:
         raise SystemExit(1)
     tot = sum(s.n_loc for s in sts)
     assert tot == n, tot
-    print(f"dd {P} ranks x {n // P} x {steps} steps ok")
+    print(f"dd {P} ranks x {n // P} x {steps} steps ({kind}) ok")
