@@ -261,6 +261,9 @@ def main():
     ap.add_argument("--force-block", type=int, default=0, help="tuning: threads per force workgroup (64/128/256)")
     ap.add_argument("--force-coop", type=int, default=0,
                     help="tuning: waves per group of the force walk (bh_params.force_coop; 0 = automatic, 1 = one wave per group)")
+    ap.add_argument("--dd-split", action="store_true",
+                    help="N > 1: two force passes per step (own pieces while the LET travels, then the remote pass) "
+                         "instead of one after X4 (dist.SPLIT_DEFAULT)")
     ap.add_argument("--graph", action="store_true",
                     help="time bh_step replayed as a HIP graph (no per-stage event records inside the timed region; "
                          "the force-launch time of the roofline block then comes from 10 extra timed-stage steps)")
@@ -337,7 +340,8 @@ def main():
             let_cap = int(os.environ["BH_BENCH_LET_CAP"]) if rehearsal and "BH_BENCH_LET_CAP" in os.environ else None
             stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
                                            xcd_mode=args.xcd_mode, let_cap=let_cap,
-                                           force_block=args.force_block, force_variant=args.force_variant)
+                                           force_block=args.force_block, force_variant=args.force_variant,
+                                           split=True if args.dd_split else None)
             eng = stepper.e
             stepper.step(args.warmup)
         except bhdist.DomainLeft as ex:  # raised on every rank after the same exchange; anything else is rank-local
@@ -511,6 +515,7 @@ def main():
                 "bodies_rank0": int(stepper.n_loc), "let_records_per_rank": [int(v) for v in stepper.let_counts],
                 "let_stride": int(stepper.stride), "emigrants_last_step_max": int(stepper.mig_last),
                 "x4": "per-destination segments, all-to-all" if stepper.let_mode == 1 else "union segment, all-gather",
+                "force_passes": "own pieces beside X4, then the remote pass" if stepper.split else "one, after X4",
                 "x4_bytes_received_per_gpu_per_step": int(world * stepper.stride * 32),
                 "let_retries": int(stepper.let_retries), "extra_migration_rounds": int(stepper.mig_rounds),
                 "phase_ms_rank0": stepper.phase_ms()}

@@ -2111,7 +2111,14 @@ int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts) {
   if (!c || !c->dd) return BH_ERR_BAD_ARG;
   bh_dd_state* d = c->dd;
   if (!d->let_copy_pending) return BH_ERR_ORDER;
-  BH_HIP(c, hipEventSynchronize(d->ev_let));
+  // (polled: hipEventSynchronize wakes the host tens of microseconds after the event — with one force pass per step
+  // that hole sits on the critical path, between the top tree and the force launch; bounded, then the blocking wait)
+  {
+    hipError_t q = hipErrorNotReady;
+    for (long spin = 0; spin < 2000000L && q == hipErrorNotReady; spin++) q = hipEventQuery(d->ev_let);
+    if (q == hipErrorNotReady) q = hipEventSynchronize(d->ev_let);
+    BH_HIP(c, q);
+  }
   d->let_copy_pending = false;
   // counts[q] = the most records rank q needed for any receiver (its needs row: every rank holds the same matrix,
   // so every rank takes the same decision); a negative header marks a rank that left the step

@@ -172,6 +172,13 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
         return e.download_order()
 
 
+# One force pass per step when the caller does not choose (split=False): the LET export and X4 are exposed, but the
+# two-pass form — own pieces on a side stream while the LET travels, then the remote pass — costs 0.42 ms more GPU
+# time per rank-step at 8 x 1M (own 1.15-1.25 + remote 0.50 against 1.23 ms for the one pass: two drains, the top
+# levels walked twice, profiles/r04_dd/split_vs_one_pass.txt), more than the ~0.3 ms (0.125 ms of LET kernels + a
+# 33-MB all-to-all over xGMI) it can hide.  split=True remains for interconnects slow enough to turn that around.
+SPLIT_DEFAULT = False
+
 # X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
 # (DomainStepper(..., let_mode=0) selects round 2's all-gather of the union; tools/dd_debug.py --let-mode 0 for A/B)
 LET_MODE_DEFAULT = 1
@@ -189,9 +196,9 @@ class DomainStepper:
     stitched tree for its own bodies.  Four all-gathers per step, no replicated stage."""
 
     def __init__(self, pkg, ic, comm, device, stream=None, params=None, slack=1.3, mig_frac=0.5,
-                 let_cap=None, order=None, split=True, let_mode=None, mig_log=False, **kw):
+                 let_cap=None, order=None, split=None, let_mode=None, mig_log=False, **kw):
         self.comm = comm
-        self.split = bool(split)
+        self.split = SPLIT_DEFAULT if split is None else bool(split)
         # X4: 0 = all-gather of the union segment (round 2), 1 = per-destination segments, all-to-all
         self.let_mode = LET_MODE_DEFAULT if let_mode is None else int(let_mode)
         self.world, self.rank = comm.world, comm.rank

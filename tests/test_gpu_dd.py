@@ -77,16 +77,18 @@ def rel(a, b):
     return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("let_mode", [0, 1])
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_dd_first_step_matches_single_context(world, let_mode):
+def test_dd_first_step_matches_single_context(world, let_mode, split):
     """let_mode 0: X4 = all-gather of the union of what any rank may open; 1 (default): per-destination segments
-    exchanged with an all-to-all — a receiver holds only what its own boxes can open, the rest arrives closed"""
+    exchanged with an all-to-all — a receiver holds only what its own boxes can open, the rest arrives closed.
+    split: one force pass after X4 (default) / own pieces on a side stream while X4 travels, then the remote pass"""
     pkg = bhpkg.load()
     n = 60000
     ic = pkg.plummer(n, seed=7)
     p1, v1, a1 = single(ic, 1)
-    out = run_ranks(world, ic, 1, let_mode=let_mode)
+    out = run_ranks(world, ic, 1, let_mode=let_mode, split=split)
     p, v, a = merge(out, n)
     e = rel(a, a1)
     # same accepted sets; fp32 summation order differs (top tree first, segments interleaved)
