@@ -1100,27 +1100,33 @@ __global__ __launch_bounds__(1024) void dd_let_sums_kernel(const int* __restrict
                                                            const int* __restrict__ lpos, int rec_cap, int lcap,
                                                            int nch, int* __restrict__ csum) {
   __shared__ int wsum[16];
-  const int j = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+  const int q = blockIdx.y, tid = threadIdx.x;
   const int L = min(lpos[rec_cap], lcap);
-  const int i0 = j * kLetChunk;
-  if (i0 >= L) {
-    if (tid == 0) csum[q * nch + j] = 0;
-    return;
-  }
-  int s = 0;
+  // (the grid is a few blocks per destination, not one per chunk of the list's CAPACITY: the list length is only
+  // known on the device, and 160 chunks x 8 destinations of 1024-thread blocks that mostly found nothing to do were
+  // most of these two kernels' 25 us)
+  for (int j = blockIdx.x; j < nch; j += gridDim.x) {
+    const int i0 = j * kLetChunk;
+    if (i0 >= L) {
+      if (tid == 0) csum[q * nch + j] = 0;
+      continue;
+    }
+    int s = 0;
 #pragma unroll
-  for (int k = 0; k < kLetChunk / 1024; k++) {
-    const int i = i0 + k * 1024 + tid;
-    if (i < L && ((list_m[i] >> q) & 1u)) s += list_w[i];
-  }
+    for (int k = 0; k < kLetChunk / 1024; k++) {
+      const int i = i0 + k * 1024 + tid;
+      if (i < L && ((list_m[i] >> q) & 1u)) s += list_w[i];
+    }
 #pragma unroll
-  for (int dd = 32; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd, 64);
-  if ((tid & 63) == 0) wsum[tid >> 6] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int t = 0;
-    for (int k = 0; k < 16; k++) t += wsum[k];
-    csum[q * nch + j] = t;
+    for (int dd = 32; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd, 64);
+    __syncthreads();  // (wsum of the previous chunk has been read)
+    if ((tid & 63) == 0) wsum[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int k = 0; k < 16; k++) t += wsum[k];
+      csum[q * nch + j] = t;
+    }
   }
 }
 
@@ -1132,43 +1138,46 @@ __global__ __launch_bounds__(1024) void dd_let_scan_kernel(const int* __restrict
   __shared__ int wsum[16];
   __shared__ int s_base;
   constexpr int kPer = kLetChunk / 1024;
-  const int j = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int L = min(lpos[rec_cap], lcap);
-  const int i0 = j * kLetChunk;
-  if (i0 >= L && j > 0) return;  // (chunk 0 always runs: it writes the total of an empty list)
-  if (tid < 64) {                // base = chunk sums before this one
-    int b = 0;
-    for (int k = tid; k < j; k += 64) b += csum[q * nch + k];
+  for (int j = blockIdx.x; j < nch; j += gridDim.x) {  // (see dd_let_sums_kernel)
+    const int i0 = j * kLetChunk;
+    if (i0 >= L && j > 0) break;  // (chunk 0 always runs: it writes the total of an empty list)
+    __syncthreads();              // (s_base / wsum of the previous chunk have been read)
+    if (tid < 64) {               // base = chunk sums before this one
+      int b = 0;
+      for (int k = tid; k < j; k += 64) b += csum[q * nch + k];
 #pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) b += __shfl_xor(b, dd, 64);
-    if (tid == 0) s_base = b;
-  }
-  int x[kPer], s = 0;
+      for (int dd = 32; dd >= 1; dd >>= 1) b += __shfl_xor(b, dd, 64);
+      if (tid == 0) s_base = b;
+    }
+    int x[kPer], s = 0;
 #pragma unroll
-  for (int k = 0; k < kPer; k++) {
-    const int i = i0 + kPer * tid + k;
-    x[k] = (i < L && ((list_m[i] >> q) & 1u)) ? list_w[i] : 0;
-    s += x[k];
-  }
-  int inc = s;
+    for (int k = 0; k < kPer; k++) {
+      const int i = i0 + kPer * tid + k;
+      x[k] = (i < L && ((list_m[i] >> q) & 1u)) ? list_w[i] : 0;
+      s += x[k];
+    }
+    int inc = s;
 #pragma unroll
-  for (int dd = 1; dd < 64; dd <<= 1) {
-    const int u = __shfl_up(inc, dd, 64);
-    if (lane >= dd) inc += u;
-  }
-  if (lane == 63) wsum[wv] = inc;
-  __syncthreads();
-  int pre = s_base;
-  for (int k = 0; k < wv; k++) pre += wsum[k];
-  int run = pre + inc - s;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int u = __shfl_up(inc, dd, 64);
+      if (lane >= dd) inc += u;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int pre = s_base;
+    for (int k = 0; k < wv; k++) pre += wsum[k];
+    int run = pre + inc - s;
 #pragma unroll
-  for (int k = 0; k < kPer; k++) {
-    const int i = i0 + kPer * tid + k;
-    if (i < L) dstd[(size_t)q * lcap + i] = run;
-    run += x[k];
+    for (int k = 0; k < kPer; k++) {
+      const int i = i0 + kPer * tid + k;
+      if (i < L) dstd[(size_t)q * lcap + i] = run;
+      run += x[k];
+    }
+    // the block of the list's last chunk (or chunk 0 of an empty list) knows the destination's total
+    if (tid == 1023 && (i0 + kLetChunk >= L)) dtot[q] = pre + inc;
   }
-  // the block of the list's last chunk (or chunk 0 of an empty list) knows the destination's total
-  if (tid == 1023 && (i0 + kLetChunk >= L)) dtot[q] = pre + inc;
 }
 
 // the copy of record `fr` (pool index c on the sender) that goes to destination q
@@ -1999,7 +2008,7 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
                                                       c->rec_cap, n_cap, d->list_e, d->list_w, d->list_m, c->info);
     {
       const int nch = (n_cap + kLetChunk - 1) / kLetChunk;
-      const dim3 grid((unsigned)nch, (unsigned)d->world);
+      const dim3 grid((unsigned)(nch < 32 ? nch : 32), (unsigned)d->world);
       dd_let_sums_kernel<<<grid, 1024, 0, c->stream>>>(d->list_w, d->list_m, d->dst, c->rec_cap, n_cap, nch, d->csum);
       dd_let_scan_kernel<<<grid, 1024, 0, c->stream>>>(d->list_w, d->list_m, d->dst, c->rec_cap, n_cap, nch, d->csum,
                                                        d->dstd, d->dtot);
