@@ -43,18 +43,34 @@ def b_alg(V, O, P, n):
     return 24 * V + 32 * O + 16 * P + 24 * n
 
 
+def csrc_sha16():
+    """identity of the kernels this run executes: sha256 over the library's sources (the GPU box has no .git)"""
+    import hashlib
+    d = os.path.join(ROOT, "nbody-barnes-hut-cuda_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(n, theta):
-    """(HBM bytes per force launch, provenance) from the committed PMC passes under profiles/, or (None, None).
-    Not measured by this run: rocprofv3 counters cannot be read from inside the benchmark."""
+    """(HBM bytes per force launch, provenance, stale) from the committed PMC passes under profiles/, or (None, None,
+    None).  Not measured by this run: rocprofv3 counters cannot be read from inside the benchmark.  `stale` = the
+    record was taken with other kernel sources than this run's (tools/collect_profiles.py stores the csrc hash the
+    profiled bench printed)."""
     path = os.path.join(ROOT, "profiles", "force_traffic.json")
     try:
         t = json.load(open(path))
         for rec in reversed(t.get("records", [])):
             if rec.get("n") == n and abs(rec.get("theta", -1) - theta) < 1e-6:
-                return rec.get("hbm_bytes_per_launch"), f"committed profile {rec.get('profile')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                return (rec.get("hbm_bytes_per_launch"),
+                        f"committed profile {rec.get('profile')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
+                        rec.get("csrc_sha16") != csrc_sha16())
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def measured_copy_bandwidth(torch, nbytes=1 << 30, reps=10):
@@ -314,8 +330,8 @@ def main():
     ic = pkg.plummer(n_total, seed=args.seed)  # identical on every rank (counter-based RNG)
 
     from nbody_barnes_hut_cuda_amd import dist as bhdist
-    # N > 1: domain-decomposed stepping (each rank owns one Morton-key range, builds only its own
-    # octree and imports locally-essential records; DESIGN.md §7).  BH_DIST_MODE=replicated selects the
+    # N > 1: domain-decomposed stepping (each rank owns one interval of the key curve, builds only its own
+    # octree and imports locally-essential records; DESIGN.md §6).  BH_DIST_MODE=replicated selects the
     # round-1 scheme (replicated tree, sharded traversal, acc all-gather) for A/B.
     dist_mode = os.environ.get("BH_DIST_MODE", "domain") if multi else "single"
     def barrier():
@@ -323,11 +339,63 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(v):
+        if dist is None:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    engine_kw = dict(theta=args.theta, xcd_mode=args.xcd_mode, force_block=args.force_block,
+                     force_variant=args.force_variant)
+
+    # The 1-GPU reference of the scaling figures, measured in THIS run before anything collective: bh_step on
+    # --bodies bodies on every GPU at the same time (the node's power / clock state of the multi-GPU job), the
+    # slowest rank counts.  aggregate_x = value / (bodies / that time).
+    n1 = None
+    if multi:
+        icn = pkg.plummer(args.n, seed=args.seed)
+        with pkg.Engine(args.n, device=local_rank, leaf_cap=args.leaf_cap, force_coop=args.force_coop, **engine_kw) as e1:
+            e1.upload(*icn)
+            e1.step(args.warmup)
+            e1.sync()
+            barrier()
+            t1 = time.perf_counter()
+            e1.step(args.steps)
+            e1.sync()
+            mine = (time.perf_counter() - t1) * 1e3 / args.steps
+        n1 = {"bodies": args.n, "ms_per_step_slowest_gpu": reduce_max(mine), "ms_per_step_rank0": mine,
+              "note": "bh_step on one GPU's share, all GPUs of the job running it at once, same process, before "
+                      "the collective part"}
+        del icn
+
+    # how the exchanges travel: the library's RCCL transport on the rank's own stream (bh_comm_rccl_init_rank, unique
+    # id broadcast through torch.distributed); every rank must get it or all use the torch.distributed callbacks
+    transport = None
+    def make_comm():
+        nonlocal transport
+        if rehearsal or os.environ.get("BH_BENCH_COMM") == "torch":
+            transport = "torch.distributed callbacks (%s)" % dist.get_backend()
+            return bhdist.TorchComm()
+        comm, ok = None, 1.0
+        try:
+            comm = bhdist.RcclComm(local_rank)
+        except Exception as ex:  # noqa: BLE001 - decided collectively below
+            print(f"[bench rank {rank}] RCCL transport unavailable: {ex!r}", file=sys.stderr, flush=True)
+            ok = 0.0
+        if reduce_max(1.0 - ok) > 0.0:   # somebody failed: everybody falls back
+            transport = "torch.distributed callbacks (nccl); the library's RCCL transport failed to initialise"
+            return bhdist.TorchComm()
+        transport = "library RCCL transport (ncclAllGather / ncclAllToAll on the rank's stream)"
+        return comm
+
+    def domain_stepper(ic_, let_cap=None):
+        return bhdist.DomainStepper(pkg, ic_, make_comm(), local_rank, let_cap=let_cap,
+                                    split=True if args.dd_split else None, **engine_kw)
+
     def replicated():
-        e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, theta=args.theta,
-                                        xcd_mode=args.xcd_mode,
-                                        leaf_cap=args.leaf_cap, force_block=args.force_block, force_coop=args.force_coop,
-                                        force_variant=args.force_variant, step_graph=1 if args.graph else 0)
+        e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, leaf_cap=args.leaf_cap,
+                                        force_coop=args.force_coop, step_graph=1 if args.graph else 0, **engine_kw)
         e.upload(*ic)
         return e, st
 
@@ -338,10 +406,7 @@ def main():
         try:
             # BH_BENCH_LET_CAP: rehearsal hook (tests/test_gpu_dist.py drives the fallback with a tiny LET capacity)
             let_cap = int(os.environ["BH_BENCH_LET_CAP"]) if rehearsal and "BH_BENCH_LET_CAP" in os.environ else None
-            stepper = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), local_rank, theta=args.theta,
-                                           xcd_mode=args.xcd_mode, let_cap=let_cap,
-                                           force_block=args.force_block, force_variant=args.force_variant,
-                                           split=True if args.dd_split else None)
+            stepper = domain_stepper(ic, let_cap)
             eng = stepper.e
             stepper.step(args.warmup)
         except bhdist.DomainLeft as ex:  # raised on every rank after the same exchange; anything else is rank-local
@@ -351,9 +416,14 @@ def main():
             dist_mode = "replicated"
             eng, stepper = replicated()
             stepper.step(args.warmup)
-    else:
+    elif multi:
         eng, stepper = replicated()
         stepper.step(args.warmup)
+    else:
+        eng = pkg.Engine(n_total, device=local_rank, leaf_cap=args.leaf_cap, force_coop=args.force_coop,
+                         step_graph=1 if args.graph else 0, **engine_kw)
+        eng.upload(*ic)
+        eng.step(args.warmup)
     barrier()
 
     # algorithmic bytes of one force launch on the tree the timed region starts from
@@ -388,11 +458,7 @@ def main():
             t0 = time.perf_counter()
             stepper.step(args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max(time.perf_counter() - t0)
 
     # per-phase device times of the domain-decomposed step: 5 further steps on every rank (the exchanges are
     # collective), events on rank 0's stream only — NOT in the timed region: each event record costs the stream
@@ -403,6 +469,32 @@ def main():
             stepper.step(5)
         except bhdist.DomainLeft as ex:
             print(f"[bench rank {rank}] profiling steps left the domain scheme: {ex!r}", file=sys.stderr, flush=True)
+        barrier()
+
+    # BASELINE.json's metric is worded on strong scaling ("1M bodies ... at 1/2/4/8 GPUs"): the same --bodies as ONE
+    # system over all GPUs, in the same invocation (the headline `value` stays the weak-scaling workload, configs[3])
+    strong = None
+    if multi and not args.strong and dist_mode == "domain" and os.environ.get("BH_BENCH_NO_STRONG") != "1":
+        ic_s = pkg.plummer(args.n, seed=args.seed)
+        st_s = None
+        try:
+            st_s = domain_stepper(ic_s)
+            st_s.step(args.warmup)
+            barrier()
+            ts = time.perf_counter()
+            st_s.step(args.steps)
+            barrier()
+            el = reduce_max(time.perf_counter() - ts)
+            strong = {"n_total": args.n, "value": args.n * args.steps / el, "unit": "particles/s/step",
+                      "ms_per_step": el * 1e3 / args.steps, "scaling": "strong",
+                      "let_records_per_rank": [int(v) for v in st_s.let_counts], "bodies_rank0": int(st_s.n_loc)}
+            if n1:
+                strong["speedup_vs_one_gpu"] = n1["ms_per_step_slowest_gpu"] / strong["ms_per_step"]
+        except bhdist.DomainLeft as ex:
+            strong = {"n_total": args.n, "error": repr(ex)}
+        finally:
+            if st_s is not None:
+                st_s.close()
         barrier()
 
     out = None
@@ -452,12 +544,12 @@ def main():
             # accumulate) and 11 per cell a body OPENS (the MAC half only: its force half is discarded)
             useful_flop = (V - O + P) * 20.0 + O * 11.0
             useful_tflops = useful_flop / (avg_force_ms * 1e-3) / 1e12
-            traffic, traffic_src = load_traffic(n_total, args.theta)
+            traffic, traffic_src, traffic_stale = load_traffic(n_total, args.theta)
             alg_gbs = bytes_alg / (avg_force_ms * 1e-3) / 1e9
             roofline = {
                 "bound": "valu", "achieved": useful_tflops, "peak": FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": useful_tflops / FP32_VECTOR_TFLOPS,
-                "traffic": traffic, "traffic_provenance": traffic_src,
+                "traffic": traffic, "traffic_provenance": traffic_src, "traffic_stale": traffic_stale,
                 "kernel": launch + "; in bh_step the launch also integrates its bodies and folds the next cube "
                           "(~3 us of the launch time)",
                 "avg_launch_ms": avg_force_ms,
@@ -487,8 +579,10 @@ def main():
                       "last_step_ms": {"bbox": st.ms_bbox, "morton": st.ms_morton, "sort": st.ms_sort,
                                        "build": st.ms_build, "com": st.ms_com, "force": st.ms_force,
                                        "integrate": st.ms_integrate}}
+        per_gpu = n_total // world
         out = {
-            "metric": "particles/sec/step (1M bodies per GPU, theta=0.5)",
+            "metric": (f"particles/sec/step ({n_total:,} bodies in total over {world} GPU(s), theta={args.theta})" if args.strong
+                       else f"particles/sec/step ({per_gpu:,} bodies per GPU, theta={args.theta})"),
             "value": value, "unit": "particles/s/step",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
@@ -499,13 +593,23 @@ def main():
                             "(BASELINE.json configs[2]; x8 = configs[3])",
                 "n_total": n_total,
                 "parallelism": "1 GPU" if not multi else (
-                    f"{world} ranks, domain decomposition: per-rank octree of one Morton-key range, top tree + "
-                    "locally-essential records: 3 all-gathers + 1 all-to-all per step (RCCL)" if dist_mode == "domain" else
+                    f"{world} ranks, domain decomposition: per-rank octree of one interval of the key curve, top tree + "
+                    "locally-essential records: 3 all-gathers + 1 all-to-all per step, protocol inside libbh.so "
+                    f"(bh_rank_step); transport: {transport}" if dist_mode == "domain" else
                     f"{world} ranks: replicated tree, Morton-slab sharded traversal, acc all-gather (RCCL)"),
                 "tree": {"cells": st.n_internal, "records": st.n_entries, "max_level": st.max_level},
             },
             "roofline": roofline,
+            "build": {"csrc_sha16": csrc_sha16(), "abi": int(pkg.lib.bh_abi_version())},
         }
+        if n1:
+            out["n1_ms_per_step"] = n1["ms_per_step_slowest_gpu"]
+            out["n1"] = n1
+            # whole-job throughput over the throughput of ONE GPU stepping one GPU's share (weak scaling: that share
+            # is --bodies; --strong: the whole system on one GPU)
+            out["aggregate_x"] = value / (n1["bodies"] / (n1["ms_per_step_slowest_gpu"] * 1e-3))
+        if strong:
+            out["strong"] = strong
         if stages:
             out["stages"] = stages
         if fallback_reason:
@@ -529,7 +633,10 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    eng.close()
+    if dist_mode == "domain":
+        stepper.close()   # the rank owns its context (and its RCCL communicator)
+    else:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 4 /* 2: bh_params grew key_curve (72 bytes); 3: bh_dd_phase_*, timing mode 3; 4: force_coop,
-                             bh_dd_get_info, larger X1 payload (boundary proposals), bh_walk_stats fields */
+#define BH_ABI_VERSION 5 /* 2: bh_params grew key_curve (72 bytes); 3: bh_dd_phase_*, timing mode 3; 4: force_coop,
+                             bh_dd_get_info, larger X1 payload (boundary proposals), bh_walk_stats fields; 5: bh_comm,
+                             bh_rank_*, bh_group (the multi-GPU step behind the ABI), BH_ERR_COMM / _DOMAIN_LEFT */
 
 typedef struct bh_ctx bh_ctx; /* opaque; replaces the globals ref:31-40 */
 
@@ -42,8 +43,14 @@ typedef enum bh_status {
                                the 2n+8 pool; checked anyway, cf. ref:321 D8)     */
   BH_ERR_ORDER = -6,        /* stage called before the stage it depends on         */
   BH_ERR_SMALL_BUFFER = -7, /* caller buffer too small for a download              */
-  BH_ERR_DEVICE_FLAG = -8   /* a device-side sticky flag (BH_FLAG_*, bh_get_stats().status_flags)
+  BH_ERR_DEVICE_FLAG = -8,  /* a device-side sticky flag (BH_FLAG_*, bh_get_stats().status_flags)
                                is set: results since it was raised are invalid       */
+  BH_ERR_COMM = -9,         /* a bh_comm transfer failed (RCCL error, a callback returned non-zero, hub aborted) */
+  BH_ERR_DOMAIN_LEFT = -10  /* COLLECTIVE: every rank returns it from the same step of bh_rank_step — a rank
+                               announced a local failure through its X4 header, or a LET outgrew let_cap (decided
+                               from all-gathered counts).  The only multi-rank error a caller may answer
+                               collectively (e.g. by moving every rank to another scheme); anything else is
+                               rank-local                                                                     */
 } bh_status;
 
 /* Physical and structural parameters.  Defaults = the reference's #defines. */
@@ -350,6 +357,125 @@ int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc);
    to step), 1 moved to the exact quantiles (a rank's body count had left n / P by more than
    1.5 %), 2 drawn from position samples (first step, or a boundary would have had to cross a whole rank) */
 int bh_dd_get_info(bh_ctx* c, int32_t out[8]);
+
+/* ---- the multi-GPU step behind the C-ABI (round 5; SURVEY §8b bh_create_group / bh_step_group) ----
+ * bh_rank  = one rank of the domain-decomposed step: a context, its exchange buffers and the per-step PROTOCOL
+ *            (the order X1..X4, extra migration rounds, the negotiation of the X2 / X4 sizes, the LET retry, the rule
+ *            that a failed rank keeps exchanging empty payloads so that nobody is stranded in a collective).  Bytes
+ *            move through a bh_comm: three transports ship with the library (RCCL, in-process device copies, caller
+ *            callbacks — through which dist.py keeps torch.distributed).  One process per GPU calls bh_rank_step.
+ * bh_group = the ranks of ONE process, one host thread per rank: `int devices[n]` all different -> one rank per GPU
+ *            over RCCL (ncclCommInitAll); a device listed several times -> in-process copies (one-GPU rehearsal and
+ *            tests; RCCL refuses two ranks on one device).  bh_step_group is simulationStep() (ref:255-283) for the
+ *            whole node, bh_group_upload / bh_group_download are main()'s copies (ref:329-335, 337-343).           */
+typedef struct bh_comm { /* how a rank's buffers travel.  Functions return 0 or non-zero; they enqueue on hip_stream
+                            (or complete before returning); pointers are device pointers (host pointers for a scripted
+                            rank) */
+  int32_t world, rank;
+  void* user;
+  /* recv[q * bytes .. (q + 1) * bytes) <- rank q's send[0 .. bytes) */
+  int (*all_gather)(void* user, void* recv, const void* send, int64_t bytes, void* hip_stream);
+  /* recv chunk q <- rank q's send chunk `rank`, chunks of bytes_per_peer */
+  int (*all_to_all)(void* user, void* recv, const void* send, int64_t bytes_per_peer, void* hip_stream);
+  void (*release)(void* user); /* called once by bh_rank_destroy (or by the caller if no rank took the comm); may be NULL */
+} bh_comm;
+
+/* RCCL transport (librccl.so.1 is opened at the first call, not linked: a process that already holds RCCL — torch —
+   shares its copy).  _from: a communicator the caller owns.  _unique_id + _init_rank: one process per GPU
+   (ncclGetUniqueId on one rank, the 128 bytes broadcast by the launcher, ncclCommInitRank everywhere); the
+   communicator is destroyed by the comm's release. */
+int bh_comm_rccl_from(bh_comm* out, void* nccl_comm, int world, int rank);
+int bh_comm_rccl_unique_id(void* id128);
+int bh_comm_rccl_init_rank(bh_comm* out, const void* id128, int world, int rank, int device);
+/* in-process transport: `world` ranks of one process (host threads), device-to-device copies ordered by events */
+typedef struct bh_hub bh_hub;
+int bh_hub_create(bh_hub** out, int world);
+int bh_comm_hub(bh_comm* out, bh_hub* hub, int rank);
+void bh_hub_abort(bh_hub* hub);   /* releases every rank waiting in an exchange with BH_ERR_COMM (a rank died) */
+void bh_hub_destroy(bh_hub* hub);
+
+typedef struct bh_rank bh_rank;
+typedef struct bh_rank_opts {
+  int32_t n_cap;    /* body capacity of the rank; 0 = 1.3 x ceil(n_total / world) + 4096                     */
+  int32_t mig_cap;  /* emigrant slots of the X2 buffers; 0 = min(max(4096, n_cap / 2), 4 n_cap / world)        */
+  int32_t let_cap;  /* records per LET segment; 0 = 516 + n_cap                                                */
+  int32_t let_mode; /* X4: 1 = per-destination segments, all-to-all (default); 0 = one union segment, all-gather */
+  int32_t split;    /* 0 = one force pass after X4 (default); 1 = own pieces beside X4, then the remote pass    */
+  int32_t log;      /* 1 = keep (emigrants, boundary action) per step for bh_rank_read_log: synchronises, tests  */
+  int32_t reserved[10];
+} bh_rank_opts;
+typedef struct bh_rank_plan { /* bh_rank_query: the resolved capacities and the byte sizes of the eight buffers */
+  int32_t n_cap, mig_cap, let_cap, stride0;
+  bh_dd_sizes sz;
+  int64_t bytes[8]; /* x1s, x1r, x2s, x2r, x3s, x3r, x4s (send segments), pool */
+} bh_rank_plan;
+typedef struct bh_rank_buffers { void *x1s, *x1r, *x2s, *x2r, *x3s, *x3r, *x4s, *pool; } bh_rank_buffers;
+typedef struct bh_rank_info {
+  int32_t n_loc;        /* bodies this rank holds                                                    */
+  int32_t stride;       /* records per LET segment of the next X4                                    */
+  int32_t mig_stride;   /* emigrant slots per rank of the next step's first X2 round                 */
+  int32_t mig_last;     /* most emigrants any rank found in the last step                            */
+  int32_t mig_rounds;   /* extra migration rounds since creation                                     */
+  int32_t let_retries;  /* X4 repeats since creation                                                 */
+  int32_t left_rank;    /* BH_ERR_DOMAIN_LEFT: the rank that left (-1: a LET outgrew let_cap)        */
+  int32_t left_status;  /* this rank's own failing status when it is the one that left, else 0       */
+  int64_t steps;        /* completed steps                                                           */
+  int32_t let_counts[64]; /* records every rank needed in the last X4                                */
+  int32_t reserved[8];
+} bh_rank_info;
+
+int bh_rank_default_opts(bh_rank_opts* o);
+int bh_rank_query(int64_t n_total, int world, const bh_rank_opts* o, bh_rank_plan* out);
+/* hip_stream NULL: the rank makes its own; bufs NULL: the rank allocates (else eight caller-owned device buffers of
+   at least plan.bytes[] each, zero-filled, alive until bh_rank_destroy).  The comm is copied. */
+int bh_rank_create(bh_rank** out, const bh_comm* comm, int64_t n_total, const bh_params* p, const bh_rank_opts* o,
+                   int device, void* hip_stream, const bh_rank_buffers* bufs);
+/* the bodies this rank starts with and their global ids (bh_dd_upload) */
+int bh_rank_upload(bh_rank* r, int n_loc, const float* x, const float* y, const float* z, const float* vx,
+                   const float* vy, const float* vz, const float* m, const int32_t* ids);
+/* `steps` steps of the protocol (collective: every rank of the comm calls it with the same count) */
+int bh_rank_step(bh_rank* r, int steps);
+int bh_rank_get_info(bh_rank* r, bh_rank_info* out);
+bh_ctx* bh_rank_ctx(bh_rank* r); /* the rank's context: bh_dd_download, bh_get_stats, bh_sync, bh_dd_get_info */
+int bh_rank_buffers_of(bh_rank* r, bh_rank_buffers* out, bh_rank_plan* plan);
+/* device time per phase, events on the rank's stream: on = 1 starts (and clears), 0 stops */
+#define BH_RANK_PHASES 6 /* x1 exchange | cube, splitters, X2 migration, local tree | x3 exchange | LET export + X4 |
+                            top tree + force | integrate + next X1 payload */
+int bh_rank_set_profile(bh_rank* r, int on);
+int bh_rank_phase_ms(bh_rank* r, double mean_ms[BH_RANK_PHASES], int* steps);
+int bh_rank_read_log(bh_rank* r, int32_t* pairs, int capacity_pairs, int* n_pairs);
+void bh_rank_destroy(bh_rank* r);
+/* Test hook: the same protocol around a SCRIPTED engine and host buffers (no GPU): tests/test_dist_cpu.py drives
+   it over gloo.  The callbacks have the meaning of bh_dd_cube_pack, bh_dd_phase_migrate, bh_dd_migrate_pack,
+   bh_dd_phase_tree, bh_dd_phase_let, bh_dd_phase_force, bh_dd_phase_end with `user` for the context. */
+typedef struct bh_rank_script {
+  void* user;
+  int (*cube_pack)(void* user, void* x1s);
+  int (*phase_migrate)(void* user, const void* x1r, void* x2s, int limit);
+  int (*migrate_pack)(void* user, void* x2s, int limit);
+  int (*phase_tree)(void* user, const void* x2r, int limit, void* x3s, int* n_loc, int* more, int* most);
+  int (*phase_let)(void* user, const void* x3r, void* x4s, int stride, int own_pass);
+  int (*phase_force)(void* user, const void* x3r, int stride, int32_t* counts, int* fits);
+  int (*phase_end)(void* user, void* x1s);
+} bh_rank_script;
+int bh_rank_create_scripted(bh_rank** out, const bh_comm* comm, const bh_rank_script* script, const bh_rank_plan* plan,
+                            const bh_rank_opts* o);
+
+typedef struct bh_group bh_group;
+/* transport: 0 = automatic (RCCL when all devices differ, else in-process copies), 1 = RCCL, 2 = in-process copies */
+int bh_create_group(bh_group** out, int ngpus, const int* devices, int64_t n_total, const bh_params* p,
+                    const bh_rank_opts* o, int transport);
+/* the whole system, caller order (as bh_upload): keyed and sorted once on devices[0], slab q of the curve -> rank q */
+int bh_group_upload(bh_group* g, const float* x, const float* y, const float* z, const float* vx, const float* vy,
+                    const float* vz, const float* m);
+int bh_step_group(bh_group* g, int steps); /* returns when every rank has enqueued its steps; BH_ERR_DOMAIN_LEFT or the
+                                              first rank-local error (the other ranks are released) */
+int bh_group_sync(bh_group* g);            /* bh_sync of every rank */
+int bh_group_download(bh_group* g, float* x, float* y, float* z, float* vx, float* vy, float* vz); /* caller order */
+int bh_group_download_acc(bh_group* g, float* ax, float* ay, float* az);                           /* caller order */
+int bh_group_size(const bh_group* g);
+bh_rank* bh_group_rank(bh_group* g, int rank);
+void bh_destroy_group(bh_group* g);
 
 /* per-step device times (hipEvent pairs recorded on the context's stream while
    bh_set_timing is on) of the most recent steps, oldest first: ms_force[i], ms_step[i].

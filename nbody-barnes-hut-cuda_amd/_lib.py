@@ -59,11 +59,59 @@ class BhDdSizes(C.Structure):
                 ("x1_bytes", "x2_bytes", "x3_bytes", "pool_records", "seg_base", "let_min", "let_cap", "top_base")]
 
 
-BH_DD_PIECE_CAP = 512
-
-# every symbol include/bh.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
+BH_DD_PIECE_CAP = 512
+BH_ERR_COMM, BH_ERR_DOMAIN_LEFT = -9, -10
+
+# ---- the multi-GPU step behind the ABI (bh_comm / bh_rank / bh_group)
+COMM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+COMM_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class BhComm(C.Structure):
+    """struct bh_comm: how a rank's buffers travel (all_gather / all_to_all on a HIP stream)."""
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("user", C.c_void_p),
+                ("all_gather", COMM_FN), ("all_to_all", COMM_FN), ("release", COMM_RELEASE_FN)]
+
+
+class BhRankOpts(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n_cap", "mig_cap", "let_cap", "let_mode", "split", "log")] + \
+               [("reserved", C.c_int32 * 10)]
+
+
+class BhRankPlan(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n_cap", "mig_cap", "let_cap", "stride0")] + \
+               [("sz", BhDdSizes), ("bytes", C.c_int64 * 8)]
+
+
+class BhRankBuffers(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x1s", "x1r", "x2s", "x2r", "x3s", "x3r", "x4s", "pool")]
+
+
+class BhRankInfo(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n_loc", "stride", "mig_stride", "mig_last", "mig_rounds", "let_retries",
+                                         "left_rank", "left_status")] + \
+               [("steps", C.c_int64), ("let_counts", C.c_int32 * 64), ("reserved", C.c_int32 * 8)]
+
+
+_PI = C.POINTER(C.c_int)
+SCRIPT_FNS = [
+    ("cube_pack", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)),
+    ("phase_migrate", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)),
+    ("migrate_pack", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)),
+    ("phase_tree", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, _PI, _PI, _PI)),
+    ("phase_let", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int)),
+    ("phase_force", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), _PI)),
+    ("phase_end", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)),
+]
+
+
+class BhRankScript(C.Structure):
+    """struct bh_rank_script: a scripted engine behind the step protocol (CPU protocol tests)."""
+    _fields_ = [("user", C.c_void_p)] + SCRIPT_FNS
+
+# every symbol include/bh.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("bh_abi_version", C.c_int, []),
     ("bh_default_params", C.c_int, [C.POINTER(BhParams)]),
@@ -128,6 +176,38 @@ SYMBOLS = [
     ("bh_dd_phase_end", C.c_int, [_P, _P]),
     ("bh_dd_download", C.c_int, [_P, _F, _F, _F]),
     ("bh_dd_get_info", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("bh_comm_rccl_from", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int]),
+    ("bh_comm_rccl_unique_id", C.c_int, [_P]),
+    ("bh_comm_rccl_init_rank", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int, C.c_int]),
+    ("bh_hub_create", C.c_int, [C.POINTER(_P), C.c_int]),
+    ("bh_comm_hub", C.c_int, [C.POINTER(BhComm), _P, C.c_int]),
+    ("bh_hub_abort", None, [_P]),
+    ("bh_hub_destroy", None, [_P]),
+    ("bh_rank_default_opts", C.c_int, [C.POINTER(BhRankOpts)]),
+    ("bh_rank_query", C.c_int, [C.c_int64, C.c_int, C.POINTER(BhRankOpts), C.POINTER(BhRankPlan)]),
+    ("bh_rank_create", C.c_int, [C.POINTER(_P), C.POINTER(BhComm), C.c_int64, C.POINTER(BhParams),
+                                 C.POINTER(BhRankOpts), C.c_int, _P, C.POINTER(BhRankBuffers)]),
+    ("bh_rank_create_scripted", C.c_int, [C.POINTER(_P), C.POINTER(BhComm), C.POINTER(BhRankScript),
+                                          C.POINTER(BhRankPlan), C.POINTER(BhRankOpts)]),
+    ("bh_rank_upload", C.c_int, [_P, C.c_int] + [_F] * 7 + [C.POINTER(C.c_int32)]),
+    ("bh_rank_step", C.c_int, [_P, C.c_int]),
+    ("bh_rank_get_info", C.c_int, [_P, C.POINTER(BhRankInfo)]),
+    ("bh_rank_ctx", _P, [_P]),
+    ("bh_rank_buffers_of", C.c_int, [_P, C.POINTER(BhRankBuffers), C.POINTER(BhRankPlan)]),
+    ("bh_rank_set_profile", C.c_int, [_P, C.c_int]),
+    ("bh_rank_phase_ms", C.c_int, [_P, C.POINTER(C.c_double), _PI]),
+    ("bh_rank_read_log", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, _PI]),
+    ("bh_rank_destroy", None, [_P]),
+    ("bh_create_group", C.c_int, [C.POINTER(_P), C.c_int, _PI, C.c_int64, C.POINTER(BhParams),
+                                  C.POINTER(BhRankOpts), C.c_int]),
+    ("bh_group_upload", C.c_int, [_P] + [_F] * 7),
+    ("bh_step_group", C.c_int, [_P, C.c_int]),
+    ("bh_group_sync", C.c_int, [_P]),
+    ("bh_group_download", C.c_int, [_P] + [_F] * 6),
+    ("bh_group_download_acc", C.c_int, [_P] + [_F] * 3),
+    ("bh_group_size", C.c_int, [_P]),
+    ("bh_group_rank", _P, [_P, C.c_int]),
+    ("bh_destroy_group", None, [_P]),
     ("bh_ic_plummer", C.c_int, [C.c_int, C.c_uint64, C.c_float, C.c_float] + [_F] * 7),
     ("bh_ic_disc", C.c_int, [C.c_int, C.c_uint64, C.c_float] + [_F] * 7),
     ("bh_ic_disc_msvc", C.c_int, [C.c_int, C.c_uint32, C.c_float] + [_F] * 7),

@@ -67,6 +67,8 @@ const char* bh_strerror(int s) {
     case BH_ERR_ORDER: return "stage called out of order";
     case BH_ERR_SMALL_BUFFER: return "caller buffer too small";
     case BH_ERR_DEVICE_FLAG: return "device-side error flag set (see bh_get_stats().status_flags)";
+    case BH_ERR_COMM: return "exchange between ranks failed (bh_comm)";
+    case BH_ERR_DOMAIN_LEFT: return "a rank left the domain-decomposed step (collective: every rank returns this)";
     default: return "unknown status";
   }
 }

@@ -1,19 +1,22 @@
-"""Multi-GPU stepping: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+"""Multi-GPU stepping from Python: one process per GPU (the reference is single-GPU).
 
-The reference is single-GPU (no NCCL/MPI call sites); this layer is new design
-(SURVEY §8e).  Round-1 scheme — exact by construction:
+DomainStepper — the product's scheme — is a thin binding of `bh_rank` (include/bh.h, csrc/bh_group.hip): every rank
+owns the bodies of one interval of the key curve (the splitter keys persist from step to step), builds only their
+octree, and per step exchanges  X1 cube + boundary proposals, X2 emigrants, X3 piece descriptors (three all-gathers)
+and X4 per-destination locally-essential records (one all-to-all); one force pass over the stitched tree.  The whole
+per-step protocol lives in the library (bh_rank_step); this module only chooses how the bytes travel:
 
-  * every rank holds the full particle state and builds the SAME tree (bbox, keys, sort, build
-    and COM are deterministic, so the replicas stay bit-identical without any exchange);
-  * the force stage — >90 % of the step — is sharded: rank r traverses only the Morton slab
-    [r*slab, (r+1)*slab) of the sorted bodies (a contiguous spatial domain);
-  * ONE collective per step: all-gather of the per-rank acceleration slabs (float4 per body)
-    straight into the engine's acceleration buffer; every rank then integrates all bodies.
+  RcclComm    the library's own RCCL transport on the rank's stream (ncclCommInitRank; the unique id is broadcast
+              through torch.distributed) — what bench.py uses under torchrun;
+  TorchComm   callbacks into torch.distributed (gloo rehearsals on one GPU, CPU protocol tests);
+  LocalComm   P ranks as threads of one process sharing a device (bh_hub: device copies) — tests, tools.
 
-P-rank results are therefore bit-identical to 1-rank results.  The replicated build is the
-Amdahl term; DESIGN.md ("what comes next") describes the domain-decomposed build + top-tree /
-LET all-gather that replaces it.
+ShardedStepper is the round-1 scheme kept for A/B and as the collective fall-back (BH_DIST_MODE=replicated): every
+rank holds all bodies and builds the same tree, the force stage is sharded by Morton slab [r*slab, (r+1)*slab), ONE
+all-gather of accelerations per step; bit-identical to one rank.
 """
+import ctypes as C
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -100,16 +103,81 @@ def make_gpu_stepper(pkg, n, params=None, device=None, group=None, **kw):
     return eng, ShardedStepper(eng, acc, n, group)
 
 
+def _round_up(v, a):
+    return (int(v) + a - 1) // a * a
+
+
 # ----------------------------------------------------------------------------------------------
-# Domain-decomposed stepping (include/bh.h bh_dd_*, csrc/bh_dd.hip)
+# Domain-decomposed stepping: bh_rank of include/bh.h (csrc/bh_group.hip) + a transport
 # ----------------------------------------------------------------------------------------------
-class TorchComm:
-    """the four per-step all-gathers over torch.distributed (backend "nccl" = RCCL over xGMI)"""
+def _lib():
+    import sys
+    return sys.modules[__name__.rsplit(".", 1)[0] + "._lib"]
+
+
+class _Comm:
+    """a filled struct bh_comm + whatever must outlive it"""
+    world = rank = 0
+
+    def bh_comm(self):
+        raise NotImplementedError
+
+    def attach(self, stepper):
+        pass
+
+
+class TensorComm(_Comm):
+    """caller-callback transport (the `callbacks` flavour of struct bh_comm): a subclass moves torch uint8 tensors in
+    all_gather(out, send) / all_to_all(out, send).  The rank's buffers are then torch tensors the stepper allocates
+    and registers here; a callback finds the tensor a pointer lies in."""
+
+    def __init__(self, world, rank):
+        L = _lib()
+        self.world, self.rank = world, rank
+        self.tensors = []
+        self.stream = None
+        self.error = None
+        self._ag = L.COMM_FN(lambda u, recv, send, nb, st: self._call(self.all_gather, recv, send, nb * world, nb))
+        self._a2a = L.COMM_FN(lambda u, recv, send, nb, st: self._call(self.all_to_all, recv, send, nb * world, nb * world))
+
+    def bh_comm(self):
+        L = _lib()
+        return L.BhComm(self.world, self.rank, None, self._ag, self._a2a, L.COMM_RELEASE_FN())
+
+    def attach(self, stepper):
+        self.tensors = [t for t in stepper._buffers if t is not None]
+        self.stream = stepper.stream
+
+    def _view(self, ptr, nbytes):
+        for t in self.tensors:
+            off = ptr - t.data_ptr()
+            if 0 <= off and off + nbytes <= t.numel():
+                return t[off:off + nbytes]
+        raise RuntimeError("exchange pointer outside the registered buffers")
+
+    def _call(self, fn, recv, send, recv_bytes, send_bytes):
+        import contextlib
+        try:
+            with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+                fn(self._view(recv, recv_bytes), self._view(send, send_bytes))
+            return 0
+        except BaseException as ex:  # noqa: BLE001 - must not propagate through the C frames: BH_ERR_COMM, then
+            self.error = ex          # DomainStepper.step re-raises it
+            return 1
+
+    def all_gather(self, out, send):
+        raise NotImplementedError
+
+    def all_to_all(self, out, send):
+        raise NotImplementedError
+
+
+class TorchComm(TensorComm):
+    """the exchanges through torch.distributed ("nccl" = RCCL, or gloo: one-GPU rehearsals, CPU protocol tests)"""
 
     def __init__(self, group=None):
+        super().__init__(dist.get_world_size(group), dist.get_rank(group))
         self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
         self.into_tensor = _into_tensor_ok(group)   # chosen once, from the backend
 
     def all_gather(self, out, send):
@@ -120,48 +188,69 @@ class TorchComm:
         dist.all_to_all_single(out.view(-1), send.view(-1), group=self.group)
 
 
+class RcclComm(_Comm):
+    """the library's RCCL transport (bh_comm_rccl_init_rank): collectives on the rank's own stream, no torch in the
+    step.  The 128-byte unique id comes from rank 0 through torch.distributed (any backend)."""
+
+    def __init__(self, device, group=None):
+        L = _lib()
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        uid = (C.c_char * 128)()
+        st = L.lib.bh_comm_rccl_unique_id(uid) if self.rank == 0 else 0
+        box = [bytes(uid) if st == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        if box[0] is None:
+            raise RuntimeError("RCCL is not available (bh_comm_rccl_unique_id failed on rank 0)")
+        self._c = L.BhComm()
+        st = L.lib.bh_comm_rccl_init_rank(C.byref(self._c), box[0], self.world, self.rank, int(device))
+        if st != 0:
+            raise RuntimeError(f"bh_comm_rccl_init_rank: {L.lib.bh_strerror(st).decode()}")
+
+    def bh_comm(self):
+        return self._c
+
+
 class LocalGroup:
-    """P ranks as P threads of one process on one device and ONE stream (tests, 1-GPU rehearsal):
-    the all-gather is P device copies; a barrier orders the ranks' enqueues on the shared stream."""
+    """P ranks as P threads of one process on one device (tests, 1-GPU rehearsal): a bh_hub"""
 
     def __init__(self, world):
         import threading
+        L = _lib()
         self.world = world
         self.barrier = threading.Barrier(world)
-        self.slots = [None] * world
+        self._h = C.c_void_p()
+        st = L.lib.bh_hub_create(C.byref(self._h), world)
+        if st != 0:
+            raise RuntimeError(f"bh_hub_create: {st}")
+
+    def abort(self):
+        _lib().lib.bh_hub_abort(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib().lib.bh_hub_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
-class LocalComm:
+class LocalComm(_Comm):
     def __init__(self, group, rank):
         self.g, self.rank, self.world = group, rank, group.world
 
-    def all_gather(self, out, send):
-        g = self.g
-        g.slots[self.rank] = send
-        g.barrier.wait()
-        n = send.numel()
-        o = out.view(-1)
-        for q in range(self.world):
-            o[q * n:(q + 1) * n].copy_(g.slots[q].view(-1))
-        g.barrier.wait()
-
-    def all_to_all(self, out, send):
-        g = self.g
-        g.slots[self.rank] = send
-        g.barrier.wait()
-        k = send.numel() // self.world
-        o = out.view(-1)
-        for q in range(self.world):
-            o[q * k:(q + 1) * k].copy_(g.slots[q].view(-1)[self.rank * k:(self.rank + 1) * k])
-        g.barrier.wait()
-
-
-def _round_up(v, a):
-    return (int(v) + a - 1) // a * a
+    def bh_comm(self):
+        L = _lib()
+        c = L.BhComm()
+        st = L.lib.bh_comm_hub(C.byref(c), self.g._h, self.rank)
+        if st != 0:
+            raise RuntimeError(f"bh_comm_hub: {st}")
+        return c
 
 
 def global_morton_order(pkg, ic, device, params=None, **kw):
-    """ids of the bodies in the Morton order of the global cube (one throw-away full-size engine:
+    """ids of the bodies in the key order of the global cube (one throw-away full-size engine:
     the same deterministic sort on every rank, so all ranks agree on the initial slabs)."""
     n = len(ic[0])
     with pkg.Engine(n, params=params, device=device, **kw) as e:
@@ -173,33 +262,32 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
 
 
 # One force pass per step when the caller does not choose (split=False): the LET export and X4 are exposed, but the
-# two-pass form — own pieces on a side stream while the LET travels, then the remote pass — costs 0.42 ms more GPU
-# time per rank-step at 8 x 1M (own 1.15-1.25 + remote 0.50 against 1.23 ms for the one pass: two drains, the top
-# levels walked twice, profiles/r04_dd/split_vs_one_pass.txt), more than the ~0.3 ms (0.125 ms of LET kernels + a
-# 33-MB all-to-all over xGMI) it can hide.  split=True remains for interconnects slow enough to turn that around.
+# two-pass form — own pieces on a side stream while the LET travels, then the remote pass — costs more GPU time than
+# it hides on xGMI (profiles/r04_dd/split_vs_one_pass.txt).  split=True remains for slower interconnects.
 SPLIT_DEFAULT = False
 
 # X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
-# (DomainStepper(..., let_mode=0) selects round 2's all-gather of the union; tools/dd_debug.py --let-mode 0 for A/B)
+# (let_mode=0: the all-gather of one union segment per rank; tools/dd_debug.py --let-mode 0 for A/B)
 LET_MODE_DEFAULT = 1
+
+BUFFER_NAMES = ("x1s", "x1r", "x2s", "x2r", "x3s", "x3r", "lets", "pool")
 
 
 class DomainLeft(RuntimeError):
-    """Raised by DomainStepper.step ON EVERY RANK after the same exchange (a rank-local failure announced through
-    the X4 header, or a LET beyond let_cap decided from all-gathered counts): the only exception a caller may
-    answer collectively, e.g. by switching every rank to another scheme.  Anything else is rank-local."""
+    """BH_ERR_DOMAIN_LEFT: raised by DomainStepper.step ON EVERY RANK after the same exchange (a rank-local failure
+    announced through the X4 header, or a LET beyond let_cap decided from all-gathered counts): the only exception a
+    caller may answer collectively, e.g. by switching every rank to another scheme.  Anything else is rank-local."""
 
 
 class DomainStepper:
-    """One rank of the domain-decomposed step: this rank owns the bodies of one Morton-key range,
-    builds only their octree, imports the other ranks' locally-essential records and traverses the
-    stitched tree for its own bodies.  Four all-gathers per step, no replicated stage."""
+    """One rank of the domain-decomposed step — a binding of bh_rank: the per-step protocol (exchange order, size
+    negotiation, retries, collective failure) runs inside the library (bh_rank_step, csrc/bh_group.hip)."""
 
     def __init__(self, pkg, ic, comm, device, stream=None, params=None, slack=1.3, mig_frac=0.5,
                  let_cap=None, order=None, split=None, let_mode=None, mig_log=False, **kw):
-        self.comm = comm
+        L = _lib()
+        self.pkg, self.comm = pkg, comm
         self.split = SPLIT_DEFAULT if split is None else bool(split)
-        # X4: 0 = all-gather of the union segment (round 2), 1 = per-destination segments, all-to-all
         self.let_mode = LET_MODE_DEFAULT if let_mode is None else int(let_mode)
         self.world, self.rank = comm.world, comm.rank
         P, r = self.world, self.rank
@@ -208,243 +296,217 @@ class DomainStepper:
         if order is None:
             order = global_morton_order(pkg, ic, device, params=params, **kw)
         cuts = [q * n // P for q in range(P + 1)]
-        counts = [cuts[q + 1] - cuts[q] for q in range(P)]
         mine = order[cuts[r]:cuts[r + 1]]
         x, y, z, vx, vy, vz, m = [a[mine] for a in ic]
-
-        self.n_cap = max(1024, int(max(counts) * slack) + 4096)
-        # X2 buffers hold up to mig_cap emigrants per rank; a step normally sends far fewer
-        # (mig_stride follows the observed count), a larger wave goes in several rounds
-        self.mig_cap = min(max(4096, int(self.n_cap * mig_frac)), 4 * self.n_cap // P)
-        self.mig_stride = min(self.mig_cap, 4096)
-        self.mig_rounds = 0
-        self.mig_last = 0
-        self.mig_log = [] if mig_log else None   # per step (emigrants, boundaries): synchronises — tests and tools only
-        e_cls = pkg.Engine
-        lmin = 4 + 512  # header + needs row + piece slots (BH_DD_PIECE_CAP, csrc/bh_dd.hip kSegBlocks0)
-        self.let_cap = int(let_cap) if let_cap else lmin + self.n_cap
-        self.let_cap += self.let_cap & 1                        # segments hold whole 64-byte digest pairs
-        sz = e_cls.dd_query(self.n_cap, P, self.mig_cap, self.let_cap)
-        self.sz = sz
+        o = L.BhRankOpts()
+        L.lib.bh_rank_default_opts(C.byref(o))
+        if slack != 1.3 or mig_frac != 0.5:   # (the library's defaults are these)
+            fair = max(cuts[q + 1] - cuts[q] for q in range(P))
+            o.n_cap = max(1024, int(fair * slack) + 4096)
+            o.mig_cap = min(max(4096, int(o.n_cap * mig_frac)), 4 * o.n_cap // P)
+        if let_cap:
+            o.let_cap = int(let_cap)
+        o.let_mode, o.split, o.log = self.let_mode, int(self.split), int(bool(mig_log))
+        self.params = params if params is not None else pkg.default_params(**kw)
+        plan = L.BhRankPlan()
+        st = L.lib.bh_rank_query(n, P, C.byref(o), C.byref(plan))
+        if st != 0:
+            raise pkg.BhError(st, "bh_rank_query")
         self.stream = stream if stream is not None else torch.cuda.Stream(device)
-        dev = f"cuda:{device}"
-        with torch.cuda.stream(self.stream):
-            u8 = dict(dtype=torch.uint8, device=dev)
-            self.x1s = torch.zeros(sz.x1_bytes, **u8)
-            self.x1r = torch.zeros(P * sz.x1_bytes, **u8)
-            self.x2s = torch.zeros(sz.x2_bytes, **u8)
-            self.x2r = torch.zeros(P * sz.x2_bytes, **u8)
-            self.x3s = torch.zeros(sz.x3_bytes, **u8)
-            self.x3r = torch.zeros(P * sz.x3_bytes, **u8)
-            self.lets = torch.zeros((P if self.let_mode == 1 else 1) * self.let_cap * 32, **u8)
-            self.pool = torch.zeros(sz.pool_records * 32, **u8)
-        self.stream.synchronize()
-        assert sz.let_min == lmin, (sz.let_min, lmin)
-        self.e = e_cls(self.n_cap, params=params, device=device, stream=self.stream.cuda_stream, **kw)
-        self.e.dd_init(P, r, n, self.mig_cap, self.let_cap, self.pool.data_ptr(), sz.pool_records)
-        self.e.dd_set_let_mode(self.let_mode)
-        self.e.dd_upload(x, y, z, vx, vy, vz, m, mine.astype("int32"))
-        self.stride = min(self.let_cap, _round_up(lmin + self.n_cap // 8, 256))
-        self.let_counts = None
-        self.let_retries = 0
-        self.n_loc = len(mine)
+        bufs = None
+        self._buffers = []
+        if isinstance(comm, TensorComm):   # the transport moves torch tensors: the buffers are ours
+            with torch.cuda.stream(self.stream):
+                self._buffers = [torch.zeros(int(plan.bytes[k]), dtype=torch.uint8, device=f"cuda:{device}")
+                                 for k in range(8)]
+            self.stream.synchronize()
+            bufs = L.BhRankBuffers(*[t.data_ptr() for t in self._buffers])
+        self._c = comm.bh_comm()
+        self._h = C.c_void_p()
+        st = L.lib.bh_rank_create(C.byref(self._h), C.byref(self._c), n, C.byref(self.params), C.byref(o), int(device),
+                                  C.c_void_p(self.stream.cuda_stream), C.byref(bufs) if bufs is not None else None)
+        if st != 0:
+            self._h = C.c_void_p()
+            raise pkg.BhError(st, "bh_rank_create")
+        self._finish(plan, mig_log)
+        comm.attach(self)
+        ids = np.ascontiguousarray(mine, dtype=np.int32)
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, z, vx, vy, vz, m)]
+        st = L.lib.bh_rank_upload(self._h, len(ids), *[a.ctypes.data_as(L._F) for a in arrs],
+                                  ids.ctypes.data_as(C.POINTER(C.c_int32)))
+        if st != 0:
+            raise pkg.BhError(st, "bh_rank_upload")
+        self.e.n = len(ids)
+
+    def _finish(self, plan, mig_log):
+        L = _lib()
+        self.plan, self.sz = plan, plan.sz
+        self.n_cap, self.mig_cap, self.let_cap = plan.n_cap, plan.mig_cap, plan.let_cap
+        self._log = bool(mig_log)
+        h = L.lib.bh_rank_ctx(self._h)
+        self.e = self.pkg.Engine.adopt(h, plan.n_cap, getattr(self, "params", None)) if h else None
+        self._sync_info()
 
     @classmethod
     def with_engine(cls, engine, sz, comm, n_cap, mig_cap, let_cap, tensor_device="cpu", split=True, let_mode=0):
-        """The per-step protocol (exchanges, size negotiation, failure handling) around ANY object with
-        the dd_* methods of Engine — tests/dd_cpu_worker.py drives it on CPU tensors over gloo."""
+        """The library's per-step protocol (bh_rank_create_scripted) around ANY object with the dd_* methods of
+        Engine, on host buffers — tests/dd_cpu_worker.py drives it on CPU tensors over gloo."""
+        import bhpkg
+        L = _lib()
         self = cls.__new__(cls)
-        self.comm, self.split = comm, bool(split)
-        self.let_mode = int(let_mode)
+        self.pkg = bhpkg.load()
+        self.comm, self.split, self.let_mode = comm, bool(split), int(let_mode)
         self.world, self.rank = comm.world, comm.rank
-        self.e, self.sz, self.stream = engine, sz, None
-        self.n_cap, self.mig_cap, self.let_cap = int(n_cap), int(mig_cap), int(let_cap)
-        self.mig_stride = min(self.mig_cap, 4096)
-        self.mig_rounds = self.mig_last = self.let_retries = self.n_loc = 0
-        self.mig_log = None
-        self.let_counts = None
+        self.stream = None
         P = self.world
-        u8 = dict(dtype=torch.uint8, device=tensor_device)
-        self.x1s = torch.zeros(sz.x1_bytes, **u8)
-        self.x1r = torch.zeros(P * sz.x1_bytes, **u8)
-        self.x2s = torch.zeros(sz.x2_bytes, **u8)
-        self.x2r = torch.zeros(P * sz.x2_bytes, **u8)
-        self.x3s = torch.zeros(sz.x3_bytes, **u8)
-        self.x3r = torch.zeros(P * sz.x3_bytes, **u8)
-        self.lets = torch.zeros((P if self.let_mode == 1 else 1) * self.let_cap * 32, **u8)
-        self.pool = torch.zeros(sz.pool_records * 32, **u8)
-        self.stride = min(self.let_cap, _round_up(sz.let_min + self.n_cap // 8, 256))
+        plan = L.BhRankPlan()
+        plan.n_cap, plan.mig_cap, plan.let_cap = int(n_cap), int(mig_cap), int(let_cap)
+        plan.stride0 = min(int(let_cap), _round_up(sz.let_min + int(n_cap) // 8, 256))
+        for k in ("x1_bytes", "x2_bytes", "x3_bytes", "pool_records", "seg_base", "let_min", "let_cap", "top_base"):
+            setattr(plan.sz, k, int(getattr(sz, k)))
+        nseg = P if self.let_mode == 1 else 1
+        for k, b in enumerate((sz.x1_bytes, P * sz.x1_bytes, sz.x2_bytes, P * sz.x2_bytes, sz.x3_bytes,
+                               P * sz.x3_bytes, nseg * int(let_cap) * 32, sz.pool_records * 32)):
+            plan.bytes[k] = int(b)
+        o = L.BhRankOpts()
+        L.lib.bh_rank_default_opts(C.byref(o))
+        o.let_mode, o.split = self.let_mode, int(self.split)
+        self._script_error = None
+
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except BaseException as ex:  # noqa: BLE001 - reported as a status, re-raised by step()
+                    self._script_error = ex
+                    return -5
+            return run
+
+        def phase_migrate(u, x1r, x2s, limit):
+            engine.dd_cube_apply(x1r)
+            engine.dd_migrate_pack(x2s, limit)
+
+        def phase_tree(u, x2r, limit, x3s, n_loc, more, most):
+            a, b, c = engine.dd_migrate_apply(x2r, limit)
+            n_loc[0], more[0], most[0] = int(a), int(bool(b)), int(c)
+            if not b:
+                engine.dd_tree(x3s)
+
+        def phase_let(u, x3r, x4s, stride, own):
+            if own:
+                engine.dd_force_local(x3r)
+            engine.dd_let_pack(x3r, x4s, stride)
+
+        def phase_force(u, x3r, stride, counts, fits):
+            engine.dd_top(x3r, stride)
+            ok, cnt = engine.dd_let_check(stride, P)
+            for q in range(P):
+                counts[q] = int(cnt[q])
+            fits[0] = int(bool(ok))
+            if ok and int(min(cnt)) >= 0:
+                engine.dd_force()
+
+        def phase_end(u, x1s):
+            engine.integrate()
+            engine.dd_cube_pack(x1s)
+
+        fns = dict(cube_pack=lambda u, p: engine.dd_cube_pack(p), phase_migrate=phase_migrate,
+                   migrate_pack=lambda u, p, limit: engine.dd_migrate_pack(p, limit), phase_tree=phase_tree,
+                   phase_let=phase_let, phase_force=phase_force, phase_end=phase_end)
+        self._script = L.BhRankScript()
+        self._script_keep = []
+        for name, ftype in L.SCRIPT_FNS:
+            cb = ftype(guard(fns[name]))
+            self._script_keep.append(cb)
+            setattr(self._script, name, cb)
+        self._c = comm.bh_comm()
+        self._h = C.c_void_p()
+        st = L.lib.bh_rank_create_scripted(C.byref(self._h), C.byref(self._c), C.byref(self._script), C.byref(plan),
+                                           C.byref(o))
+        if st != 0:
+            raise self.pkg.BhError(st, "bh_rank_create_scripted")
+        b = L.BhRankBuffers()
+        L.lib.bh_rank_buffers_of(self._h, C.byref(b), None)
+        self._buffers = [torch.frombuffer((C.c_char * int(plan.bytes[k])).from_address(getattr(b, f)), dtype=torch.uint8)
+                         for k, f in enumerate(("x1s", "x1r", "x2s", "x2r", "x3s", "x3r", "x4s", "pool"))]
+        self.e = engine
+        self.plan, self.sz = plan, sz
+        self.n_cap, self.mig_cap, self.let_cap = int(n_cap), int(mig_cap), int(let_cap)
+        self._log = False
+        self._sync_info()
+        comm.attach(self)
         return self
 
-    # ---- optional per-phase device timing (events on the main stream; bench.py reports the means) ----
+    def __getattr__(self, name):   # x1s ... pool: the exchange buffers as tensors (scripted ranks, TorchComm)
+        if name in BUFFER_NAMES and self.__dict__.get("_buffers"):
+            return self._buffers[BUFFER_NAMES.index(name)]
+        raise AttributeError(name)
+
+    def _sync_info(self):
+        L = _lib()
+        i = L.BhRankInfo()
+        L.lib.bh_rank_get_info(self._h, C.byref(i))
+        self.n_loc, self.stride, self.mig_stride, self.mig_last = i.n_loc, i.stride, i.mig_stride, i.mig_last
+        self.mig_rounds, self.let_retries = i.mig_rounds, i.let_retries
+        self.let_counts = np.array(i.let_counts[:self.world], np.int32) if i.steps or i.let_retries else None
+        self._info = i
+        if getattr(self, "e", None) is not None and hasattr(self.e, "_h") and i.n_loc:
+            self.e.n = i.n_loc
+
+    # ---- optional per-phase device timing (events on the rank's stream; bench.py reports the means) ----
     PHASES = ("x1_exchange", "cube_splitters_x2_migration_local_tree", "x3_exchange", "let_export_x4",
               "top_remote_force", "integrate_pack_x1")
 
     def set_profile(self, on=True):
-        self._prof = [] if on and self.stream is not None else None
-
-    def _mark(self, k):
-        if getattr(self, "_prof", None) is None:
-            return
-        if k == 0:
-            self._cur = [None] * 7
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(self.stream)
-        self._cur[k] = ev          # a repeated phase (LET retry) keeps its last mark
-
-    def _close_marks(self):
-        if getattr(self, "_prof", None) is not None:
-            self._prof.append(self._cur)
+        _lib().lib.bh_rank_set_profile(self._h, 1 if on else 0)
+        self._profiled = bool(on)
 
     def phase_ms(self):
-        """mean device time per phase over the profiled steps (the own force pass overlaps the LET phase
-        on its own stream and is waited for inside 'top_remote_force')"""
-        if not getattr(self, "_prof", None):
+        """mean device time per phase over the profiled steps"""
+        if not getattr(self, "_profiled", False):
             return None
-        torch.cuda.synchronize()
-        acc = [0.0] * 6
-        for evs in self._prof:
-            for k in range(6):
-                acc[k] += evs[k].elapsed_time(evs[k + 1])
-        return {name: acc[k] / len(self._prof) for k, name in enumerate(self.PHASES)}
+        ms = (C.c_double * 6)()
+        cnt = C.c_int(0)
+        _lib().lib.bh_rank_phase_ms(self._h, ms, C.byref(cnt))
+        if cnt.value == 0:
+            return None
+        return {name: float(ms[k]) for k, name in enumerate(self.PHASES)}
 
-    def _on_stream(self):
-        import contextlib
-        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
-
-    # ---- phase groups: one C call each (bh_dd_phase_*) when the engine has them; the scripted stand-in of
-    # tests/dd_cpu_worker.py only has the fine-grained calls, which these fall back to
-    def _phase_migrate(self, limit):
-        e = self.e
-        if hasattr(e, "dd_phase_migrate"):
-            e.dd_phase_migrate(self.x1r.data_ptr(), self.x2s.data_ptr(), limit)
-        else:
-            e.dd_cube_apply(self.x1r.data_ptr())
-            e.dd_migrate_pack(self.x2s.data_ptr(), limit)
-
-    def _phase_tree(self, limit):
-        e = self.e
-        if hasattr(e, "dd_phase_tree"):
-            return e.dd_phase_tree(self.x2r.data_ptr(), limit, self.x3s.data_ptr())
-        n_loc, more, most = e.dd_migrate_apply(self.x2r.data_ptr(), limit)
-        if not more:
-            e.dd_tree(self.x3s.data_ptr())
-        return n_loc, more, most
-
-    def _phase_let(self, stride, own_pass):
-        e = self.e
-        if hasattr(e, "dd_phase_let"):
-            e.dd_phase_let(self.x3r.data_ptr(), self.lets.data_ptr(), stride, own_pass)
-        else:
-            if own_pass:
-                e.dd_force_local(self.x3r.data_ptr())
-            e.dd_let_pack(self.x3r.data_ptr(), self.lets.data_ptr(), stride)
-
-    def _phase_force(self, stride):
-        e = self.e
-        if hasattr(e, "dd_phase_force"):
-            return e.dd_phase_force(self.x3r.data_ptr(), stride, self.world)
-        e.dd_top(self.x3r.data_ptr(), stride)
-        e.dd_force()
-        return e.dd_let_check(stride, self.world)
-
-    def _phase_end(self):
-        e = self.e
-        if hasattr(e, "dd_phase_end"):
-            e.dd_phase_end(self.x1s.data_ptr())
-        else:
-            e.integrate()
-            e.dd_cube_pack(self.x1s.data_ptr())
-        self._x1_ready = True   # the next step's X1 payload is packed
+    @property
+    def mig_log(self):
+        """per step (most emigrants on any rank, what the step did with the boundaries) — mig_log=True only"""
+        if not self._log:
+            return None
+        L = _lib()
+        n = C.c_int(0)
+        L.lib.bh_rank_read_log(self._h, None, 0, C.byref(n))
+        buf = np.zeros((max(n.value, 1), 2), np.int32)
+        L.lib.bh_rank_read_log(self._h, buf.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n))
+        return [(int(a), int(b)) for a, b in buf[:n.value]]
 
     def step(self, steps=1):
-        """Five library calls and four all-gathers per step in the common case:
-             [X1] phase_migrate [X2] phase_tree [X3] phase_let [X4] phase_force, phase_end
-           (extra migration rounds, a LET retry and the collective handling of a rank-local failure use the
-           fine-grained entry points)."""
-        e, c, sz, P = self.e, self.comm, self.sz, self.world
-        with self._on_stream():
-            for _ in range(int(steps)):
-                self._mark(0)
-                if not getattr(self, "_x1_ready", False):
-                    e.dd_cube_pack(self.x1s.data_ptr())                # X1: cube + splitters (first step only:
-                self._x1_ready = False                                 # afterwards the previous step packed it)
-                c.all_gather(self.x1r, self.x1s)
-                self._mark(1)
-                limit, first = self.mig_stride, None                   # X2: bodies that changed owner
-                self.mig_stride_used = limit                           # (slots per rank of this step's first round)
-                failed = None   # a rank-local failure must not strand the others inside a collective: the
-                rounds = 0      # failing rank keeps taking part with empty payloads and marks its LET segment
-                while True:
-                    nb = 32 + 32 * limit
-                    if failed is not None:
-                        self.x2s[:32].zero_()
-                    elif rounds == 0:
-                        self._phase_migrate(limit)                     # global cube + splitters, emigrants packed
-                    else:
-                        e.dd_migrate_pack(self.x2s.data_ptr(), limit)
-                    rounds += 1
-                    c.all_gather(self.x2r[:P * nb], self.x2s[:nb])
-                    if failed is None:
-                        try:   # immigrants absorbed; once no rank has emigrants left: local sort / build / COM,
-                            self.n_loc, more, most = self._phase_tree(limit)   # X3 piece descriptors packed
-                        except Exception as ex:  # noqa: BLE001 - e.g. more bodies than this context can hold
-                            failed = ex
-                    if failed is not None:
-                        h = self.x2r[:P * nb].view(P, nb)[:, :16].contiguous().view(torch.int32).cpu().view(P, 4)
-                        more, most = bool(((h[:, 0] - h[:, 2]) > 0).any()), int(h[:, 0].max())
-                    first = most if first is None else first
-                    if not more:
-                        break
-                    self.mig_rounds += 1                                # rare: a splitter changed octant
-                    limit = min(self.mig_cap, max(limit, _round_up(most, 256)))
-                self.mig_last = first
-                if self.mig_log is not None and hasattr(e, "dd_info"):   # tests / tools: (emigrants, boundaries) per step
-                    self.mig_log.append((first, e.dd_info()[3]))
-                # next step's slots: one and a half times what this step moved (boundaries that persist move a fraction of a per
-                # cent of a rank per step; a rebalance or a collapse moves more and goes in several rounds)
-                self.mig_stride = max(1024, min(self.mig_cap, _round_up(first * 1.5 + 512, 256)))
-                self._mark(2)
-                if failed is not None:
-                    self.x3s.zero_()
-                c.all_gather(self.x3r, self.x3s)
-                self._mark(3)
-                tries = 0
-                while True:
-                    stride = self.stride
-                    seg = self.pool[sz.seg_base * 32:(sz.seg_base + P * stride) * 32]
-                    nseg = P if self.let_mode == 1 else 1               # segments this rank sends
-                    send = self.lets[:nseg * stride * 32]
-                    x4 = c.all_to_all if self.let_mode == 1 else c.all_gather
-                    if failed is not None:
-                        send.zero_()
-                        # header count < 0: "this rank failed" (record 0 of a digest pair: field `first` is dword 10,
-                        # csrc/bh_internal.h) — in every segment it sends
-                        send.view(nseg, stride * 32)[:, :64].view(torch.int32)[:, 10] = -1
-                        x4(seg, send)
-                        raise DomainLeft(f"rank {self.rank} left the domain-decomposed step: {failed!r}")
-                    # own pieces on the side stream (first try only: it overlaps X4), LET marked / exported
-                    self._phase_let(stride, self.split and tries == 0)
-                    tries += 1
-                    x4(seg, send)                                       # X4: LET records, in place
-                    self._mark(4)
-                    ok, counts = self._phase_force(stride)              # top tree, remote (or whole) pass, X4 sizes
-                    self.let_counts = counts
-                    if int(counts.min()) < 0:
-                        raise DomainLeft(f"rank {int(counts.argmin())} left the domain-decomposed step")
-                    need = int(counts.max())
-                    if ok:
-                        break
-                    if need > self.let_cap:
-                        raise DomainLeft(f"LET of {need} records exceeds let_cap {self.let_cap}")
-                    self.let_retries += 1
-                    self.stride = min(self.let_cap, _round_up(need * 1.25, 256))
-                # every rank sees the same counts, so every rank picks the same next stride
-                self.stride = max(sz.let_min, min(self.let_cap, _round_up(need * 1.15 + 1024, 256)))
-                self._mark(5)
-                self._phase_end()                                       # integrate + the next step's X1 payload
-                self._mark(6)
-                self._close_marks()
+        """bh_rank_step: `steps` steps of  [X1] phase_migrate [X2] phase_tree [X3] phase_let [X4] phase_force,
+        phase_end  (collective: every rank calls it with the same count)"""
+        L = _lib()
+        st = L.lib.bh_rank_step(self._h, int(steps))
+        self._sync_info()
+        if st == 0:
+            return
+        i = self._info
+        if st == L.BH_ERR_DOMAIN_LEFT:
+            if i.left_rank == self.rank:
+                why = getattr(self, "_script_error", None)
+                why = repr(why) if why is not None else self.pkg.lib.bh_strerror(i.left_status).decode()
+                raise DomainLeft(f"rank {self.rank} left the domain-decomposed step: {why}")
+            if i.left_rank >= 0:
+                raise DomainLeft(f"rank {i.left_rank} left the domain-decomposed step")
+            raise DomainLeft(f"LET of {int(max(i.let_counts[:self.world]))} records exceeds let_cap {self.let_cap}; "
+                             "every rank left the domain-decomposed step")
+        err = getattr(self.comm, "error", None) or getattr(self, "_script_error", None)
+        if err is not None:
+            raise err
+        raise self.pkg.BhError(st, "bh_rank_step")
 
     def local_state(self):
         """(ids, posm[n,4], vel[n,3], acc[n,3]) of this rank's bodies"""
@@ -452,4 +514,14 @@ class DomainStepper:
         return ids, posm, vel, acc
 
     def close(self):
-        self.e.close()
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib().lib.bh_rank_destroy(self._h)
+            self._h = None
+            if hasattr(self.e, "_h"):
+                self.e._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -86,10 +86,21 @@ class Engine:
             self._h = C.c_void_p()
             raise BhError(st, "bh_create")
 
+    @classmethod
+    def adopt(cls, handle, n, params=None):
+        """an Engine view of a context somebody else owns (the context of a bh_rank): close() does not destroy it"""
+        self = cls.__new__(cls)
+        self.n = int(n)
+        self.params = params if params is not None else default_params()
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        return self
+
     # -- lifecycle
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            lib.bh_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                lib.bh_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

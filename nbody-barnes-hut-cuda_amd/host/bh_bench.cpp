@@ -10,6 +10,12 @@
 //            [--literal-force]   the root-monopole force the CUDA binary literally computes
 //            [--dump FILE]       final state in the older generation's text format (output_bh.txt:1-4)
 //            [--snapshot FILE]   lossless binary snapshot for restart
+//            [--gpus G]          the whole node: G ranks, one per GPU, domain-decomposed step over RCCL
+//                                (bh_create_group / bh_step_group; --n stays the TOTAL body count)
+//            [--dist]            with --gpus 1: the multi-GPU step at world size 1 (RCCL path on one GPU)
+//            [--devices a,b,..]  explicit device per rank; a device listed twice selects the in-process
+//                                transport (one-GPU rehearsal of G ranks)
+//            [--split]           two force passes per step (own pieces beside X4, then the remote pass)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -32,8 +38,70 @@ static double now_ms() {
     }                                                                    \
   } while (0)
 
+// the frame loop of main() (ref:353-367) over bh_step_group: every rank steps, then the whole node is synchronised
+static int run_group(int N, int frames, int warmup, bool quiet, const bh_params& p, const std::vector<int>& devs,
+                     bool split, const char* ic_name, std::vector<float>* a, const char* dump_path, const char* snap_path) {
+  bh_rank_opts o;
+  bh_rank_default_opts(&o);
+  o.split = split ? 1 : 0;
+  bh_group* g = nullptr;
+  CK(bh_create_group(&g, (int)devs.size(), devs.data(), N, &p, &o, 0));
+  CK(bh_group_upload(g, a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data(), a[6].data()));
+  CK(bh_step_group(g, warmup));
+  CK(bh_group_sync(g));
+  printf("------------------------------------------\n");
+  printf("\n%-10s | %-15s | %-10s\n", "Frame", "Trajanje (ms)", "FPS");  // ref:351
+  double sum = 0.0;
+  for (int frame = 0; frame < frames; frame++) {
+    const double t0 = now_ms();
+    CK(bh_step_group(g, 1));
+    CK(bh_group_sync(g));  // bh_sync of every rank: BH_ERR_DEVICE_FLAG if a sticky device flag is set anywhere
+    const double ms = now_ms() - t0;
+    sum += ms;
+    if (!quiet) printf("%-10d | %-15.3f | %-10.1f\n", frame, ms, 1000.0 / ms);  // ref:366
+  }
+  // the same frames without a host synchronisation per frame (what a caller that only needs the final state pays)
+  const double t0 = now_ms();
+  CK(bh_step_group(g, frames));
+  CK(bh_group_sync(g));
+  const double free_run = (now_ms() - t0) / (frames > 0 ? frames : 1);
+  const double avg = sum / (frames > 0 ? frames : 1);
+  double ph[BH_RANK_PHASES];
+  int ph_steps = 0;
+  CK(bh_rank_set_profile(bh_group_rank(g, 0), 1));
+  CK(bh_step_group(g, 5));
+  CK(bh_rank_phase_ms(bh_group_rank(g, 0), ph, &ph_steps));
+  CK(bh_rank_set_profile(bh_group_rank(g, 0), 0));
+  bh_rank_info info;
+  CK(bh_rank_get_info(bh_group_rank(g, 0), &info));
+  printf("------------------------------------------\n");
+  printf("N=%d gpus=%d ic=%s theta=%.2f steps=%d avg %.3f ms/step  %.3e particles/s/step | %d steps without a sync per "
+         "frame: %.3f ms/step  %.3e particles/s/step\n",
+         N, (int)devs.size(), ic_name, p.theta, frames, avg, (double)N / (avg * 1e-3), frames, free_run,
+         (double)N / (free_run * 1e-3));
+  printf("rank 0, mean of %d steps (ms): x1 %.3f | cube+migration+local tree %.3f | x3 %.3f | LET export + x4 %.3f | "
+         "top tree + force %.3f | integrate + next x1 %.3f || bodies %d LET stride %d emigrants %d extra migration "
+         "rounds %d LET retries %d\n",
+         ph_steps, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], info.n_loc, info.stride, info.mig_last, info.mig_rounds,
+         info.let_retries);
+  if (dump_path || snap_path) {
+    CK(bh_group_download(g, a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data()));
+    if (dump_path)
+      CK(bh_write_text(dump_path, N, warmup + 2 * frames + 5, p.theta, p.dt, a[0].data(), a[1].data(), a[2].data(),
+                       a[3].data(), a[4].data(), a[5].data()));
+    if (snap_path)
+      CK(bh_write_snapshot(snap_path, N, warmup + 2 * frames + 5, &p, a[0].data(), a[1].data(), a[2].data(),
+                           a[3].data(), a[4].data(), a[5].data(), a[6].data()));
+  }
+  bh_destroy_group(g);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   int N = 500000;  // ref:31
+  int gpus = 0;
+  bool dist = false, split = false;
+  std::vector<int> devs;
   int frames = 1000;  // ref:353
   int warmup = 0;
   int device = 0;
@@ -57,6 +125,12 @@ int main(int argc, char** argv) {
       plummer = !strcmp(argv[i], "plummer");
       msvc = !strcmp(argv[i], "msvc");
     }
+    else if (arg("--gpus")) gpus = atoi(argv[++i]);
+    else if (arg("--devices")) {
+      for (char* t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) devs.push_back(atoi(t));
+    }
+    else if (!strcmp(argv[i], "--dist")) dist = true;
+    else if (!strcmp(argv[i], "--split")) split = true;
     else if (arg("--dump")) dump_path = argv[++i];
     else if (arg("--snapshot")) snap_path = argv[++i];
     else if (!strcmp(argv[i], "--literal-force")) p.literal_force = 1;  // what the CUDA binary computes (D1)
@@ -76,6 +150,14 @@ int main(int argc, char** argv) {
     CK(bh_ic_disc_msvc(N, (uint32_t)seed, p.G, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
   else
     CK(bh_ic_disc(N, seed, p.G, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data()));
+
+  if (!devs.empty() || gpus > 1 || dist) {
+    if (devs.empty())
+      for (int q = 0; q < (gpus > 0 ? gpus : 1); q++) devs.push_back(device + q);
+    std::vector<float> a[7] = {x, y, z, vx, vy, vz, m};
+    return run_group(N, frames, warmup, quiet, p, devs, split,
+                     plummer ? "plummer" : (msvc ? "disc(msvc rand)" : "disc"), a, dump_path, snap_path);
+  }
 
   bh_ctx* c = nullptr;
   CK(bh_create(&c, N, &p, device));

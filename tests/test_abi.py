@@ -30,7 +30,65 @@ def test_header_symbols_all_exported(pkg):
 def test_struct_layouts(pkg):
     assert C.sizeof(pkg.BhNode) == 32
     assert C.sizeof(pkg.BhParams) == 5 * 4 + 4 * 4 + 9 * 4
-    assert pkg.lib.bh_abi_version() == 4
+    assert pkg.lib.bh_abi_version() == 5
+
+
+def test_struct_layouts_match_the_c_compiler(pkg, tmp_path):
+    """every struct the ctypes binding mirrors has the size (and, for bh_comm / bh_rank_plan, the field offsets) a C
+    compiler gives include/bh.h"""
+    import subprocess
+    L = __import__("nbody_barnes_hut_cuda_amd")._lib
+    names = {"bh_params": L.BhParams, "bh_node": L.BhNode, "bh_stats": L.BhStats, "bh_walk_stats": L.BhWalkStats,
+             "bh_dd_sizes": L.BhDdSizes, "bh_comm": L.BhComm, "bh_rank_opts": L.BhRankOpts,
+             "bh_rank_plan": L.BhRankPlan, "bh_rank_buffers": L.BhRankBuffers, "bh_rank_info": L.BhRankInfo,
+             "bh_rank_script": L.BhRankScript}
+    src = tmp_path / "sz.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "bh.h"', "int main(void) {"]
+    for n in names:
+        lines.append(f'  printf("{n} %zu\\n", sizeof({n}));')
+    for st, f in (("bh_comm", "all_to_all"), ("bh_comm", "release"), ("bh_rank_plan", "sz"), ("bh_rank_plan", "bytes"),
+                  ("bh_rank_info", "steps"), ("bh_rank_info", "let_counts"), ("bh_rank_script", "phase_end")):
+        lines.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    lines.append("  return 0; }")
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n, cls in names.items():
+        assert int(out[n]) == C.sizeof(cls), (n, out[n], C.sizeof(cls))
+    assert int(out["bh_comm.all_to_all"]) == L.BhComm.all_to_all.offset
+    assert int(out["bh_comm.release"]) == L.BhComm.release.offset
+    assert int(out["bh_rank_plan.sz"]) == L.BhRankPlan.sz.offset
+    assert int(out["bh_rank_plan.bytes"]) == L.BhRankPlan.bytes.offset
+    assert int(out["bh_rank_info.steps"]) == L.BhRankInfo.steps.offset
+    assert int(out["bh_rank_info.let_counts"]) == L.BhRankInfo.let_counts.offset
+    assert int(out["bh_rank_script.phase_end"]) == L.BhRankScript.phase_end.offset
+
+
+def test_rank_plan_defaults(pkg):
+    """bh_rank_query: the capacities a rank gets when the caller names none (8 x 1M: BASELINE configs[3])"""
+    L = __import__("nbody_barnes_hut_cuda_amd")._lib
+    pl = L.BhRankPlan()
+    assert L.lib.bh_rank_query(8_000_000, 8, None, C.byref(pl)) == 0
+    assert (pl.n_cap, pl.mig_cap, pl.let_cap, pl.stride0) == (1304096, 652048, 1304612, 163584)
+    assert pl.sz.let_min == 516 and pl.bytes[7] == pl.sz.pool_records * 32 and pl.bytes[6] == 8 * pl.let_cap * 32
+    assert L.lib.bh_rank_query(8_000_000, 14, None, C.byref(pl)) == -1     # more ranks than the top tree holds pieces for
+    o = L.BhRankOpts()
+    L.lib.bh_rank_default_opts(C.byref(o))
+    assert (o.let_mode, o.split, o.n_cap) == (1, 0, 0)
+    o.let_mode = 0
+    assert L.lib.bh_rank_query(1000, 2, C.byref(o), C.byref(pl)) == 0 and pl.bytes[6] == pl.let_cap * 32
+
+
+def test_group_layer_fails_loudly_without_a_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    L = __import__("nbody_barnes_hut_cuda_amd")._lib
+    g = C.c_void_p()
+    dev = (C.c_int * 2)(0, 0)
+    assert L.lib.bh_create_group(C.byref(g), 2, dev, 100000, None, None, 0) == -2      # BH_ERR_NO_DEVICE
+    assert L.lib.bh_step_group(None, 1) == -1
 
 
 def test_default_params_are_reference_constants(pkg):
@@ -43,7 +101,7 @@ def test_default_params_are_reference_constants(pkg):
 
 def test_strerror(pkg):
     assert pkg.lib.bh_strerror(0) == b"ok"
-    for s in range(-8, 0):
+    for s in range(-10, 0):
         assert pkg.lib.bh_strerror(s) not in (b"ok", b"unknown status")
     assert pkg.lib.bh_strerror(-99) == b"unknown status"
 

@@ -1,6 +1,6 @@
-"""Domain-decomposed multi-GPU stepping (bh_dd_* of include/bh.h, dist.DomainStepper) on ONE GPU:
-P ranks run as P threads of this process (dist.LocalComm: the all-gathers are device copies), each
-with its own context, owning one Morton-key range.  The stitched tree (local octree + top tree +
+"""Domain-decomposed multi-GPU stepping (bh_rank / bh_dd_* of include/bh.h, dist.DomainStepper) on ONE GPU:
+P ranks run as P threads of this process (dist.LocalComm = the library's in-process transport bh_hub: the
+exchanges are device copies), each with its own context, owning one interval of the key curve.  The stitched tree (local octree + top tree +
 imported LET segments) must reproduce the single-context run: same canonical octree, so forces
 agree up to summation order / the last bit of cell sums."""
 import threading
@@ -35,6 +35,7 @@ def run_ranks(world, ic, steps, **kw):
             st.close()
         except BaseException as ex:  # noqa: BLE001 - report from the main thread
             errs.append((r, ex))
+            group.abort()            # releases ranks waiting inside an exchange (BH_ERR_COMM)
             group.barrier.abort()
 
     th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
@@ -231,6 +232,87 @@ def test_dd_eight_ranks_vs_the_oracle_itself():
     assert np.median(e) <= 1e-6 and e.max() <= 1e-4
 
 
+def test_group_step_from_c_vs_oracle_and_python_binding():
+    """the multi-GPU step driven from C only (ctypes on bh_create_group / bh_group_upload / bh_step_group /
+    bh_group_download: no Python protocol code, one library thread per rank): 8 ranks on this GPU through the
+    in-process transport, 65,536 bodies, 5 steps — within test_dd_eight_ranks_vs_the_oracle_itself's bounds of the
+    ORACLE, and bit-identical to the DomainStepper-driven run (the same bh_rank_step under both)."""
+    import ctypes as C
+    import oracle as O
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import _lib as L
+    n, K, world = 65536, 5, 8
+    ic = pkg.plummer(n, seed=42)
+    g = C.c_void_p()
+    dev = (C.c_int * world)(*([0] * world))
+    assert L.lib.bh_create_group(C.byref(g), world, dev, n, None, None, 0) == 0
+    try:
+        F = L._F
+        assert L.lib.bh_group_size(g) == world
+        assert L.lib.bh_group_upload(g, *[np.ascontiguousarray(a).ctypes.data_as(F) for a in ic]) == 0
+        assert L.lib.bh_step_group(g, K) == 0
+        assert L.lib.bh_group_sync(g) == 0
+        st6 = [np.full(n, np.nan, np.float32) for _ in range(6)]
+        assert L.lib.bh_group_download(g, *[a.ctypes.data_as(F) for a in st6]) == 0
+        acc = [np.full(n, np.nan, np.float32) for _ in range(3)]
+        assert L.lib.bh_group_download_acc(g, *[a.ctypes.data_as(F) for a in acc]) == 0
+        info = L.BhRankInfo()
+        held = 0
+        for q in range(world):
+            assert L.lib.bh_rank_get_info(L.lib.bh_group_rank(g, q), C.byref(info)) == 0
+            assert info.steps == K
+            held += info.n_loc
+        assert held == n
+    finally:
+        L.lib.bh_destroy_group(g)
+    p, v, a = np.stack(st6[:3], 1), np.stack(st6[3:], 1), np.stack(acc, 1)
+    assert np.isfinite(p).all() and np.isfinite(a).all()          # every body came back exactly once
+    o = O.Oracle(n, O.params(key_curve=pkg.default_params().key_curve))
+    o.upload(*ic)
+    o.step(K, order=O.ORDER_BATCHED)
+    w = np.stack(o.download(), 1).astype(np.float64)
+    oa = np.stack(o.download_acc(), 1)
+    o.close()
+    dx = np.abs(p.astype(np.float64) - w[:, :3]).max(axis=1)
+    dv = np.abs(v.astype(np.float64) - w[:, 3:]).max(axis=1)
+    e = rel(a, oa)
+    print(f"bh_step_group x8 vs oracle, n={n} K={K}: |dx| p50 {np.median(dx):.3e} p99.99 {np.percentile(dx, 99.99):.3e} "
+          f"max {dx.max():.3e}; |dv| max {dv.max():.3e}; acc rel p50 {np.median(e):.3e} max {e.max():.3e}")
+    assert np.median(dx) <= 3.1e-5 and np.percentile(dx, 99.99) <= 3.1e-5 and dx.max() <= 6.2e-5
+    assert np.median(dv) <= 1e-7 and np.percentile(dv, 99.99) <= 4e-6 and dv.max() <= 5e-6
+    assert np.median(e) <= 1e-6 and e.max() <= 1e-4
+    out = run_ranks(world, ic, K)
+    p2, v2, a2 = merge(out, n)
+    assert np.array_equal(p, p2) and np.array_equal(v, v2) and np.array_equal(a, a2)
+
+
+def test_group_rank_local_failure_releases_the_other_ranks():
+    """a rank that fails on its own AFTER the last exchange of a step (here: bh_group_upload never ran, so phase 1
+    fails everywhere — and a group whose rank 1 alone was never given bodies) must not leave the other library
+    threads waiting in an exchange: bh_step_group returns an error and the group reports BH_ERR_COMM afterwards"""
+    import ctypes as C
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import _lib as L
+    n, world = 40000, 3
+    ic = pkg.plummer(n, seed=1)
+    g = C.c_void_p()
+    dev = (C.c_int * world)(0, 0, 0)
+    assert L.lib.bh_create_group(C.byref(g), world, dev, n, None, None, 2) == 0
+    try:
+        F = L._F
+        ids = np.arange(n, dtype=np.int32)
+        for q in (0, 2):     # rank 1 gets nothing: its first call fails with BH_ERR_ORDER, before any exchange
+            lo, hi = q * n // world, (q + 1) * n // world
+            arrs = [np.ascontiguousarray(a[lo:hi]) for a in ic]
+            assert L.lib.bh_rank_upload(L.lib.bh_group_rank(g, q), hi - lo, *[a.ctypes.data_as(F) for a in arrs],
+                                        ids[lo:hi].ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        st = L.lib.bh_step_group(g, 2)
+        assert st not in (0, L.BH_ERR_DOMAIN_LEFT), st
+        assert L.lib.bh_step_group(g, 1) == L.BH_ERR_COMM
+    finally:
+        L.lib.bh_destroy_group(g)
+
+
 def test_dd_disc_initial_conditions():
     """the reference's thin rotating disc (ref:297-307): strongly anisotropic domains"""
     pkg = bhpkg.load()
@@ -366,8 +448,14 @@ def test_dd_malformed_let_record_is_closed_and_reported(how):
     stream = torch.cuda.Stream(0)
     res, errs = [None] * world, []
 
-    class CorruptingComm(bhdist.LocalComm):
+    group.slots = [None] * world
+
+    class CorruptingComm(bhdist.TensorComm):   # the caller-callback transport: device copies done here, in Python
         hits = 0
+
+        def __init__(self, group, rank):
+            super().__init__(group.world, rank)
+            self.g = group
 
         def all_gather(self, out, send):
             g = self.g
@@ -429,6 +517,7 @@ def test_dd_malformed_let_record_is_closed_and_reported(how):
             st.close()
         except BaseException as ex:  # noqa: BLE001
             errs.append((r, ex))
+            group.abort()
             group.barrier.abort()
 
     th = [threading.Thread(target=work, args=(r,)) for r in range(world)]

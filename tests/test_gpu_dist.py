@@ -40,6 +40,16 @@ def test_bench_distributed_path_world1(mode, word):
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
     assert out["scaling"] == "weak" and out["config"]["n_total"] == 200000
     assert word in out["config"]["parallelism"]
+    # the line says what it measured: the metric names THIS workload, the 1-GPU reference of the scaling figures is
+    # measured in the same run, and (domain scheme) the strong-scaling run BASELINE.json's metric is worded on rides along
+    assert "200,000 bodies per GPU" in out["metric"] and "theta=0.5" in out["metric"]
+    assert out["n1_ms_per_step"] > 0 and out["n1"]["bodies"] == 200000
+    assert abs(out["aggregate_x"] - out["n1_ms_per_step"] / out["ms_per_step"]) < 1e-6 * out["aggregate_x"]
+    assert len(out["build"]["csrc_sha16"]) == 16 and out["build"]["abi"] == 5
+    if mode == "domain":
+        assert "library RCCL transport" in out["config"]["parallelism"]      # ncclCommInitRank at world size 1
+        assert out["strong"]["n_total"] == 200000 and out["strong"]["value"] > 0 and out["strong"]["scaling"] == "strong"
+        assert out["config"]["domain"]["phase_ms_rank0"]["top_remote_force"] > 0
 
 
 @pytest.mark.parametrize("mode", ["domain", "replicated"])
@@ -61,8 +71,10 @@ def test_bench_two_ranks_rehearsal(mode):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["n_total"] == 300000 and out["value"] > 0
     assert "domain_fallback" not in out["config"]
+    assert "150,000 bodies per GPU" in out["metric"] and out["aggregate_x"] > 0
     if mode == "domain":
         assert len(out["config"]["domain"]["let_records_per_rank"]) == 2
+        assert out["strong"]["n_total"] == 150000 and len(out["strong"]["let_records_per_rank"]) == 2
 
 
 def test_bench_two_ranks_domain_fallback_is_collective():
@@ -105,6 +117,21 @@ def test_domain_stepper_multiprocess_one_gpu(world, tmp_path):
     assert res["world"] == world and res["owned_once"] and res["flags"] == 0
     assert res["max_dpos"] < 5e-2, res
     assert res["acc_rel_median"] < 1e-4, res
+
+
+def test_bh_bench_whole_node_frame_loop_on_one_gpu():
+    """the C++ host of the multi-GPU step (host/bh_bench.cpp --gpus / --devices: bh_create_group, bh_group_upload,
+    bh_step_group, bh_group_sync; the frame loop of ref:353-367 for a whole node): 4 ranks on this one GPU through the
+    in-process transport, and the RCCL path (ncclCommInitAll) at world size 1"""
+    exe = os.path.join(ROOT, "nbody-barnes-hut-cuda_amd", "bh_bench")
+    for extra in (["--devices", "0,0,0,0"], ["--gpus", "1", "--dist"]):
+        r = subprocess.run([exe, "--n", "200000", "--steps", "4", "--warmup", "2", "--ic", "plummer"] + extra,
+                           cwd=ROOT, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:] + r.stdout.decode()[-2000:]
+        txt = r.stdout.decode()
+        assert "Pokretanje Benchmarka za N = 200000" in txt and "Trajanje (ms)" in txt     # ref:287, 351
+        assert f"gpus={4 if 'devices' in extra[0] else 1} " in txt and "particles/s/step" in txt
+        assert "LET retries" in txt
 
 
 def test_sharded_stepper_equals_bh_step(pkg):
