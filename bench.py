@@ -278,8 +278,9 @@ def main():
     ap.add_argument("--force-coop", type=int, default=0,
                     help="tuning: waves per group of the force walk (bh_params.force_coop; 0 = automatic, 1 = one wave per group)")
     ap.add_argument("--dd-split", action="store_true",
-                    help="N > 1: two force passes per step (own pieces while the LET travels, then the remote pass) "
-                         "instead of one after X4 (dist.SPLIT_DEFAULT)")
+                    help="N > 1: two force passes per step (own pieces while the LET travels, then the remote pass): "
+                         "the default with more than one rank")
+    ap.add_argument("--dd-one-pass", action="store_true", help="N > 1: one force pass per step, after X4")
     ap.add_argument("--graph", action="store_true",
                     help="time bh_step replayed as a HIP graph (no per-stage event records inside the timed region; "
                          "the force-launch time of the roofline block then comes from 10 extra timed-stage steps)")
@@ -391,7 +392,7 @@ def main():
 
     def domain_stepper(ic_, let_cap=None):
         return bhdist.DomainStepper(pkg, ic_, make_comm(), local_rank, let_cap=let_cap,
-                                    split=True if args.dd_split else None, **engine_kw)
+                                    split=True if args.dd_split else (False if args.dd_one_pass else None), **engine_kw)
 
     def replicated():
         e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, leaf_cap=args.leaf_cap,

@@ -187,7 +187,11 @@ int bh_com(bh_ctx* c);       /* computeCOM+finalizeCOM ref:279-280              
 int bh_force(bh_ctx* c);     /* computeForceKernel ref:281                                     */
 int bh_integrate(bh_ctx* c); /* integrateKernel ref:282                                        */
 
-/* force for the Morton-sorted bodies [lo,hi) only (multi-rank sharding) */
+/* force for the Morton-sorted bodies [lo,hi) only (multi-rank sharding).  Every body gets the bits of the
+   full launch.  Where the context walks groups with several waves (force_coop != 1: the whole context below ~305,000
+   bodies, the last ~2,400 groups above) a body's bits depend on its 64-body group, so a slab that starts inside that
+   part must start on one of its group boundaries — a multiple of 64 bodies (256 is always safe: dist.slab_bounds) —
+   else BH_ERR_BAD_ARG */
 int bh_force_range(bh_ctx* c, int lo, int hi);
 /* same traversal with per-body V/O/P counters; totals land in bh_stats */
 int bh_force_count(bh_ctx* c);
@@ -325,6 +329,10 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
    the received bytes at 8 ranks.  Every segment carries its sender's needs for all receivers (records 1..3), so all
    ranks still take the same stride decision in bh_dd_let_check. */
 int bh_dd_set_let_mode(bh_ctx* c, int mode);
+/* on = 1: the own-pieces pass of a two-pass step runs on the context's main stream instead of a side stream — for
+   ranks that SHARE one GPU (one-GPU rehearsals: bh_create_group sets it when a device is listed twice), whose side
+   streams would run into each other's work and measure nothing a GPU of their own would show */
+int bh_dd_set_serial(bh_ctx* c, int on);
 /* optional, right after the X3 all-gather: walk the rank's OWN pieces on a side stream while the LET
    marking, export and the X4 all-gather run on the main stream.  bh_dd_top / bh_dd_force then cover
    only the other ranks' pieces and bh_integrate adds the two partial accelerations.  The split is
@@ -351,6 +359,13 @@ int bh_dd_phase_let(bh_ctx* c, const void* gathered_x3, void* send_x4, int strid
 int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* counts, int* fits);
 int bh_dd_phase_end(bh_ctx* c, void* send_x1);
 int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc);
+/* Measurement only: bh_force_walk_stats for a rank of the decomposed step — the counted walk of its bodies over the
+   stitched pool as the last step left it; which = 0: the tree of the last (or only) force pass, 1: the own-pieces pass
+   (two-pass steps) */
+int bh_dd_walk_stats(bh_ctx* c, int which, bh_walk_stats* out);
+/* Measurement only (two-pass steps): the rank's force passes re-launched over the pool as the last step left it, with
+   nothing else on the GPU: ms[0] own-pieces pass alone, ms[1] remote pass alone, ms[2] both at once on two streams */
+int bh_dd_pass_times(bh_ctx* c, float ms[3]);
 /* what the last step's migration did, for logs and tests (synchronises): out[0] bodies this rank holds, [1] emigrants
    it found in its last classification, [2] steps since bh_dd_init in which the domain boundaries moved, [3] what the
    last step did with them: 0 kept (a rank owns a fixed interval of the curve: the splitter keys persist from step
@@ -400,9 +415,12 @@ typedef struct bh_rank_opts {
   int32_t mig_cap;  /* emigrant slots of the X2 buffers; 0 = min(max(4096, n_cap / 2), 4 n_cap / world)        */
   int32_t let_cap;  /* records per LET segment; 0 = 516 + n_cap                                                */
   int32_t let_mode; /* X4: 1 = per-destination segments, all-to-all (default); 0 = one union segment, all-gather */
-  int32_t split;    /* 0 = one force pass after X4 (default); 1 = own pieces beside X4, then the remote pass    */
+  int32_t split;    /* -1 = automatic (default): 1 when world > 1, else 0;  0 = one force pass after X4;  1 = own pieces
+                       on a side stream while the LET is marked, exported and exchanged, then the remote pass: 1.25 ms
+                       of force kernels instead of 1.22 at 8 x 1M, and X4 is off the critical path                 */
   int32_t log;      /* 1 = keep (emigrants, boundary action) per step for bh_rank_read_log: synchronises, tests  */
-  int32_t reserved[10];
+  int32_t serial;   /* 1 = bh_dd_set_serial (ranks sharing one GPU)                                               */
+  int32_t reserved[9];
 } bh_rank_opts;
 typedef struct bh_rank_plan { /* bh_rank_query: the resolved capacities and the byte sizes of the eight buffers */
   int32_t n_cap, mig_cap, let_cap, stride0;

@@ -76,8 +76,8 @@ class BhComm(C.Structure):
 
 
 class BhRankOpts(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("n_cap", "mig_cap", "let_cap", "let_mode", "split", "log")] + \
-               [("reserved", C.c_int32 * 10)]
+    _fields_ = [(k, C.c_int32) for k in ("n_cap", "mig_cap", "let_cap", "let_mode", "split", "log", "serial")] + \
+               [("reserved", C.c_int32 * 9)]
 
 
 class BhRankPlan(C.Structure):
@@ -169,6 +169,7 @@ SYMBOLS = [
     ("bh_dd_force", C.c_int, [_P]),
     ("bh_dd_let_check", C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),
     ("bh_dd_set_let_mode", C.c_int, [_P, C.c_int]),
+    ("bh_dd_set_serial", C.c_int, [_P, C.c_int]),
     ("bh_dd_phase_migrate", C.c_int, [_P, _P, _P, C.c_int]),
     ("bh_dd_phase_tree", C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("bh_dd_phase_let", C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
@@ -176,6 +177,8 @@ SYMBOLS = [
     ("bh_dd_phase_end", C.c_int, [_P, _P]),
     ("bh_dd_download", C.c_int, [_P, _F, _F, _F]),
     ("bh_dd_get_info", C.c_int, [_P, C.POINTER(C.c_int32)]),
+    ("bh_dd_walk_stats", C.c_int, [_P, C.c_int, C.POINTER(BhWalkStats)]),
+    ("bh_dd_pass_times", C.c_int, [_P, _F]),
     ("bh_comm_rccl_from", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int]),
     ("bh_comm_rccl_unique_id", C.c_int, [_P]),
     ("bh_comm_rccl_init_rank", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int, C.c_int]),

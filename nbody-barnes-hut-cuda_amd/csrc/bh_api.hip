@@ -373,6 +373,7 @@ int bh_com(bh_ctx* c) {
 int bh_force_range(bh_ctx* c, int lo, int hi) {
   BH_NEED(c, BH_ST_COM);
   if (lo < 0 || hi > c->n || lo > hi) return BH_ERR_BAD_ARG;
+  if (!bhk_force_range_aligned(c, lo)) return BH_ERR_BAD_ARG;  // cooperative walk: slabs start on group boundaries
   BH_HIP(c, bhk_force(c, lo, hi, false));
   c->stage |= BH_ST_FORCE;
   c->ever |= BH_ST_FORCE;
@@ -401,13 +402,20 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
   if (!out) return BH_ERR_BAD_ARG;
   BH_NEED(c, BH_ST_COM);
   if (c->p.strict_fp || c->p.literal_force || c->dd) return BH_ERR_BAD_ARG;  // the default walk only
+  return bh_walk_stats_from(c, 0, out);
+}
+
+}  // extern "C"
+
+// the counted walk of the context's bodies from pool record `root` (bh_force_walk_stats: 0; bh_dd_walk_stats: a top tree)
+int bh_walk_stats_from(bh_ctx* c, int root, bh_walk_stats* out) {
   memset(out, 0, sizeof(*out));
   const size_t W = (size_t)bhk_force_walk_rows(c);
   u32* rows = nullptr;
   BH_HIP(c, hipMalloc((void**)&rows, W * BH_WALK_ROW * sizeof(u32)));
   std::vector<u32> h(W * BH_WALK_ROW);
   hipError_t e = hipMemsetAsync(rows, 0, W * BH_WALK_ROW * sizeof(u32), c->stream);
-  if (e == hipSuccess) e = bhk_force_walk_stats(c, rows);
+  if (e == hipSuccess) e = bhk_force_walk_stats(c, rows, root);
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), rows, W * BH_WALK_ROW * sizeof(u32), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(rows);
@@ -440,6 +448,8 @@ int bh_force_walk_stats(bh_ctx* c, bh_walk_stats* out) {
   out->wave_cycles_mean = out->waves ? cyc_sum / (double)out->waves : 0.0;
   return BH_OK;
 }
+
+extern "C" {
 
 int bh_force_launch_trace(bh_ctx* c, uint32_t* rows, int capacity_rows, int* n_rows) {
   if (!rows || !n_rows || capacity_rows < 1) return BH_ERR_BAD_ARG;
@@ -595,6 +605,10 @@ int bh_step(bh_ctx* c) {
   c->cur = par ^ 1;  // the bookkeeping step_launch does next to its launches
   c->key_buf = c->g_keybuf[par];
   c->sort_calls++;
+  // what the replayed COM stage leaves behind (bhk_build / bhk_com_records set these next to their launches, which a
+  // replay does not run on the host): proto records again unless the engine keeps canonical ones, digests of THIS tree
+  c->rec_proto = !(c->p.strict_fp || c->p.literal_force);
+  c->com_digests = true;
   c->stage = BH_ST_UPLOADED;
   c->steps++;
   return BH_OK;

@@ -80,6 +80,9 @@ struct bh_dd_state {
   int samp_cap;    // sample slots per rank in X1 (kSampTotal / world)
   u64* skeys;      // [world-1] splitter keys: they PERSIST from step to step (a rank owns a fixed interval of the
                    // curve) and move only when a rank's body count leaves the tolerance band (dd_split_kernel)
+  int* drift;      // [0..63] per-rank drift of the body count, bodies per step x 16 (smoothed over the steps that kept the
+                   // boundaries); [64..127] every rank's count at the previous step's X1; [128] counts valid, [129]
+                   // estimate valid.  Written by dd_split_kernel from all-gathered counts: identical on every rank
   int* piece_tmp;  // [BH_DD_PIECE_CAP] unsorted piece records
   int* piece_idx;  // [BH_DD_PIECE_CAP] pieces in body order
   int* ddi;        // [16] device scalars: 0 piece counter, 1 remote boxes, 2 top pieces, 3 top children,
@@ -96,6 +99,8 @@ struct bh_dd_state {
   hipEvent_t ev_x3, ev_top1, ev_own;
   hipStream_t stream_own;  // lowest priority: the own pass is background work behind the LET export and X4
   bool split;      // two-pass force: own pieces while X4 is in flight, remote pieces after it
+  bool serial;     // the own pass runs on the context's main stream instead of the side stream (bh_dd_set_serial: ranks
+                   // that share one GPU in a rehearsal — their side streams would overlap each other's work)
   int* host;       // pinned: [world] LET counts, [64 .. 67] migration results, [68] their sequence number
   hipEvent_t ev_let;
   bool let_copy_pending;
@@ -145,6 +150,31 @@ constexpr int kX1Samples0 = 16;
 __host__ __device__ inline int x1_floats(int world) { return kX1Samples0 + 4 * samp_cap_of(world); }
 constexpr float kSplitTolerance = 0.015f;  // a rank's body count may leave n / P by this fraction before the
                                            // boundaries move
+constexpr float kSplitHardBound = 0.10f;   // ... and beyond this fraction the proposals are not trusted: sample quantiles
+constexpr int kDriftHorizon = 4;           // a rebalance aims at where the quantile will be this many steps ahead
+
+// Where boundary q (between ranks q and q + 1) should stand in the global body order when the boundaries move: at the
+// quantile (q + 1) n / P, shifted against the drift the ranks below it have shown — every rank sees every rank's count
+// in X1, so the drift of a rank's count while the boundaries stood still is known everywhere (drift16: bodies per step
+// x 16).  A rank that gains d bodies per step is given kDriftHorizon d bodies less than its share (at most 0.8 of the
+// tolerance band, `cap`), so that its count crosses the band once instead of leaving it from the middle: the
+// rebalances come about half as often for the same imbalance (the reference's per-step cube moves the key grid under
+// the bodies, which is what makes the counts drift: DESIGN.md §6).  Pure integer arithmetic on all-gathered data:
+// dd_x1_pack_kernel (which proposes) and dd_split_kernel (which checks) agree on every rank.
+__device__ inline long long dd_want(int q, int world, long long n_total, const int* drift16, int est_valid,
+                                    long long cap) {
+  long long want = (long long)(q + 1) * n_total / world;
+  if (!est_valid || cap <= 0) return want;
+  long long sum = 0, below = 0;
+  for (int r = 0; r < world; r++) {
+    long long b = (long long)drift16[r] * kDriftHorizon / 16;
+    b = b > cap ? cap : (b < -cap ? -cap : b);
+    sum += b;
+    if (r <= q) below += b;
+  }
+  const long long mean = sum / world;  // (the drifts add up to zero; what clamping leaves over is spread evenly)
+  return want - (below - mean * (q + 1));
+}
 
 __device__ __forceinline__ int owner_of(u64 key, const u64* sk, int nsplit) {
   int o = 0;
@@ -166,7 +196,8 @@ __device__ __forceinline__ int owner_of(u64 key, const u64* sk, int nsplit) {
 __global__ __launch_bounds__(256) void dd_x1_pack_kernel(float* __restrict__ send, const float* __restrict__ mm,
                                                          int n_loc, const float4* __restrict__ posm, double g,
                                                          int samp_cap, const int* __restrict__ nloc, int world,
-                                                         int rank, long long n_total) {
+                                                         int rank, long long n_total, const int* __restrict__ drift,
+                                                         long long cap) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < 6) send[t] = mm[t];
   if (t == 0) {
@@ -180,14 +211,15 @@ __global__ __launch_bounds__(256) void dd_x1_pack_kernel(float* __restrict__ sen
     const bool known = total == n_total && nloc[rank] == n_loc;
     float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
     if (known && rank > 0) {
-      const long long d = (long long)rank * n_total / world - before;  // > 0: the lower boundary moves up into this range
+      // > 0: the lower boundary moves up into this range
+      const long long d = dd_want(rank - 1, world, n_total, drift, drift[129], cap) - before;
       if (d > 0 && d < n_loc) {
         lo = posm[d];
         lo.w = 1.0f;
       }
     }
     if (known && rank < world - 1) {
-      const long long d = before + n_loc - (long long)(rank + 1) * n_total / world;  // > 0: the upper one moves down
+      const long long d = before + n_loc - dd_want(rank, world, n_total, drift, drift[129], cap);  // > 0: the upper one moves down
       if (d > 0 && d < n_loc) {
         hi = posm[n_loc - d];
         hi.w = 1.0f;
@@ -219,7 +251,10 @@ __global__ __launch_bounds__(256) void dd_x1_pack_kernel(float* __restrict__ sen
 __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict__ g, int world, int xf,
                                                         int samp_cap, float* __restrict__ bounds,
                                                         int curve, u64* __restrict__ skeys,
-                                                        int* __restrict__ ddi, long long n_total, float tol) {
+                                                        int* __restrict__ ddi, long long n_total, float tol,
+                                                        int* __restrict__ drift, long long cap) {
+  __shared__ int s_drift[64];  // the drift estimate the proposals of this step were made with (dd_x1_pack_kernel)
+  __shared__ int s_est, s_prev_action;
   __shared__ u64 k[kSampTotal];
   __shared__ int nvalid;
   __shared__ float cube[8];
@@ -227,7 +262,28 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
   __shared__ int s_need2;
   __shared__ float4 prop[64];
   const int tid = threadIdx.x;
+  if (tid < 64) s_drift[tid] = drift[tid];
   if (tid == 0) {
+    s_est = drift[129];
+    s_prev_action = ddi[11];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // the drift estimate for the NEXT steps' proposals: the change of every rank's count over a step that kept the
+    // boundaries (a step that moved them changed the counts by the rebalance itself), smoothed 3 : 1
+    if (world > 1) {
+      const bool sample = drift[128] && s_prev_action == 0;
+      for (int r = 0; r < world; r++) {
+        const int now = __float_as_int(g[(size_t)r * xf + 6]);
+        if (sample) {
+          const int dlt = now - drift[64 + r];
+          drift[r] = s_est ? (3 * s_drift[r] + 16 * dlt) / 4 : 16 * dlt;
+        }
+        drift[64 + r] = now;
+      }
+      if (sample) drift[129] = 1;
+      drift[128] = 1;
+    }
     nvalid = 0;
     s_need2 = 0;
     float mn[3] = {1e10f, 1e10f, 1e10f}, mx[3] = {-1e10f, -1e10f, -1e10f};  // sentinels ref:138
@@ -252,6 +308,12 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
         for (int r = 0; r < world; r++) {
           const double nr = (double)__float_as_int(g[(size_t)r * xf + 6]);
           if (fabs(nr - fair) > (double)tol * fair) mode = 1;
+        }
+        // far outside the band (proposals rejected step after step, or a step that scrambled the body order): the
+        // proposals are bodies picked by their place in the previous key order and cannot be trusted to cross that much
+        for (int r = 0; r < world; r++) {
+          const double nr = (double)__float_as_int(g[(size_t)r * xf + 6]);
+          if (fabs(nr - fair) > (double)kSplitHardBound * fair) mode = 2;
         }
       }
     }
@@ -295,7 +357,7 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
     const int q = tid;
     long long before = 0;
     for (int r = 0; r <= q; r++) before += __float_as_int(g[(size_t)r * xf + 6]);
-    const long long want = (long long)(q + 1) * n_total / world;
+    const long long want = dd_want(q, world, n_total, s_drift, s_est, cap);
     const double stride = fmax(1.34 * (double)n_total / (double)kSampTotal, 1.0);  // (bh_dd_cube_pack)
     const float4 up = reinterpret_cast<const float4*>(g + (size_t)(q + 1) * xf + 8)[0];  // rank q+1, lower end
     const float4 dn = reinterpret_cast<const float4*>(g + (size_t)q * xf + 8)[1];        // rank q, upper end
@@ -331,9 +393,11 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
   __syncthreads();
   if (tid == 0) {
     const int mode = s_mode == 1 && !s_need2 ? 1 : 2;
-    ddi[9] += 1;
+    bool any = mode == 2;
+    for (int q = 0; q < world - 1 && !any; q++) any = prop[q].w > 0.5f;
+    if (any) ddi[9] += 1;  // steps in which a boundary really moved (every proposal may have been rejected)
     ddi[10] = 1;
-    ddi[11] = mode;
+    ddi[11] = any ? mode : 0;
     s_mode = mode;
   }
   __syncthreads();
@@ -1668,6 +1732,11 @@ __global__ __launch_bounds__(256) void dd_pack_ids_kernel(const float* __restric
     }                                         \
   } while (0)
 
+// the most a rebalance shifts a rank's share against its drift: 0.8 of the tolerance band (bodies)
+static long long dd_drift_cap(const bh_dd_state* d) {
+  return (long long)(0.8 * (double)kSplitTolerance * (double)d->n_total / (double)d->world);
+}
+
 static void dd_set_n(bh_ctx* c, int n) {
   c->n = n;
   c->sort_tiles = (n + BH_SORT_TILE - 1) / BH_SORT_TILE;
@@ -1681,7 +1750,7 @@ void bh_dd_free(bh_ctx* c) {
     (void)hipStreamSynchronize(d->stream_own);
     (void)hipStreamDestroy(d->stream_own);
   }
-  void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->piece_tmp,
+  void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->drift, d->piece_tmp,
                   d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2,
                   d->cls_done, d->abs_done, d->arrive, c->dd_minmax, d->wmask, d->list_e, d->list_w, d->list_m, d->dstd,
                   d->dtot, d->csum, d->mark_cnt, d->mark_done};
@@ -1767,6 +1836,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipMalloc((void**)&d->fpos, (fl + 1 + 64) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->nloc, 64 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->skeys, 64 * 8) == hipSuccess;
+  ok = ok && hipMalloc((void**)&d->drift, 192 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_tmp, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->piece_idx, BH_DD_PIECE_CAP * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->ddi, 16 * 4) == hipSuccess;
@@ -1821,6 +1891,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   }
   d->samp_cap = samp_cap_of(world);
   BH_HIP(c, hipMemsetAsync(d->nloc, 0, 64 * 4, c->stream));
+  BH_HIP(c, hipMemsetAsync(d->drift, 0, 192 * 4, c->stream));
   BH_HIP(c, hipMemsetAsync(d->ddi, 0, 16 * 4, c->stream));  // piece counter: re-cleared by dd_describe_kernel
   // the caller's pool becomes the record pool: the COM stage writes the local tree at [0, rec_cap)
   BH_HIP(c, hipMemsetAsync(pool, 0, (size_t)pool_records * sizeof(bh_frec), c->stream));
@@ -1854,6 +1925,11 @@ int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const flo
   c->slow_seen_sorts = c->sort_calls;
   BH_HIP(c, hipMemsetAsync(c->info, 0, sizeof(bh_devinfo), c->stream));
   BH_HIP(c, hipMemsetAsync(c->acc, 0, N * sizeof(float4), c->stream));
+  // new bodies: the boundaries of an earlier run mean nothing for them (the first step draws sample quantiles:
+  // ddi[10] "splitter keys valid"), nor do its counts, its boundary statistics and its drift estimate
+  BH_HIP(c, hipMemsetAsync(c->dd->ddi + 9, 0, 4 * sizeof(int), c->stream));
+  BH_HIP(c, hipMemsetAsync(c->dd->nloc, 0, 64 * sizeof(int), c->stream));
+  BH_HIP(c, hipMemsetAsync(c->dd->drift, 0, 192 * sizeof(int), c->stream));
   BH_HIP(c, hipStreamSynchronize(c->stream));
   c->stage = BH_ST_UPLOADED;
   c->ever = BH_ST_UPLOADED;
@@ -1874,7 +1950,7 @@ int bh_dd_cube_pack(bh_ctx* c, void* send_x1) {
   const int th = d->samp_cap > 8 ? d->samp_cap : 8;
   dd_x1_pack_kernel<<<(th + 255) / 256, 256, 0, c->stream>>>((float*)send_x1, c->dd_minmax, c->n, c->posm[c->cur],
                                                              g > 1.0 ? g : 1.0, d->samp_cap, d->nloc, d->world,
-                                                             d->rank, d->n_total);
+                                                             d->rank, d->n_total, d->drift, dd_drift_cap(d));
   BH_HIP(c, hipGetLastError());
   return BH_OK;
 }
@@ -1884,7 +1960,8 @@ int bh_dd_cube_apply(bh_ctx* c, const void* gathered_x1) {
   bh_dd_state* d = c->dd;
   const int xf = x1_floats(d->world);
   dd_split_kernel<<<1, 1024, 0, c->stream>>>((const float*)gathered_x1, d->world, xf, d->samp_cap, c->bounds,
-                                             c->p.key_curve, d->skeys, d->ddi, d->n_total, kSplitTolerance);
+                                             c->p.key_curve, d->skeys, d->ddi, d->n_total, kSplitTolerance, d->drift,
+                                             dd_drift_cap(d));
   BH_HIP(c, hipGetLastError());
   c->stage = BH_ST_UPLOADED | BH_ST_BBOX;
   c->ever |= BH_ST_BBOX;
@@ -2031,6 +2108,12 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
   return BH_OK;
 }
 
+int bh_dd_set_serial(bh_ctx* c, int on) {
+  if (!c || !c->dd) return BH_ERR_BAD_ARG;
+  c->dd->serial = on != 0;
+  return BH_OK;
+}
+
 int bh_dd_set_let_mode(bh_ctx* c, int mode) {
   if (!c || !c->dd || (mode != 0 && mode != 1)) return BH_ERR_BAD_ARG;
   c->dd->let_mode = mode;
@@ -2046,17 +2129,18 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
   d->split = true;
+  hipStream_t so = d->serial ? c->stream : d->stream_own;
   BH_HIP(c, hipEventRecord(d->ev_x3, c->stream));  // the X3 gather and the local tree are complete here
-  BH_HIP(c, hipStreamWaitEvent(d->stream_own, d->ev_x3, 0));
-  dd_top_kernel<<<1, 1024, 0, d->stream_own>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
+  BH_HIP(c, hipStreamWaitEvent(so, d->ev_x3, 0));
+  dd_top_kernel<<<1, 1024, 0, so>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
                                             d->top_base2, d->seg_base, kSegBlocks0, c->bounds, c->p.G,
                                             c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + kTopCap,
                                             d->top_b + kTopCap, d->top_ci + kTopCap, d->ddi,
                                             c->info, 1);
   BH_HIP(c, hipGetLastError());
-  BH_HIP(c, hipEventRecord(d->ev_top1, d->stream_own));  // the remote pass re-emits from this tree's scratch
-  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, d->stream_own, c->acc));
-  BH_HIP(c, hipEventRecord(d->ev_own, d->stream_own));
+  BH_HIP(c, hipEventRecord(d->ev_top1, so));  // the remote pass re-emits from this tree's scratch
+  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, so, c->acc));
+  BH_HIP(c, hipEventRecord(d->ev_own, so));
   return BH_OK;
 }
 
@@ -2173,13 +2257,17 @@ int bh_dd_phase_let(bh_ctx* c, const void* gathered_x3, void* send_x4, int strid
 int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* counts, int* fits) {
   int s = bh_dd_top(c, gathered_x3, stride);
   if (s) return s;
+  int32_t own_counts[64];  // a caller that does not ask for the counts must still not walk a departed rank's LET
+  if (!counts) counts = own_counts;
   s = bh_dd_let_check(c, stride, counts);
   if (fits) *fits = (s == BH_OK) ? 1 : 0;
   if (s == BH_ERR_SMALL_BUFFER) return BH_OK;  // the caller repeats X4 with a larger stride
   if (s) return s;
-  if (counts)
-    for (int q = 0; q < c->dd->world; q++)
-      if (counts[q] < 0) return BH_OK;  // a rank left the step: the caller raises on every rank, nothing to walk
+  for (int q = 0; q < c->dd->world; q++)
+    if (counts[q] < 0) {  // a rank left the step: the caller raises on every rank, nothing to walk
+      if (fits) *fits = 0;
+      return counts == own_counts ? BH_ERR_DOMAIN_LEFT : BH_OK;
+    }
   // (one rank: the remote pass walks nothing but the top record, and a launch that short integrates slower than the
   // streaming kernel does — 0.100 against 0.055 + 0.021 ms at 1M bodies)
   return dd_force_impl(c, c->dd->world > 1);
@@ -2200,6 +2288,52 @@ int bh_dd_get_info(bh_ctx* c, int32_t out[8]) {
   BH_HIP(c, hipStreamSynchronize(c->stream));
   out[0] = c->n; out[1] = h[12]; out[2] = h[9]; out[3] = h[11];
   out[4] = out[5] = out[6] = out[7] = 0;
+  return BH_OK;
+}
+
+// Measurement only: the counted walk (bh_force_walk_stats) of this rank's bodies over the stitched pool as the last
+// step left it — which = 0: the top tree of the last (or only) force pass, 1: that of the own-pieces pass (two-pass
+// steps only).  The bodies have moved by one step since that tree was built: counts, not forces.
+int bh_dd_walk_stats(bh_ctx* c, int which, bh_walk_stats* out) {
+  if (!c || !c->dd || !out || which < 0 || which > 1) return BH_ERR_BAD_ARG;
+  if (!(c->ever & BH_ST_FORCE)) return BH_ERR_ORDER;
+  if (which == 1 && !c->dd->split) return BH_ERR_ORDER;
+  return bh_walk_stats_from(c, which ? c->dd->top_base2 : c->dd->top_base, out);
+}
+
+// Measurement only (two-pass steps): the force passes of this rank re-launched over the pool as the last step left it,
+// with nothing else on the GPU — ms[0] the own-pieces pass alone, ms[1] the remote pass alone, ms[2] both at once
+// (own pass on the side stream, remote pass on the main stream: first launch to last completion).  Overwrites the
+// partial accelerations; the bodies are not touched.
+int bh_dd_pass_times(bh_ctx* c, float ms[3]) {
+  if (!c || !c->dd || !ms) return BH_ERR_BAD_ARG;
+  bh_dd_state* d = c->dd;
+  if (!(c->ever & BH_ST_FORCE) || !d->split) return BH_ERR_ORDER;
+  BH_HIP(c, hipSetDevice(c->device));
+  hipEvent_t e[4];
+  for (int k = 0; k < 4; k++) BH_HIP(c, hipEventCreate(&e[k]));
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  BH_HIP(c, hipStreamSynchronize(d->stream_own));
+  for (int rep = 0; rep < 2; rep++) {  // (the first round warms the caches)
+    BH_HIP(c, hipEventRecord(e[0], c->stream));
+    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, c->stream, c->acc));
+    BH_HIP(c, hipEventRecord(e[1], c->stream));
+    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, d->acc2));
+    BH_HIP(c, hipEventRecord(e[2], c->stream));
+    BH_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  BH_HIP(c, hipEventElapsedTime(&ms[0], e[0], e[1]));
+  BH_HIP(c, hipEventElapsedTime(&ms[1], e[1], e[2]));
+  BH_HIP(c, hipEventRecord(e[0], c->stream));
+  BH_HIP(c, hipStreamWaitEvent(d->stream_own, e[0], 0));
+  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, d->stream_own, c->acc));
+  BH_HIP(c, hipEventRecord(e[3], d->stream_own));
+  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, d->acc2));
+  BH_HIP(c, hipStreamWaitEvent(c->stream, e[3], 0));
+  BH_HIP(c, hipEventRecord(e[1], c->stream));
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  BH_HIP(c, hipEventElapsedTime(&ms[2], e[0], e[1]));
+  for (int k = 0; k < 4; k++) (void)hipEventDestroy(e[k]);
   return BH_OK;
 }
 

@@ -1264,7 +1264,8 @@ constexpr int kWalkRow = BH_WALK_ROW;
 template <bool PF>
 __global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __restrict__ frec_g,
                                                                const float4* __restrict__ posm, int n, float eps2,
-                                                               int xcd_mode, int group, u32* __restrict__ rows) {
+                                                               int xcd_mode, int group, u32* __restrict__ rows,
+                                                               int root) {
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int chunk = block_chunk(xcd_mode);
@@ -1281,7 +1282,7 @@ __global__ __launch_bounds__(256) void force_walk_stats_kernel(const float* __re
   if (m0 == 0) return;
   bool limit;
   u32 st[8];
-  (void)fast_traverse_asm<false, true, PF>(frec_g, 0, m0, px, py, pz, eps2, ax, ay, az, 0, limit, st);
+  (void)fast_traverse_asm<false, true, PF>(frec_g, root, m0, px, py, pz, eps2, ax, ay, az, 0, limit, st);
   const bool odd = __float_as_uint(ax + ay + az) == 0x7fc12345u;  // never: keeps the walk's arithmetic alive
   if (lane == 0 || odd) {
     u32* r = rows + (size_t)wave * kWalkRow;
@@ -1469,6 +1470,19 @@ static int mixed_tail_grid(int mmode, int tail) {
   return mmode == 2 ? (tail + 8 * kTailRun - 1) / (8 * kTailRun) * (8 * kTailRun) : tail;
 }
 
+// bh_force_range: a slab [lo, hi) gets the bits of the full launch only if the groups it forms are the full launch's
+// groups — with several waves per group (cooperative walk) a body's bits depend on its group's composition, and the
+// groups of the cooperative part are counted from `bulk`: lo must then sit on a group boundary.  (One wave per group:
+// any lo — the result does not depend on the group.)
+bool bhk_force_range_aligned(const bh_ctx* c, int lo) {
+  if (c->p.strict_fp || c->p.literal_force || c->p.force_variant != 0) return true;
+  const int group = force_group(c, c->n);
+  const int K = force_coop(c, group);
+  const int bulk = force_bulk_bodies(c, group, K);
+  if (bulk >= c->n) return true;  // one wave per group throughout
+  return lo <= bulk || (lo - bulk) % group == 0;
+}
+
 // fuse_integrate (bh_step): the launch may also integrate the bodies and fold the next step's cube into
 // c->bounds_next (force_fast_kernel FUSE); *fused tells whether it did (only the hand-scheduled walk over all bodies)
 hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate, bool* fused) {
@@ -1653,7 +1667,7 @@ int bhk_force_walk_rows(const bh_ctx* c) {
   const int group = force_group(c, c->n);
   return (c->n + group - 1) / group;
 }
-hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][BH_WALK_ROW], device */) {
+hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][BH_WALK_ROW], device */, int root) {
   int tpb = c->p.force_block;
   if (tpb != 64 && tpb != 128 && tpb != 256) tpb = BH_FORCE_BLOCK_DEFAULT;
   const int mode = (c->p.xcd_mode == 1) ? 1 : 0;  // one row per wave in launch order: no grid padding here
@@ -1661,10 +1675,10 @@ hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][BH
   const int g2 = (bhk_force_walk_rows(c) * 64 + tpb - 1) / tpb;
   if (c->n <= kPrefetchMaxBodies)
     force_walk_stats_kernel<true><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->n, c->p.eps2,
-                                                             mode, group, rows);
+                                                             mode, group, rows, root);
   else
     force_walk_stats_kernel<false><<<g2, tpb, 0, c->stream>>>((const float*)c->frec, c->posm[c->cur], c->n, c->p.eps2,
-                                                              mode, group, rows);
+                                                              mode, group, rows, root);
   return hipGetLastError();
 }
 

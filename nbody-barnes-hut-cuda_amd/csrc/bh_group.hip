@@ -555,6 +555,7 @@ int bh_rank_default_opts(bh_rank_opts* o) {
   if (!o) return BH_ERR_BAD_ARG;
   memset(o, 0, sizeof(*o));
   o->let_mode = 1;
+  o->split = -1;
   return BH_OK;
 }
 
@@ -601,6 +602,7 @@ static void rank_common_init(bh_rank* r, const bh_comm* comm, const bh_rank_plan
   r->comm = *comm;
   r->plan = *plan;
   r->o = *o;
+  if (r->o.split < 0) r->o.split = comm->world > 1 ? 1 : 0;  // two passes hide X4; one rank has nothing remote
   r->stride = plan->stride0;
   r->mig_stride = plan->mig_cap < 4096 ? plan->mig_cap : 4096;
   if (o->log) r->log = new (std::nothrow) std::vector<int32_t>();
@@ -655,6 +657,7 @@ int bh_rank_create(bh_rank** out, const bh_comm* comm, int64_t n_total, const bh
   if (!s) s = bh_dd_init(r->ctx, comm->world, comm->rank, n_total, plan.mig_cap, plan.let_cap, r->buf[POOL],
                          plan.sz.pool_records);
   if (!s) s = bh_dd_set_let_mode(r->ctx, o.let_mode);
+  if (!s && o.serial) s = bh_dd_set_serial(r->ctx, 1);
   if (s) {
     r->comm.release = nullptr;
     bh_rank_destroy(r);
@@ -856,6 +859,8 @@ struct bh_group {
   std::vector<nccl_comm_t> nccl;  // ncclCommInitAll's communicators (owned by the group)
   std::vector<bh_rank*> ranks;
   std::vector<worker*> w;
+  std::vector<hipStream_t> stream;  // ranks that share a device share ONE stream (owned here): their kernels run one
+                                    // after the other, as on a GPU of their own — what a one-GPU rehearsal measures
   bool dead = false;  // a rank failed on its own: the transport was aborted
 
   // fn(rank) on every rank's own thread; -> first non-zero result in rank order, BH_ERR_DOMAIN_LEFT last
@@ -917,6 +922,11 @@ void bh_destroy_group(bh_group* g) {
     for (nccl_comm_t c : g->nccl)
       if (c) (void)a->CommDestroy(c);
   if (g->hub) bh_hub_destroy(g->hub);
+  for (size_t q = 0; q < g->stream.size(); q++) {
+    bool first = g->stream[q] != nullptr;
+    for (size_t k = 0; k < q; k++) first = first && g->stream[k] != g->stream[q];
+    if (first && hipSetDevice(g->dev[q]) == hipSuccess) (void)hipStreamDestroy(g->stream[q]);
+  }
   delete g;
 }
 
@@ -972,6 +982,18 @@ int bh_create_group(bh_group** out, int ngpus, const int* devices, int64_t n_tot
         for (int k = 0; k < ngpus; k++)
           if (k != q && hipSetDevice(devices[q]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[k], 0);
   }
+  g->stream.assign(ngpus, nullptr);
+  if (!distinct)
+    for (int q = 0; q < ngpus; q++) {
+      for (int k = 0; k < q && !g->stream[q]; k++)
+        if (devices[k] == devices[q]) g->stream[q] = g->stream[k];
+      if (!g->stream[q] && (hipSetDevice(devices[q]) != hipSuccess ||
+                            hipStreamCreateWithFlags(&g->stream[q], hipStreamNonBlocking) != hipSuccess)) {
+        g->stream[q] = nullptr;
+        bh_destroy_group(g);
+        return BH_ERR_HIP;
+      }
+    }
   for (int q = 0; q < ngpus; q++) {
     worker* k = new (std::nothrow) worker();
     if (!k) {
@@ -981,12 +1003,13 @@ int bh_create_group(bh_group** out, int ngpus, const int* devices, int64_t n_tot
     g->w.push_back(k);
     k->th = std::thread(worker_main, k, devices[q]);
   }
+  if (!distinct) g->o.serial = 1;  // ranks that share a GPU: one stream each, own pass included (bh_dd_set_serial)
   s = g->run_all([g](int q) {
     bh_comm c;
     memset(&c, 0, sizeof(c));
     int s1 = g->hub ? bh_comm_hub(&c, g->hub, q) : rccl_fill(&c, g->nccl[q], false, g->P, q);
     if (s1) return s1;
-    s1 = bh_rank_create(&g->ranks[q], &c, g->n_total, &g->p, &g->o, g->dev[q], nullptr, nullptr);
+    s1 = bh_rank_create(&g->ranks[q], &c, g->n_total, &g->p, &g->o, g->dev[q], (void*)g->stream[q], nullptr);
     if (s1 && c.release) c.release(c.user);
     return s1;
   });

@@ -261,10 +261,11 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
         return e.download_order()
 
 
-# One force pass per step when the caller does not choose (split=False): the LET export and X4 are exposed, but the
-# two-pass form — own pieces on a side stream while the LET travels, then the remote pass — costs more GPU time than
-# it hides on xGMI (profiles/r04_dd/split_vs_one_pass.txt).  split=True remains for slower interconnects.
-SPLIT_DEFAULT = False
+# Force passes per step when the caller does not choose: None = the library's rule (bh_rank_opts.split -1): two passes
+# with more than one rank — own pieces on a side stream while the LET is marked, exported and exchanged, then the
+# remote pass (0.78 + 0.47 ms of force kernels against 1.22 for one pass at 8 x 1M, each measured with the GPU to
+# itself: profiles/r05_dd/pass_times.txt; X4 is off the critical path) — and one pass with one rank.
+SPLIT_DEFAULT = None
 
 # X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
 # (let_mode=0: the all-gather of one union segment per rank; tools/dd_debug.py --let-mode 0 for A/B)
@@ -287,7 +288,9 @@ class DomainStepper:
                  let_cap=None, order=None, split=None, let_mode=None, mig_log=False, **kw):
         L = _lib()
         self.pkg, self.comm = pkg, comm
-        self.split = SPLIT_DEFAULT if split is None else bool(split)
+        if split is None:
+            split = SPLIT_DEFAULT
+        self.split = (comm.world > 1) if split is None else bool(split)
         self.let_mode = LET_MODE_DEFAULT if let_mode is None else int(let_mode)
         self.world, self.rank = comm.world, comm.rank
         P, r = self.world, self.rank
@@ -307,6 +310,7 @@ class DomainStepper:
         if let_cap:
             o.let_cap = int(let_cap)
         o.let_mode, o.split, o.log = self.let_mode, int(self.split), int(bool(mig_log))
+        o.serial = int(isinstance(comm, LocalComm))   # ranks of one process on one GPU: no side stream (bh_dd_set_serial)
         self.params = params if params is not None else pkg.default_params(**kw)
         plan = L.BhRankPlan()
         st = L.lib.bh_rank_query(n, P, C.byref(o), C.byref(plan))

@@ -15,7 +15,8 @@
 //            [--dist]            with --gpus 1: the multi-GPU step at world size 1 (RCCL path on one GPU)
 //            [--devices a,b,..]  explicit device per rank; a device listed twice selects the in-process
 //                                transport (one-GPU rehearsal of G ranks)
-//            [--split]           two force passes per step (own pieces beside X4, then the remote pass)
+//            [--split | --one-pass]  two force passes per step (own pieces beside X4, then the remote pass: the
+//                                default with more than one rank) or one pass after X4
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -40,10 +41,10 @@ static double now_ms() {
 
 // the frame loop of main() (ref:353-367) over bh_step_group: every rank steps, then the whole node is synchronised
 static int run_group(int N, int frames, int warmup, bool quiet, const bh_params& p, const std::vector<int>& devs,
-                     bool split, const char* ic_name, std::vector<float>* a, const char* dump_path, const char* snap_path) {
+                     int split, const char* ic_name, std::vector<float>* a, const char* dump_path, const char* snap_path) {
   bh_rank_opts o;
   bh_rank_default_opts(&o);
-  o.split = split ? 1 : 0;
+  o.split = split;
   bh_group* g = nullptr;
   CK(bh_create_group(&g, (int)devs.size(), devs.data(), N, &p, &o, 0));
   CK(bh_group_upload(g, a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data(), a[6].data()));
@@ -100,7 +101,8 @@ static int run_group(int N, int frames, int warmup, bool quiet, const bh_params&
 int main(int argc, char** argv) {
   int N = 500000;  // ref:31
   int gpus = 0;
-  bool dist = false, split = false;
+  bool dist = false;
+  int split = -1;
   std::vector<int> devs;
   int frames = 1000;  // ref:353
   int warmup = 0;
@@ -130,7 +132,8 @@ int main(int argc, char** argv) {
       for (char* t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) devs.push_back(atoi(t));
     }
     else if (!strcmp(argv[i], "--dist")) dist = true;
-    else if (!strcmp(argv[i], "--split")) split = true;
+    else if (!strcmp(argv[i], "--split")) split = 1;
+    else if (!strcmp(argv[i], "--one-pass")) split = 0;
     else if (arg("--dump")) dump_path = argv[++i];
     else if (arg("--snapshot")) snap_path = argv[++i];
     else if (!strcmp(argv[i], "--literal-force")) p.literal_force = 1;  // what the CUDA binary computes (D1)
