@@ -75,7 +75,7 @@ def test_rank_plan_defaults(pkg):
     assert L.lib.bh_rank_query(8_000_000, 14, None, C.byref(pl)) == -1     # more ranks than the top tree holds pieces for
     o = L.BhRankOpts()
     L.lib.bh_rank_default_opts(C.byref(o))
-    assert (o.let_mode, o.split, o.n_cap) == (1, 0, 0)
+    assert (o.let_mode, o.split, o.n_cap) == (1, -1, 0)     # split -1: two force passes when world > 1
     o.let_mode = 0
     assert L.lib.bh_rank_query(1000, 2, C.byref(o), C.byref(pl)) == 0 and pl.bytes[6] == pl.let_cap * 32
 
