@@ -157,8 +157,9 @@ def test_dd_boundaries_persist_and_rebalance():
     """The domain boundaries (splitter keys) persist from step to step and move only when a rank's body count leaves
     n / P by more than 1.5 %: 200 steps of a system whose two halves
     stream through each other at first (so the counts drift and the boundaries HAVE to move several times) and then
-    settles.  Checked: nobody lost or duplicated; the boundaries moved more than once but in a minority of the
-    steps; in the steps that kept them the emigrants are what physically crossed a boundary — per step well under
+    settles.  Checked: nobody lost or duplicated; the boundaries moved more than once but in at most a fifth of the
+    steps (measured on MI355X, round 5: see the printed line; the bound was loosened to a third in round 4 to pass a
+    run with 42 moves — restored); in the steps that kept them the emigrants are what physically crossed a boundary — per step well under
     1 % of a rank (round 3 re-drew the boundaries from samples every step: 2-5 % of every rank per step); every rank
     ends within 3 % of its fair share; forces of the final state against a single context."""
     pkg = bhpkg.load()
@@ -179,7 +180,7 @@ def test_dd_boundaries_persist_and_rebalance():
     print(f"boundaries moved in {moved} of {steps} steps; emigrants per step (max over ranks): kept steps median "
           f"{np.median(log[kept, 0]):.0f} max {log[kept, 0].max()}, moved steps max {log[~kept, 0].max()}; "
           f"final counts {counts.tolist()}")
-    assert 2 <= moved <= steps // 3, moved
+    assert 2 <= moved <= steps // 5, moved
     assert (log[:, 1] != 0).sum() == moved
     assert np.median(log[kept, 0]) < 0.01 * n / world
     assert np.abs(counts - n / world).max() <= 0.03 * n / world, counts

@@ -589,6 +589,30 @@ def test_force_fast_vs_oracle(pkg, orc, n, theta, variant):
     e.close()
 
 
+@pytest.mark.parametrize("n", [125_000, 250_000])
+def test_force_default_engine_vs_oracle_where_every_group_is_cooperative(pkg, orc, n):
+    """125,000 (the strong-scaling share of 1M over 8 GPUs) and 250,000 bodies: the default engine walks EVERY group
+    with four waves there (force_coop 0 -> K = 4 up to ~305,000 bodies).  test_force_coop_walk_matches_the_one_wave_walk
+    compares that walk with the one-wave walk; this compares it with the ORACLE directly, same stated tolerance as
+    test_force_fast_vs_oracle: relative |da| median <= 2e-6, 99.9th percentile <= 2e-5, max <= 5e-4."""
+    ic = pkg.plummer(n, seed=42)
+    e = _engine(pkg, ic)
+    assert e.params.force_coop == 0
+    e.tree_stages(); e.force()
+    ga = np.stack(e.download_acc(), 1)
+    p = oparams(orc, e.params)
+    o = oracle_pipeline(orc, ic, p)
+    oacc, *_ = orc.force(o["rec"], o["xyzm"], p, orc.ORDER_PREORDER)
+    oa = np.zeros((n, 3), np.float32)
+    oa[o["perm"]] = oacc[:, :3]
+    rel = np.linalg.norm(ga - oa, axis=1) / np.linalg.norm(oa, axis=1)
+    print(f"default engine (K = 4 everywhere) vs oracle, n={n}: p50 {np.median(rel):.2e} p99.9 {np.quantile(rel, 0.999):.2e} "
+          f"max {rel.max():.2e}")
+    assert np.median(rel) <= 2e-6 and np.quantile(rel, 0.999) <= 2e-5 and rel.max() <= 5e-4
+    assert e.stats().status_flags == 0 and e.stats().force_redo_waves == 0
+    e.close()
+
+
 def test_force_walk_stats_match_the_oracles_group_walk(pkg, orc):
     """bh_force_walk_stats (the counters bench.py prices the issue-rate roofline with): blocks popped by the
     64-body waves == pops of the oracle's group walk on the same tree (MAC ties aside), pairs = the records

@@ -45,9 +45,13 @@ elif mode == "single":
     assert np.isfinite(x).all() and np.isfinite(vx).all()
     print(f"single {n} x {steps} steps ok, {time.time() - t0:.1f} s, |x|max {np.abs(x).max():.1f}")
 else:
-    import torch
-    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    # dd P n steps [log_every] [kind]: the domain-decomposed step through the C group API (bh_create_group /
+    # bh_step_group: P ranks on this one GPU, in-process transport) — no Python in the step.  log_every = 1 prints every
+    # step (bodies / emigrants / boundary action per rank: the step log of profiles/r05_dd/).
+    import ctypes as C
+    from nbody_barnes_hut_cuda_amd import _lib as L
     P, n, steps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    every = int(sys.argv[5]) if len(sys.argv) > 5 else 100
     kind = sys.argv[6] if len(sys.argv) > 6 else "plummer"   # plummer | disc | stream (two halves passing through each
     ic = [a.copy() for a in (pkg.disc if kind == "disc" else pkg.plummer)(n, seed=17)]   # other) | cold (collapse from rest)
     if kind == "stream":
@@ -55,43 +59,40 @@ else:
         ic[3][: n // 2] -= 800.0
     if kind == "cold":
         ic[3][:] = 0.0; ic[4][:] = 0.0; ic[5][:] = 0.0
-    ic = tuple(ic)
-    order = bhdist.global_morton_order(pkg, ic, 0)
-    group = bhdist.LocalGroup(P)
-    stream = torch.cuda.Stream(0)
-    errs, sts = [], [None] * P
-    log_from = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 30
-    hist = [[] for _ in range(P)]
-    def work(r):
-        try:
-            torch.cuda.set_device(0)
-            st = bhdist.DomainStepper(pkg, ic, bhdist.LocalComm(group, r), 0, stream=stream, order=order)
-            sts[r] = st
-            group.barrier.wait()
-            for s in range(0, steps, 100):
-                if s >= log_from:   # (argv[5]: log every step from here on; printed when the run fails)
-                    for k in range(min(100, steps - s)):
-                        st.step(1)
-                        hist[r].append((s + k + 1, st.n_loc, st.e.dd_info(), st.mig_last, st.mig_stride_used, st.mig_rounds))
-                        del hist[r][:-14]
-                else:
-                    st.step(min(100, steps - s))
-                fl = st.e.stats().status_flags
-                assert fl == 0, (r, s, fl)
-                group.barrier.wait()
-                if r == 0:
-                    print(f"step {s + 100}: n_loc {[x.n_loc for x in sts]} let {st.let_counts.tolist()} emig {st.mig_last} "
-                          f"mig_rounds {st.mig_rounds} let_retries {st.let_retries}", flush=True)
-                group.barrier.wait()
-        except BaseException as ex:
-            errs.append((r, ex)); print("rank", r, repr(ex), flush=True); group.barrier.abort()
-    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
-    [t.start() for t in th]; [t.join() for t in th]
-    if errs:
-        for r in range(P):
-            for h in hist[r]:
-                print(f"rank {r} step {h[0]}: n_loc {h[1]} info(bodies, emigrants, moves, mode) {h[2][:4]} emig_max {h[3]} stride {h[4]} rounds {h[5]}")
-        raise SystemExit(1)
-    tot = sum(s.n_loc for s in sts)
+    g = C.c_void_p()
+    dev = (C.c_int * P)(*([0] * P))
+    st = L.lib.bh_create_group(C.byref(g), P, dev, n, None, None, 0)
+    assert st == 0, st
+    assert L.lib.bh_group_upload(g, *[np.ascontiguousarray(a).ctypes.data_as(L._F) for a in ic]) == 0
+    t0 = time.time()
+    moved_prev = 0
+    for s in range(0, steps, every):
+        k = min(every, steps - s)
+        st = L.lib.bh_step_group(g, k)
+        info = [L.BhRankInfo() for _ in range(P)]
+        dd = np.zeros((P, 8), np.int32)
+        flags = []
+        for q in range(P):
+            r = L.lib.bh_group_rank(g, q)
+            L.lib.bh_rank_get_info(r, C.byref(info[q]))
+            ctx = L.lib.bh_rank_ctx(r)
+            L.lib.bh_dd_get_info(ctx, dd[q].ctypes.data_as(C.POINTER(C.c_int32)))
+            bs = L.BhStats(); L.lib.bh_get_stats(ctx, C.byref(bs)); flags.append(bs.status_flags)
+        line = (f"step {s + k}: bodies {[i.n_loc for i in info]} emigrants found {dd[:, 1].tolist()} "
+                f"boundaries {['kept', 'moved to the proposed quantiles', 'sample quantiles'][int(dd[0, 3])]} "
+                f"(moved in {int(dd[0, 2])} steps so far) X2 slots {info[0].mig_stride} LET {list(info[0].let_counts[:P])} "
+                f"stride {info[0].stride} extra rounds {info[0].mig_rounds} LET retries {info[0].let_retries}")
+        if st != 0 or any(flags):
+            print(line, flush=True)
+            print(f"FAILED: status {st} ({L.lib.bh_strerror(st).decode()}), left_rank {info[0].left_rank}, flags {flags}", flush=True)
+            raise SystemExit(1)
+        if every == 1 or (s // every) % 5 == 0 or s + k == steps:
+            print(line, flush=True)
+    tot = sum(i.n_loc for i in info)
     assert tot == n, tot
-    print(f"dd {P} ranks x {n // P} x {steps} steps ({kind}) ok")
+    out = [np.full(n, np.nan, np.float32) for _ in range(6)]
+    assert L.lib.bh_group_download(g, *[a.ctypes.data_as(L._F) for a in out]) == 0
+    assert all(np.isfinite(a).all() for a in out)
+    print(f"dd {P} ranks x {n // P} x {steps} steps ({kind}) ok: boundaries moved in {int(dd[0, 2])} of {steps} steps, "
+          f"{time.time() - t0:.1f} s")
+    L.lib.bh_destroy_group(g)
