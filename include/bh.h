@@ -261,17 +261,15 @@ int bh_device_acc(bh_ctx* c, void** dptr, int64_t* bytes);
 int bh_bind_acc(bh_ctx* c, void* device_float4_n);
 int bh_n(const bh_ctx* c);
 
-/* ---- domain-decomposed multi-GPU stepping (the reference is single-GPU) ----
- * One context per rank, each owning the bodies of one contiguous Morton-key range.  Per step
- * the host side (nbody-barnes-hut-cuda_amd/dist.py: DomainStepper) alternates these calls with
- * four all-gathers of plain device buffers; the library never communicates itself:
+/* ---- domain-decomposed multi-GPU stepping, engine side (the reference is single-GPU) ----
+ * One context per rank, each owning the bodies of one contiguous interval of the key curve.  These entry points pack
+ * and consume plain device buffers and never communicate; bh_rank_step (below) is the per-step protocol around them:
  *
- *   bh_dd_cube_pack      -> all-gather X1 -> bh_dd_cube_apply      global cube (exact) + splitters
- *   bh_dd_migrate_pack   -> all-gather X2 -> bh_dd_migrate_apply   bodies that left the key range
- *   bh_dd_tree           -> all-gather X3                          local octree; piece descriptors
- *   bh_dd_force_local (optional: own pieces, side stream, overlaps the next two lines)
- *   bh_dd_let_pack       -> all-gather X4 (into the record pool)   locally-essential records
- *   bh_dd_top, bh_dd_force, bh_dd_let_check, bh_integrate
+ *   [X1 all-gather] bh_dd_phase_migrate   global cube (exact), splitter keys, emigrants packed
+ *   [X2 all-gather] bh_dd_phase_tree      immigrants absorbed; local sort / build / COM; piece descriptors
+ *   [X3 all-gather] bh_dd_phase_let       own pieces walked on a side stream (two-pass steps); LET marked + exported
+ *   [X4 all-to-all] bh_dd_phase_force     validation, top tree, remote (or whole) pass — which integrates
+ *                   bh_dd_phase_end       the next step's X1 payload
  *
  * The local octree of a rank is the canonical octree of the global cube restricted to its bodies;
  * every cell that does not touch either end of the rank's body range is a complete global cell.
@@ -282,7 +280,8 @@ int bh_n(const bh_ctx* c);
  * A LET segment holds the child blocks of every local cell that some body of another rank could
  * open (conservative box test against the remote pieces).  Requires key_bits 63, leaf_cap 1 and max_depth 21
  * (the default: unsplit cells then hold coincident bodies only and are far too small for a remote body to open;
- * bh_dd_init returns BH_ERR_BAD_ARG otherwise). */
+ * bh_dd_init returns BH_ERR_BAD_ARG otherwise).  The fine-grained calls (bh_dd_cube_pack .. bh_dd_let_check) are the
+ * pieces the phase calls are made of; tests and tools drive them directly. */
 #define BH_DD_PIECE_CAP 512          /* pieces per rank: <= 2 spines x 21 levels x 7 = 294      */
 #define BH_FLAG_DD_BODIES 16         /* local body count exceeded the context's capacity         */
 #define BH_FLAG_DD_PIECES 32         /* more than BH_DD_PIECE_CAP pieces                          */

@@ -1,47 +1,47 @@
-// bh_dd.hip — domain-decomposed multi-GPU stepping (include/bh.h "bh_dd_*").
+// bh_dd.hip — the engine side of the domain-decomposed multi-GPU step (include/bh.h "bh_dd_*").
 //
-// The reference is single-GPU; nothing here has a reference counterpart.  One context per rank owns
-// the bodies of one contiguous Morton-key range.  The library never communicates: each entry point
-// packs or consumes a plain device buffer and the host side (dist.py) moves the buffers with four
-// all-gathers per step (RCCL over xGMI).
+// The reference is single-GPU; nothing here has a reference counterpart.  One context per rank owns the bodies of ONE
+// INTERVAL OF THE KEY CURVE.  This file packs and consumes plain device buffers and never communicates: the per-step
+// protocol that moves them (three all-gathers and one all-to-all, size negotiation, retries, collective failure) is
+// bh_rank_step in bh_group.hip; DESIGN.md §6 is the overview.
 //
-//  X1 cube + splitters  each rank's min/max (6 floats) and a regular sample of its body positions
-//                       (one body in every n_total / 4096).  min/max are exact, so the global cube —
-//                       hence every Morton key — is bit-identical to the single-GPU run.  Every rank
-//                       keys all samples under the NEW cube, sorts them and takes the world-1
-//                       equal-count quantiles as this step's splitter keys.  (Splitters carried over
-//                       from the previous step do not survive a moving cube: a boundary body that
-//                       crosses a top-level cell plane changes its key by whole octants.)
-//  X2 migration         owner(key) = #{splitter keys <= key}.  Bodies whose owner changed are
-//                       compacted into the exchange buffer (its used size follows the observed
-//                       count; a larger wave leaves in further rounds of the same step); every rank
-//                       picks its immigrants out of the gathered buffers.  Scan-based, so arrival
-//                       order is deterministic.
-//  X3 piece descriptors after the local sort/build/COM.  A local cell that does not touch either end
-//                       of the local body range is a complete global cell (its key prefix is bounded
-//                       by local bodies on both sides).  The end-touching cells form two root-to-leaf
-//                       "spines"; their other children are the rank's PIECES (<= 2 x 21 x 7).  The
-//                       canonical octree above all pieces (top tree) is a pure function of the piece
-//                       keys, so every rank rebuilds it identically (dd_top_kernel).
-//  X4 LET segments      child blocks of every local cell some body of another rank could open:
-//                       conservative test of the cell's MAC radius against the boxes of the remote
-//                       pieces.  Records are written with pool-relative child indices, so the gathered
-//                       segments are traversable in place.
+//  X1 cube + boundaries  each rank's min / max (exact, so the global cube — hence every key — is bit-identical to the
+//                        single-GPU run), its body count, the bodies it proposes for its two domain boundaries and a
+//                        regular sample of its positions.  The splitter KEYS PERSIST from step to step: a rank owns a
+//                        fixed interval of the curve and a body changes owner when its key leaves it.  They move only
+//                        when some rank's count leaves n / P by more than 1.5 % (decided from the gathered counts, so
+//                        collectively), then to the exact quantiles the ranks propose — shifted against the drift of
+//                        the counts (dd_want) — or, first step / far out of balance, to sample quantiles
+//                        (dd_split_kernel; a position re-keyed under a new cube can jump octants, a key cannot).
+//  X2 migration          owner(key) = #{splitter keys <= key}.  Bodies whose owner changed are compacted into the
+//                        exchange buffer (its used size follows the observed count; a larger wave leaves in further
+//                        rounds of the same step); every rank picks its immigrants out of the gathered buffers.
+//                        Scan-based, so arrival order is deterministic.
+//  X3 piece descriptors  after the local sort / build / COM.  A local cell that does not touch either end of the local
+//                        body range is a complete global cell.  The end-touching cells form two root-to-leaf spines;
+//                        their other children are the rank's PIECES (<= 2 x 21 x 7).  The canonical octree above all
+//                        pieces (top tree) is a pure function of the piece keys: every rank rebuilds it identically
+//                        (dd_top_kernel).
+//  X4 LET segments       child blocks of every local cell some body of another rank could open (conservative test of
+//                        the cell's MAC radius against the boxes of the remote pieces), one segment PER DESTINATION
+//                        (all-to-all; let_mode 0: one union segment, all-gather), written with pool-relative child
+//                        indices so that the received segments are traversable in place.  Every segment carries its
+//                        sender's needs for all receivers: every rank holds the same needs matrix and takes the same
+//                        decision on the next stride.
 //
-// The stitched pool [local tree + body digests | two top trees | world x LET segment] is the same
-// canonical octree a single GPU builds; the unchanged force kernel traverses it from a top-tree root.
+// The stitched pool [local tree + body digests | two top trees | world x LET segment] is the same canonical octree a
+// single GPU builds; the unchanged force walk traverses it from a top-tree root.
 //
-// Two-pass force: the own pieces (about two thirds of the work) need nothing from other ranks, so
-// bh_dd_force_local walks them on a lowest-priority side stream right after X3 — top tree #1: other
-// ranks' pieces are null records, top cells carry this rank's share of their mass — while the main
-// stream marks/exports the LET and runs X4; bh_dd_top/bh_dd_force then do the mirror image (top tree
-// #2, re-emitted from #1's structure) and bh_integrate adds the two partial accelerations.  Both
-// passes apply the same MAC to the same cells, so the split is exact up to summation order.
+// Force passes: one pass over the stitched tree after X4, or — the default with more than one rank — two: the own
+// pieces (two thirds of the pair work; they need nothing from other ranks) on a low-priority side stream right after
+// X3, with the other ranks' pieces as null records and every top cell carrying this rank's share of its mass, while
+// the main stream marks / exports the LET and runs X4; then the mirror image (top tree re-emitted from the first one's
+// structure), whose launch adds the own pass's accelerations, integrates and folds this rank's min / max.  Both passes
+// apply the same MAC to the same cells, so the split is exact up to summation order.
 //
-// Failure handling: sizes that can overflow (X2, X4) are negotiated from all-gathered counts, so every
-// rank takes the same decision; an X4 segment that does not fit is sent closed (pieces unopenable) and
-// the exchange is repeated larger; a rank-local capacity failure is announced through the X4 header
-// (dist.py) so that no rank is left waiting in a collective.
+// Safety: every walk over imported records is bounded; dd_validate_kernel closes malformed imported records before
+// anything walks them (BH_FLAG_DD_LET_INVALID); an X4 segment that does not fit is sent closed (pieces unopenable)
+// and the exchange is repeated larger; sticky flags of a step surface at the next step's bh_dd_migrate_apply.
 #include <stdlib.h>
 #include <string.h>
 
