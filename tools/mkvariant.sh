@@ -15,12 +15,12 @@ out=$root/tools/bin/libs; bld=$root/tools/bin/build_$name
 mkdir -p $out $bld
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -fno-slp-vectorize -I$src/include -I$pkg/csrc"
 pids=()
-for f in bh_api bh_scan bh_sort bh_sort_onesweep bh_tree bh_force bh_dd; do
+for f in bh_api bh_scan bh_sort bh_sort_onesweep bh_tree bh_force bh_dd bh_group; do
   /opt/rocm/bin/hipcc $flags "$@" -c $pkg/csrc/$f.hip -o $bld/$f.o 2> $bld/$f.log & pids+=($!)
 done
 for f in bh_ic bh_io; do
   /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -I$src/include -I$pkg/csrc -c $pkg/csrc/$f.cpp -o $bld/$f.o 2> $bld/$f.log & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $bld/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $bld/*.o -ldl -lpthread
 echo built $out/$name.so
