@@ -287,6 +287,50 @@ def test_group_step_from_c_vs_oracle_and_python_binding():
     assert np.array_equal(p, p2) and np.array_equal(v, v2) and np.array_equal(a, a2)
 
 
+def test_ranks_given_arbitrary_subsets_of_the_bodies():
+    """distributed input (bh_rank_upload takes ANY subset with its global ids: INTEGRATION.md §4b): every rank starts
+    with a RANDOM quarter of the system — nothing sorted, nothing near its own domain — the first step draws sample
+    quantiles and three quarters of every rank's bodies change owner over several X2 rounds; from then on the run
+    must be the run that started from slabs of the curve: same canonical tree, forces to summation order."""
+    import ctypes as C
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import _lib as L
+    n, world, K = 100_000, 4, 3
+    ic = pkg.plummer(n, seed=31)
+    rng = np.random.default_rng(5)
+    owner = rng.permutation(n) % world
+    g = C.c_void_p()
+    dev = (C.c_int * world)(*([0] * world))
+    assert L.lib.bh_create_group(C.byref(g), world, dev, n, None, None, 0) == 0
+    try:
+        F = L._F
+        for q in range(world):
+            ids = np.nonzero(owner == q)[0].astype(np.int32)
+            arrs = [np.ascontiguousarray(a[ids]) for a in ic]
+            assert L.lib.bh_rank_upload(L.lib.bh_group_rank(g, q), len(ids), *[a.ctypes.data_as(F) for a in arrs],
+                                        ids.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        assert L.lib.bh_step_group(g, K) == 0 and L.lib.bh_group_sync(g) == 0
+        st6 = [np.full(n, np.nan, np.float32) for _ in range(6)]
+        assert L.lib.bh_group_download(g, *[a.ctypes.data_as(F) for a in st6]) == 0
+        acc = [np.full(n, np.nan, np.float32) for _ in range(3)]
+        assert L.lib.bh_group_download_acc(g, *[a.ctypes.data_as(F) for a in acc]) == 0
+        info = L.BhRankInfo()
+        counts = []
+        for q in range(world):
+            L.lib.bh_rank_get_info(L.lib.bh_group_rank(g, q), C.byref(info))
+            counts.append(info.n_loc)
+        assert info.mig_rounds >= 1                       # the first step's wave did not fit one X2 round
+    finally:
+        L.lib.bh_destroy_group(g)
+    p, a = np.stack(st6[:3], 1), np.stack(acc, 1)
+    assert np.isfinite(p).all() and sum(counts) == n
+    assert np.abs(np.array(counts) - n / world).max() < 0.05 * n / world, counts
+    p1, v1, a1 = single(ic, K)
+    assert np.abs(p - p1).max() < 1e-3
+    e = rel(a, a1)
+    assert np.median(e) < 2e-6 and e.max() < 2e-3, (np.median(e), e.max())
+
+
 def test_group_rank_local_failure_releases_the_other_ranks():
     """a rank that fails on its own AFTER the last exchange of a step (here: bh_group_upload never ran, so phase 1
     fails everywhere — and a group whose rank 1 alone was never given bodies) must not leave the other library

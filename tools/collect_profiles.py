@@ -18,9 +18,17 @@ def newest(pattern):
 ks = newest("prof_trace/*/*kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(out, "kernel_stats.csv"))
-for src, dst in (("prof_trace.json", "bench_under_rocprof.json"), ("bench_final.json", "bench.json")):
+for src, dst in (("prof_trace.json", "bench_under_rocprof.json"), ("bench_final.json", "bench.json"),
+                 ("step_timeline_1M.txt", "step_timeline_1M.txt"), ("bh_bench_disc500k.txt", "configs/bh_bench_disc500k.txt"),
+                 ("bh_bench_disc1m.txt", "configs/bh_bench_disc1m.txt")):
     if os.path.exists(os.path.join(G, src)):
+        os.makedirs(os.path.dirname(os.path.join(out, dst)), exist_ok=True)
         shutil.copy(os.path.join(G, src), os.path.join(out, dst))
+for f in glob.glob(os.path.join(G, "cfg_*.json")) + glob.glob(os.path.join(G, "step_timeline_[0-9]*.txt")) + \
+        glob.glob(os.path.join(G, "force_trace_*.txt")):
+    sub = "configs" if os.path.basename(f).startswith("cfg_") else ""
+    os.makedirs(os.path.join(out, sub), exist_ok=True)
+    shutil.copy(f, os.path.join(out, sub, os.path.basename(f)))
 
 
 def counters(path):
@@ -56,6 +64,16 @@ if fk:
         if kk:
             cal[name] = {c: pmc[kk[0]][c]["mean_KiB"] for c in pmc[kk[0]]}
     fetch, write = pmc[k]["FETCH_SIZE"]["mean_KiB"], pmc[k]["WRITE_SIZE"]["mean_KiB"]
+    # which kernel sources the profiled bench ran: its own line says (bench.py build.csrc_sha16); bench.py compares
+    # that with the sources it runs and prints roofline.traffic_stale
+    sha = None
+    for src in ("prof_fetch.json", "prof_write.json"):
+        try:
+            line = [l for l in open(os.path.join(G, src)) if l.startswith("{")][-1]
+            sha = json.loads(line)["build"]["csrc_sha16"]
+            break
+        except Exception:
+            pass
     rec = {"n": 1000000, "theta": 0.5, "kernel": k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
            "fused_with_integrate": True, "dispatches": pmc[k]["FETCH_SIZE"]["dispatches"], "FETCH_SIZE_KiB": fetch,
            "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "calibration_KiB": cal,
@@ -64,7 +82,7 @@ if fk:
                   "counts 64 B per 128-B request (MI355X_MICROARCH.md HBM section). The same table holds the streaming kernels "
                   "of the step as a cross-check (keys_split_kernel reads 16 B and writes 8 B per body, com_kernel<false> "
                   "writes 32 B per record; FETCH_SIZE reports half of what they read, WRITE_SIZE is exact).",
-           "profile": tag}
+           "profile": tag, "csrc_sha16": sha}
     path = os.path.join(ROOT, "profiles", "force_traffic.json")
     try:
         old = json.load(open(path)).get("records", [])
