@@ -24,8 +24,12 @@ for src, dst in (("prof_trace.json", "bench_under_rocprof.json"), ("bench_final.
     if os.path.exists(os.path.join(G, src)):
         os.makedirs(os.path.dirname(os.path.join(out, dst)), exist_ok=True)
         shutil.copy(os.path.join(G, src), os.path.join(out, dst))
+# (only what the same final_round.sh run left: gpurun_out/ keeps earlier rounds' files of the same names)
+t_run = os.path.getmtime(os.path.join(G, "bench_final.json")) - 120 if os.path.exists(os.path.join(G, "bench_final.json")) else 0
 for f in glob.glob(os.path.join(G, "cfg_*.json")) + glob.glob(os.path.join(G, "step_timeline_[0-9]*.txt")) + \
         glob.glob(os.path.join(G, "force_trace_*.txt")):
+    if os.path.getmtime(f) < t_run:
+        continue
     sub = "configs" if os.path.basename(f).startswith("cfg_") else ""
     os.makedirs(os.path.join(out, sub), exist_ok=True)
     shutil.copy(f, os.path.join(out, sub, os.path.basename(f)))
