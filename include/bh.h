@@ -332,6 +332,10 @@ int bh_dd_set_let_mode(bh_ctx* c, int mode);
    ranks that SHARE one GPU (one-GPU rehearsals: bh_create_group sets it when a device is listed twice), whose side
    streams would run into each other's work and measure nothing a GPU of their own would show */
 int bh_dd_set_serial(bh_ctx* c, int on);
+/* two-pass steps: the walk of only the first pct per cent of the rank's bodies is split into an own-pieces pass (beside
+   the LET export and X4) and a remote pass; the other bodies are walked in ONE pass after X4, at the same time as that
+   remote pass (1 <= pct <= 100; 100 = every body in two passes) */
+int bh_dd_set_split_percent(bh_ctx* c, int pct);
 /* optional, right after the X3 all-gather: walk the rank's OWN pieces on a side stream while the LET
    marking, export and the X4 all-gather run on the main stream.  bh_dd_top / bh_dd_force then cover
    only the other ranks' pieces and bh_integrate adds the two partial accelerations.  The split is
@@ -363,8 +367,10 @@ int bh_dd_download(bh_ctx* c, float* posm, float* velid, float* acc);
    (two-pass steps) */
 int bh_dd_walk_stats(bh_ctx* c, int which, bh_walk_stats* out);
 /* Measurement only (two-pass steps): the rank's force passes re-launched over the pool as the last step left it, with
-   nothing else on the GPU: ms[0] own-pieces pass alone, ms[1] remote pass alone, ms[2] both at once on two streams */
-int bh_dd_pass_times(bh_ctx* c, float ms[3]);
+   nothing else on the GPU.  Full two-pass step: ms[0] own-pieces pass alone, ms[1] remote pass alone, ms[2] both at
+   once on two streams, ms[3] 0.  Partial step (split_pct < 100): ms[0] / ms[1] own / remote pass of the split part,
+   ms[2] the one pass of the other bodies, ms[3] that one pass and the remote pass at once, as the step runs them */
+int bh_dd_pass_times(bh_ctx* c, float ms[4]);
 /* what the last step's migration did, for logs and tests (synchronises): out[0] bodies this rank holds, [1] emigrants
    it found in its last classification, [2] steps since bh_dd_init in which the domain boundaries moved, [3] what the
    last step did with them: 0 kept (a rank owns a fixed interval of the curve: the splitter keys persist from step
@@ -414,12 +420,15 @@ typedef struct bh_rank_opts {
   int32_t mig_cap;  /* emigrant slots of the X2 buffers; 0 = min(max(4096, n_cap / 2), 4 n_cap / world)        */
   int32_t let_cap;  /* records per LET segment; 0 = 516 + n_cap                                                */
   int32_t let_mode; /* X4: 1 = per-destination segments, all-to-all (default); 0 = one union segment, all-gather */
-  int32_t split;    /* -1 = automatic (default): 1 when world > 1, else 0;  0 = one force pass after X4;  1 = own pieces
-                       on a side stream while the LET is marked, exported and exchanged, then the remote pass: 1.25 ms
-                       of force kernels instead of 1.22 at 8 x 1M, and X4 is off the critical path                 */
+  int32_t split;    /* -1 = automatic (default): 1 when world > 1, else 0;  0 = one force pass after X4;  1 = two passes
+                       for the first split_pct per cent of the rank's bodies — own pieces on a side stream while the
+                       LET is marked, exported and exchanged, remote pieces after X4 — and one pass after X4 for the
+                       rest: X4 leaves the critical path for the price of two passes on a fraction of the bodies   */
   int32_t log;      /* 1 = keep (emigrants, boundary action) per step for bh_rank_read_log: synchronises, tests  */
   int32_t serial;   /* 1 = bh_dd_set_serial (ranks sharing one GPU)                                               */
-  int32_t reserved[9];
+  int32_t split_pct; /* two-pass steps: per cent of the bodies whose walk is split (bh_dd_set_split_percent); 0 = default
+                        (30), 100 = every body in two passes                                                        */
+  int32_t reserved[8];
 } bh_rank_opts;
 typedef struct bh_rank_plan { /* bh_rank_query: the resolved capacities and the byte sizes of the eight buffers */
   int32_t n_cap, mig_cap, let_cap, stride0;

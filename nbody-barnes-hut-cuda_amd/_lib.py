@@ -76,8 +76,9 @@ class BhComm(C.Structure):
 
 
 class BhRankOpts(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("n_cap", "mig_cap", "let_cap", "let_mode", "split", "log", "serial")] + \
-               [("reserved", C.c_int32 * 9)]
+    _fields_ = [(k, C.c_int32) for k in ("n_cap", "mig_cap", "let_cap", "let_mode", "split", "log", "serial",
+                                         "split_pct")] + \
+               [("reserved", C.c_int32 * 8)]
 
 
 class BhRankPlan(C.Structure):
@@ -170,6 +171,7 @@ SYMBOLS = [
     ("bh_dd_let_check", C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),
     ("bh_dd_set_let_mode", C.c_int, [_P, C.c_int]),
     ("bh_dd_set_serial", C.c_int, [_P, C.c_int]),
+    ("bh_dd_set_split_percent", C.c_int, [_P, C.c_int]),
     ("bh_dd_phase_migrate", C.c_int, [_P, _P, _P, C.c_int]),
     ("bh_dd_phase_tree", C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("bh_dd_phase_let", C.c_int, [_P, _P, _P, C.c_int, C.c_int]),

@@ -71,7 +71,12 @@ struct bh_dd_state {
   int mig_cap, let_cap;
   bh_frec* pool;
   long long pool_records;
-  int top_base, top_base2, seg_base;  // top tree of the remote pass (or the whole tree) / of the own pass
+  int top_base, top_base2, top_base3, seg_base;  // top tree of the remote pass (or the whole tree) / of the own pass /
+                                                 // the whole tree beside a remote one (partial two-pass steps)
+  int split_pct;   // two-pass steps: per cent of the rank's bodies whose walk is split into own + remote pass (100:
+                   // all of them); the others are walked in one pass after X4
+  int own_hi;      // bodies [0, own_hi) were walked by this step's own pass
+  hipEvent_t ev_x4;
   int* w;          // [rec_cap + 1] records a cell exports (0: not needed by any other rank)
   int* dst;        // [rec_cap + 1] exclusive scan of w
   int* flag;       // [max(n_cap, world*mig_cap) + 1]
@@ -1762,6 +1767,7 @@ void bh_dd_free(bh_ctx* c) {
   if (d->ev_x3) (void)hipEventDestroy(d->ev_x3);
   if (d->ev_own) (void)hipEventDestroy(d->ev_own);
   if (d->ev_top1) (void)hipEventDestroy(d->ev_top1);
+  if (d->ev_x4) (void)hipEventDestroy(d->ev_x4);
 
   c->acc2 = nullptr;
   c->dd_minmax = nullptr;
@@ -1788,7 +1794,7 @@ int bh_dd_query(int n_cap, int world, int mig_cap, int let_cap, bh_dd_sizes* o) 
   o->x2_bytes = 32 + 32LL * mig_cap;
   o->x3_bytes = (int64_t)sizeof(bh_dd_piece) * kDescPerRank;
   o->top_base = rec_cap;
-  o->seg_base = rec_cap + 2 * top_cap;  // two top trees: remote pass (or the whole tree), own pass
+  o->seg_base = rec_cap + 3 * top_cap;  // three top trees: remote pass (or the whole tree), own pass, whole tree
   o->pool_records = o->seg_base + (long long)world * let_cap + 8;
   o->let_min = let_min;
   o->let_cap = let_cap;
@@ -1826,6 +1832,8 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   d->pool_records = pool_records;
   d->top_base = (int)sz.top_base;
   d->top_base2 = (int)sz.top_base + kTopCap;
+  d->top_base3 = (int)sz.top_base + 2 * kTopCap;
+  d->split_pct = 100;
   d->seg_base = (int)sz.seg_base;
   size_t fl = (size_t)n_cap;
   if ((size_t)world * mig_cap > fl) fl = (size_t)world * mig_cap;
@@ -1850,6 +1858,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipEventCreateWithFlags(&d->ev_x3, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_own, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_top1, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&d->ev_x4, hipEventDisableTiming) == hipSuccess;
   {
     int least = 0, greatest = 0;
     ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
@@ -2108,6 +2117,12 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
   return BH_OK;
 }
 
+int bh_dd_set_split_percent(bh_ctx* c, int pct) {
+  if (!c || !c->dd || pct < 1 || pct > 100) return BH_ERR_BAD_ARG;
+  c->dd->split_pct = pct;
+  return BH_OK;
+}
+
 int bh_dd_set_serial(bh_ctx* c, int on) {
   if (!c || !c->dd) return BH_ERR_BAD_ARG;
   c->dd->serial = on != 0;
@@ -2139,7 +2154,13 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
                                             c->info, 1);
   BH_HIP(c, hipGetLastError());
   BH_HIP(c, hipEventRecord(d->ev_top1, so));  // the remote pass re-emits from this tree's scratch
-  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, so, c->acc));
+  // Partial two-pass step (split_pct < 100): only the first bodies' walk is split — their own pass lasts as long as
+  // the LET export and X4 take —, the others wait for X4 and are walked in ONE pass: the exchange is hidden and the
+  // price of two passes (a second drain, the top levels twice) is paid for a fraction of the bodies.
+  d->own_hi = d->split_pct >= 100 ? c->n : (int)((long long)c->n * d->split_pct / 100) / 256 * 256;
+  if (d->own_hi > 0) BH_HIP(c, bhk_force_root(c, 0, d->own_hi, d->top_base2, so, c->acc));
+  if (d->own_hi < c->n)  // (bh_dd_download adds the two partial accelerations: none of a remote pass beyond own_hi)
+    BH_HIP(c, hipMemsetAsync(d->acc2 + d->own_hi, 0, (size_t)(c->n - d->own_hi) * sizeof(float4), so));
   BH_HIP(c, hipEventRecord(d->ev_own, so));
   return BH_OK;
 }
@@ -2167,6 +2188,11 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
         (const bh_dd_piece*)gathered_x3, d->rank, d->pool, d->top_base, d->seg_base, stride, c->bounds, c->p.G,
         c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + kTopCap, d->top_b + kTopCap,
         d->top_ci + kTopCap, d->ddi, 2);
+    if (d->own_hi < c->n)  // the bodies beyond own_hi walk the whole stitched tree: every piece real
+      dd_top_emit_kernel<<<(kTopCap + 255) / 256, 256, 0, c->stream>>>(
+          (const bh_dd_piece*)gathered_x3, d->rank, d->pool, d->top_base3, d->seg_base, stride, c->bounds, c->p.G,
+          c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + kTopCap, d->top_b + kTopCap,
+          d->top_ci + kTopCap, d->ddi, 0);
   } else {
     dd_top_kernel<<<1, 1024, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
                                              d->top_base, d->seg_base, stride, c->bounds, c->p.G, c->p.theta,
@@ -2184,7 +2210,27 @@ static int dd_force_impl(bh_ctx* c, bool allow_fuse) {
   // The last pass of the step also integrates the bodies and folds this rank's min / max (large local body counts:
   // force_mixed_kernel FUSE) — in the two-pass form it then starts after the own pass, whose accelerations it adds.
   bool fused = false;
-  if (d->split) {  // remote pass -> acc2; acc + acc2 is integrated once the own pass has finished too
+  if (d->split && d->own_hi < c->n) {
+    // partial two-pass step: the remote pass of bodies [0, own_hi) follows their own pass on the side stream (low
+    // priority: its workgroups fill what the other launch leaves), the one pass of the rest runs on the main stream;
+    // both integrate their bodies and share one min / max fold (fold_groups)
+    const int groups = (c->n + 63) / 64;
+    hipStream_t so = d->serial ? c->stream : d->stream_own;
+    bool f1 = false, f2 = false;
+    BH_HIP(c, hipEventRecord(d->ev_x4, c->stream));  // X4, the validation and both top trees are complete here
+    BH_HIP(c, hipStreamWaitEvent(so, d->ev_x4, 0));
+    if (d->own_hi > 0)
+      BH_HIP(c, bhk_force_root(c, 0, d->own_hi, d->top_base, so, d->acc2, c->acc, allow_fuse, &f1, groups));
+    BH_HIP(c, hipEventRecord(d->ev_own, so));
+    BH_HIP(c, bhk_force_root(c, d->own_hi, c->n, d->top_base3, c->stream, c->acc, nullptr,
+                             allow_fuse && (f1 || d->own_hi == 0), &f2, groups));
+    BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_own, 0));
+    // (both launches take the fused instance or neither: the same conditions decide — a mixed outcome would leave
+    // some bodies integrated and the others not)
+    if (d->own_hi > 0 && f1 != f2) return BH_ERR_BAD_ARG;
+    fused = f2;
+    c->acc2 = d->acc2;
+  } else if (d->split) {  // remote pass -> acc2; acc + acc2 is integrated once the own pass has finished too
     BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_own, 0));
     BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, d->acc2, c->acc, allow_fuse, &fused));
     c->acc2 = d->acc2;
@@ -2302,38 +2348,53 @@ int bh_dd_walk_stats(bh_ctx* c, int which, bh_walk_stats* out) {
 }
 
 // Measurement only (two-pass steps): the force passes of this rank re-launched over the pool as the last step left it,
-// with nothing else on the GPU — ms[0] the own-pieces pass alone, ms[1] the remote pass alone, ms[2] both at once
-// (own pass on the side stream, remote pass on the main stream: first launch to last completion).  Overwrites the
-// partial accelerations; the bodies are not touched.
-int bh_dd_pass_times(bh_ctx* c, float ms[3]) {
+// with nothing else on the GPU (the second of two rounds: caches warm).  Full two-pass step: ms[0] the own-pieces pass
+// alone, ms[1] the remote pass alone, ms[2] both at once (own pass on the side stream, remote pass on the main stream:
+// first launch to last completion), ms[3] = 0.  Partial step (split_pct < 100): ms[0] own pass of the split part,
+// ms[1] its remote pass, ms[2] the one pass of the other bodies, ms[3] those two at once on two streams, as the step
+// runs them.  Overwrites the partial accelerations; the bodies are not touched.
+int bh_dd_pass_times(bh_ctx* c, float ms[4]) {
   if (!c || !c->dd || !ms) return BH_ERR_BAD_ARG;
   bh_dd_state* d = c->dd;
   if (!(c->ever & BH_ST_FORCE) || !d->split) return BH_ERR_ORDER;
   BH_HIP(c, hipSetDevice(c->device));
-  hipEvent_t e[4];
-  for (int k = 0; k < 4; k++) BH_HIP(c, hipEventCreate(&e[k]));
+  hipEvent_t e[5];
+  for (int k = 0; k < 5; k++) BH_HIP(c, hipEventCreate(&e[k]));
   BH_HIP(c, hipStreamSynchronize(c->stream));
   BH_HIP(c, hipStreamSynchronize(d->stream_own));
-  for (int rep = 0; rep < 2; rep++) {  // (the first round warms the caches)
+  const bool partial = d->own_hi < c->n;
+  const int oh = partial ? d->own_hi : c->n;
+  ms[0] = ms[1] = ms[2] = ms[3] = 0.0f;
+  for (int rep = 0; rep < 2; rep++) {
     BH_HIP(c, hipEventRecord(e[0], c->stream));
-    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, c->stream, c->acc));
+    if (oh > 0) BH_HIP(c, bhk_force_root(c, 0, oh, d->top_base2, c->stream, c->acc));
     BH_HIP(c, hipEventRecord(e[1], c->stream));
-    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, d->acc2));
+    if (oh > 0) BH_HIP(c, bhk_force_root(c, 0, oh, d->top_base, c->stream, d->acc2));
     BH_HIP(c, hipEventRecord(e[2], c->stream));
+    if (partial) BH_HIP(c, bhk_force_root(c, oh, c->n, d->top_base3, c->stream, c->acc));
+    BH_HIP(c, hipEventRecord(e[3], c->stream));
     BH_HIP(c, hipStreamSynchronize(c->stream));
   }
   BH_HIP(c, hipEventElapsedTime(&ms[0], e[0], e[1]));
   BH_HIP(c, hipEventElapsedTime(&ms[1], e[1], e[2]));
+  if (partial) BH_HIP(c, hipEventElapsedTime(&ms[2], e[2], e[3]));
+  // two launches at once: the first on the low-priority side stream, the second on the main stream
   BH_HIP(c, hipEventRecord(e[0], c->stream));
   BH_HIP(c, hipStreamWaitEvent(d->stream_own, e[0], 0));
-  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, d->stream_own, c->acc));
-  BH_HIP(c, hipEventRecord(e[3], d->stream_own));
-  BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, d->acc2));
-  BH_HIP(c, hipStreamWaitEvent(c->stream, e[3], 0));
+  if (partial) {
+    if (oh > 0) BH_HIP(c, bhk_force_root(c, 0, oh, d->top_base, d->stream_own, d->acc2));
+    BH_HIP(c, hipEventRecord(e[4], d->stream_own));
+    BH_HIP(c, bhk_force_root(c, oh, c->n, d->top_base3, c->stream, c->acc));
+  } else {
+    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base2, d->stream_own, c->acc));
+    BH_HIP(c, hipEventRecord(e[4], d->stream_own));
+    BH_HIP(c, bhk_force_root(c, 0, c->n, d->top_base, c->stream, d->acc2));
+  }
+  BH_HIP(c, hipStreamWaitEvent(c->stream, e[4], 0));
   BH_HIP(c, hipEventRecord(e[1], c->stream));
   BH_HIP(c, hipStreamSynchronize(c->stream));
-  BH_HIP(c, hipEventElapsedTime(&ms[2], e[0], e[1]));
-  for (int k = 0; k < 4; k++) (void)hipEventDestroy(e[k]);
+  BH_HIP(c, hipEventElapsedTime(&ms[partial ? 3 : 2], e[0], e[1]));
+  for (int k = 0; k < 5; k++) (void)hipEventDestroy(e[k]);
   return BH_OK;
 }
 

@@ -1200,8 +1200,10 @@ __global__ __launch_bounds__(512) BH_WALK_SGPRS void force_coop_kernel(const flo
   extern __shared__ __attribute__((aligned(16))) u32 coop_lds[];
   const int K = (int)(blockDim.x >> 6);
   const int g = block_chunk(xcd_mode);  // one group per workgroup
-  coop_group<FUSE, SUBSH, TRACE>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, lo, hi,
-                                 eps2, info, g, group, fz, g * K, root);
+  // (lo is a multiple of the group size: lo / group + g is the group's index among all groups of the context — what
+  // the fused epilogue files its rows under when several launches share one fold, bhk_force_root)
+  coop_group<FUSE, SUBSH, TRACE>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, 0, hi,
+                                 eps2, info, lo / group + g, group, fz, g * K, root);
 }
 
 // A launch that fills the GPU many times over still ends with one wave lifetime (~0.35 ms at 1M bodies) in which no
@@ -1223,7 +1225,8 @@ template <bool FUSE, int SUBSH, bool BUDGET = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                           float4* __restrict__ acc, int hi, float eps2, int xcd_mode,
                                                           bh_devinfo* __restrict__ info, int nbulk, int gb,
-                                                          bh_fuse_args fz, int root = 0) {
+                                                          bh_fuse_args fz, int root = 0, int g0 = 0) {
+  // g0: the launch covers the groups g0 .. of the context (bodies [64 g0, hi)), gb of them by one wave each
   __shared__ __attribute__((aligned(16))) u32 coop_lds[coop_lds_bytes(kMixedK, SUBSH) / 4];
   const int lane = threadIdx.x & 63;
   const int wib = rfl((int)(threadIdx.x >> 6));
@@ -1231,13 +1234,14 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
     // (XCD placement of the tail as of the bulk: runs of kTailRun consecutive groups per XCD; nbulk is a multiple of
     // eight in mode 2, so a workgroup's XCD is also that of its index in the tail)
     const int t = block_chunk_of<kTailRun>(xcd_mode == 2 ? 2 : 1, (int)blockIdx.x - nbulk, 0);
-    coop_group<FUSE, SUBSH, TRACE>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, gb + t, 64, fz,
-                                   gb + t * kMixedK, root);
+    coop_group<FUSE, SUBSH, TRACE>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, g0 + gb + t, 64,
+                                   fz, gb + t * kMixedK, root);
     return;
   }
-  const int w = block_chunk_of<kMixedRun>(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group
-  if (w >= gb) return;
-  const int i = w * 64 + lane;  // (groups below gb are full: gb * 64 <= hi)
+  const int wl = block_chunk_of<kMixedRun>(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group in the launch
+  if (wl >= gb) return;
+  const int w = g0 + wl;
+  const int i = w * 64 + lane;  // (groups below gb are full: (g0 + gb) * 64 <= hi)
   const u32 tr0 = TRACE ? (u32)__builtin_amdgcn_s_memrealtime() : 0u;
   const float4 p = posm[i];  // ref:196
   float px = p.x, py = p.y, pz = p.z;
@@ -1254,7 +1258,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
   }
   if (limit && lane == 0) atomicOr(&info->flags, BH_FLAG_TRAVERSAL_LIMIT);
   acc[i] = make_float4(ax, ay, az, 0.0f);  // ref:222-224
-  if (TRACE && lane == 0) trace_row(fz.trace, w, tr0);
+  if (TRACE && lane == 0) trace_row(fz.trace, wl, tr0);
   if (FUSE) fuse_integrate_and_fold(fz, w, i, true, lane, px, py, pz, p.w, ax, ay, az);
 }
 
@@ -1688,7 +1692,9 @@ hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows /* [bhk_force_walk_rows][BH
 // accelerations (null pointer value (float4*)1: there were none), integrates the bodies and folds this rank's min / max
 // into c->dd_minmax (force_mixed_kernel FUSE); *fused tells whether it did (large local body counts only).
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream, float4* acc, const float4* fuse_add,
-                          bool fuse, bool* fused) {
+                          bool fuse, bool* fused, int fold_groups) {
+  // fold_groups: a step whose bodies are covered by SEVERAL fused launches (partial two-pass step: bh_dd.hip) shares
+  // one min / max fold between them — the number of groups of all of them (0: this launch alone)
   if (fused) *fused = false;
   if (hi <= lo) return hipSuccess;
   int tpb = c->p.force_block;
@@ -1700,51 +1706,50 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   // a wave pops one child block per opened cell: no wave of a well-formed pool can pop more blocks than
   // the pool has records, so this bound never fires on valid data and always ends a walk over a cycle
   const int budget = kTraversalBudget;
+  const bool aligned = lo % 256 == 0;  // the launch's groups are the context's groups
+  const long long G = ((long long)(hi - lo) + 63) / 64;  // groups of this launch
+  const long long Gall = fold_groups > 0 ? fold_groups : G;
+  const bool can_fuse = fuse && fused && (fold_groups > 0 || (lo == 0 && hi == c->n)) && (int)Gall <= c->fuse_waves;
+  bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
+                  c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->dd_minmax, (int)Gall};
+  fz.acc_add = fuse_add;
+  fz.raw = 1;
   // big jobs first, short jobs last (force_mixed_kernel), as in bh_step: every pass of the domain-decomposed step is
   // a launch with its own drain
-  if (c->p.force_variant == 0 && c->p.force_coop == 0 && lo == 0 && group == 64 &&
-      (long long)(hi + 63) / 64 > 2 * force_tail_groups(c)) {
-    const long long G = ((long long)hi + 63) / 64;
+  if (c->p.force_variant == 0 && c->p.force_coop == 0 && aligned && group == 64 && G > 2 * force_tail_groups(c)) {
     const int gb = (int)((G - force_tail_groups(c)) & ~3ll), tail = (int)(G - gb);
     const int mmode = resolve_xcd_mode(c, gb * 64, 64);
     int nbulk = gb / 4;
     if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
-    if (fuse && fused && hi == c->n && (int)G <= c->fuse_waves) {
-      bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
-                      c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->dd_minmax, (int)G};
-      fz.acc_add = fuse_add;
-      fz.raw = 1;
+    if (can_fuse) {
       force_mixed_kernel<true, 11, true><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, stream>>>(
-          (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, fz, root);
+          (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, fz, root, lo / 64);
       *fused = true;
       return hipGetLastError();
     }
     force_mixed_kernel<false, 11, true><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, stream>>>(
-        (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, bh_fuse_args{}, root);
+        (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, bh_fuse_args{}, root,
+        lo / 64);
     return hipGetLastError();
   }
   // ... and a pass that would not fill the GPU is cooperative throughout (force_coop_kernel from the top-tree root:
-  // the strong-scaling sizes, 1M bodies over 8 ranks = 125,000 per rank), K as in bh_step
-  if (c->p.force_variant == 0 && c->p.force_coop != 1 && lo == 0 && (c->p.force_group == 0 || c->p.force_group == 64)) {
-    const long long G = ((long long)hi + 63) / 64;
+  // the strong-scaling sizes, 1M bodies over 8 ranks = 125,000 per rank; the first part of a partial two-pass step),
+  // K as in bh_step
+  if (c->p.force_variant == 0 && c->p.force_coop != 1 && aligned && (c->p.force_group == 0 || c->p.force_group == 64)) {
     const int K = c->p.force_coop >= 2 && c->p.force_coop <= kCoopMaxK
                       ? c->p.force_coop
                       : (G * kCoopMaxK <= (long long)c->num_cus * 4 * kWalkWaves ? kCoopMaxK : 4);
-    const int cmode = resolve_xcd_mode(c, hi, 64);
+    const int cmode = resolve_xcd_mode(c, hi - lo, 64);
     int gc = (int)G;
     if (cmode == 2) gc = (gc + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
-    if (fuse && fused && hi == c->n && (int)G <= c->fuse_waves) {
-      bh_fuse_args fz{c->posm[c->cur], c->velid[c->cur], c->p.dt,       c->p.max_speed, c->fuse_rows,
-                      c->fuse_rows + (size_t)c->fuse_waves * 6, c->fuse_cnt, c->dd_minmax, (int)G};
-      fz.acc_add = fuse_add;
-      fz.raw = 1;
+    if (can_fuse) {
       force_coop_kernel<true, 11><<<gc, K * 64, coop_lds_bytes(K, 11), stream>>>(
-          (const float*)c->frec, c->posm[c->cur], acc, 0, hi, c->p.eps2, cmode, c->info, 64, fz, root);
+          (const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.eps2, cmode, c->info, 64, fz, root);
       *fused = true;
       return hipGetLastError();
     }
     force_coop_kernel<false, 11><<<gc, K * 64, coop_lds_bytes(K, 11), stream>>>(
-        (const float*)c->frec, c->posm[c->cur], acc, 0, hi, c->p.eps2, cmode, c->info, 64, bh_fuse_args{}, root);
+        (const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.eps2, cmode, c->info, 64, bh_fuse_args{}, root);
     return hipGetLastError();
   }
   if (c->p.force_variant == 1)

@@ -300,7 +300,7 @@ hipError_t bhk_force(bh_ctx* c, int lo, int hi, bool count, bool fuse_integrate 
 bool bhk_force_range_aligned(const bh_ctx* c, int lo);  // a slab starting at lo forms the full launch's groups
 hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t stream, float4* acc,
                           const float4* fuse_add = nullptr, bool fuse = false,
-                          bool* fused = nullptr);  // fast kernel from pool record `root`
+                          bool* fused = nullptr, int fold_groups = 0);  // fast kernel from pool record `root`
 hipError_t bhk_force_walk_stats(bh_ctx* c, u32* rows, int root = 0);  // measurement: per-wave event counters of the fast walk
 int bh_walk_stats_from(bh_ctx* c, int root, bh_walk_stats* out);       // bh_api.hip: that launch + its reduction on the host
 int bhk_force_walk_rows(const bh_ctx* c);               // waves (rows) of that launch

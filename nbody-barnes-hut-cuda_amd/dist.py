@@ -285,7 +285,7 @@ class DomainStepper:
     negotiation, retries, collective failure) runs inside the library (bh_rank_step, csrc/bh_group.hip)."""
 
     def __init__(self, pkg, ic, comm, device, stream=None, params=None, slack=1.3, mig_frac=0.5,
-                 let_cap=None, order=None, split=None, let_mode=None, mig_log=False, **kw):
+                 let_cap=None, order=None, split=None, let_mode=None, mig_log=False, split_pct=0, **kw):
         L = _lib()
         self.pkg, self.comm = pkg, comm
         if split is None:
@@ -310,6 +310,7 @@ class DomainStepper:
         if let_cap:
             o.let_cap = int(let_cap)
         o.let_mode, o.split, o.log = self.let_mode, int(self.split), int(bool(mig_log))
+        o.split_pct = int(split_pct)
         o.serial = int(isinstance(comm, LocalComm))   # ranks of one process on one GPU: no side stream (bh_dd_set_serial)
         self.params = params if params is not None else pkg.default_params(**kw)
         plan = L.BhRankPlan()

@@ -41,10 +41,11 @@ static double now_ms() {
 
 // the frame loop of main() (ref:353-367) over bh_step_group: every rank steps, then the whole node is synchronised
 static int run_group(int N, int frames, int warmup, bool quiet, const bh_params& p, const std::vector<int>& devs,
-                     int split, const char* ic_name, std::vector<float>* a, const char* dump_path, const char* snap_path) {
+                     int split, int split_pct, const char* ic_name, std::vector<float>* a, const char* dump_path, const char* snap_path) {
   bh_rank_opts o;
   bh_rank_default_opts(&o);
   o.split = split;
+  o.split_pct = split_pct;
   bh_group* g = nullptr;
   CK(bh_create_group(&g, (int)devs.size(), devs.data(), N, &p, &o, 0));
   CK(bh_group_upload(g, a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data(), a[6].data()));
@@ -102,7 +103,7 @@ int main(int argc, char** argv) {
   int N = 500000;  // ref:31
   int gpus = 0;
   bool dist = false;
-  int split = -1;
+  int split = -1, split_pct = 0;
   std::vector<int> devs;
   int frames = 1000;  // ref:353
   int warmup = 0;
@@ -134,6 +135,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--dist")) dist = true;
     else if (!strcmp(argv[i], "--split")) split = 1;
     else if (!strcmp(argv[i], "--one-pass")) split = 0;
+    else if (arg("--split-pct")) split_pct = atoi(argv[++i]);
     else if (arg("--dump")) dump_path = argv[++i];
     else if (arg("--snapshot")) snap_path = argv[++i];
     else if (!strcmp(argv[i], "--literal-force")) p.literal_force = 1;  // what the CUDA binary computes (D1)
@@ -158,7 +160,7 @@ int main(int argc, char** argv) {
     if (devs.empty())
       for (int q = 0; q < (gpus > 0 ? gpus : 1); q++) devs.push_back(device + q);
     std::vector<float> a[7] = {x, y, z, vx, vy, vz, m};
-    return run_group(N, frames, warmup, quiet, p, devs, split,
+    return run_group(N, frames, warmup, quiet, p, devs, split, split_pct,
                      plummer ? "plummer" : (msvc ? "disc(msvc rand)" : "disc"), a, dump_path, snap_path);
   }
 

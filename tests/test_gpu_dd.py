@@ -78,18 +78,22 @@ def rel(a, b):
     return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, 100])
 @pytest.mark.parametrize("let_mode", [0, 1])
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_dd_first_step_matches_single_context(world, let_mode, split):
     """let_mode 0: X4 = all-gather of the union of what any rank may open; 1 (default): per-destination segments
     exchanged with an all-to-all — a receiver holds only what its own boxes can open, the rest arrives closed.
-    split: one force pass after X4 (default) / own pieces on a side stream while X4 travels, then the remote pass"""
+    split: False = one force pass after X4; True = the default two-pass form (the first 30 % of a rank's bodies: own
+    pieces on a side stream while X4 travels, then the remote pass; the rest in one pass after X4); 100 = every body in
+    two passes"""
+    kw = dict(split_pct=100) if split == 100 and split is not True else {}
+    split = bool(split)
     pkg = bhpkg.load()
     n = 60000
     ic = pkg.plummer(n, seed=7)
     p1, v1, a1 = single(ic, 1)
-    out = run_ranks(world, ic, 1, let_mode=let_mode, split=split)
+    out = run_ranks(world, ic, 1, let_mode=let_mode, split=split, **kw)
     p, v, a = merge(out, n)
     e = rel(a, a1)
     # same accepted sets; fp32 summation order differs (top tree first, segments interleaved)
@@ -99,20 +103,49 @@ def test_dd_first_step_matches_single_context(world, let_mode, split):
     assert np.abs(p - p1).max() < 1e-3
 
 
-@pytest.mark.parametrize("world,split,let_mode", [(2, True, 1), (4, True, 1), (4, False, 1), (4, True, 0), (3, False, 0)])
+@pytest.mark.parametrize("world,split,let_mode", [(2, True, 1), (4, True, 1), (4, 100, 1), (4, False, 1), (4, True, 0), (3, False, 0)])
 def test_dd_many_steps_conserve_and_track(world, split, let_mode):
-    """split: two-pass force (own pieces on a side stream while X4 is in flight + remote pieces)"""
+    """split: two-pass force (own pieces on a side stream while X4 is in flight + remote pieces; 100: for every body)"""
+    kw = dict(split_pct=100) if split == 100 else {}
+    split = bool(split)
     pkg = bhpkg.load()
     n = 40000
     ic = pkg.plummer(n, seed=11)
     steps = 12
     p1, v1, a1 = single(ic, steps)
-    out = run_ranks(world, ic, steps, split=split, let_mode=let_mode)
+    out = run_ranks(world, ic, steps, split=split, let_mode=let_mode, **kw)
     p, v, a = merge(out, n)     # also checks that migration lost / duplicated nobody
     assert sum(o[-1] for o in out) == n
     assert np.abs(p - p1).max() < 5e-2, np.abs(p - p1).max()
     e = rel(a, a1)
     assert np.median(e) < 1e-4, np.median(e)
+
+
+@pytest.mark.parametrize("world,pct,n,steps", [(3, 25, 60000, 1), (8, 25, 60000, 1), (8, 60, 160000, 5), (2, 10, 40000, 12),
+                                                 (4, 25, 6000, 3)])
+def test_dd_partial_two_pass_step(world, pct, n, steps):
+    """split_pct < 100: only the first pct per cent of a rank's bodies are walked in two passes (their own pass hides
+    the LET export and X4), the others in ONE pass after X4 — the remote pass of the first part on the side stream at
+    the same time, both launches integrating their bodies and sharing one min / max fold.  Same canonical tree, same
+    accepted sets: forces to summation order, as the other two forms (the last case: ranks so small that the split
+    part rounds to nothing or to everything)."""
+    pkg = bhpkg.load()
+    ic = pkg.plummer(n, seed=13)
+    p1, v1, a1 = single(ic, steps)
+    out = run_ranks(world, ic, steps, split=True, split_pct=pct)
+    p, v, a = merge(out, n)
+    assert sum(o[-1] for o in out) == n
+    e = rel(a, a1)
+    if steps == 1:
+        assert np.median(e) < 2e-6 and np.quantile(e, 0.9999) < 1e-4 and e.max() < 2e-3, (np.median(e), e.max())
+        assert np.abs(p - p1).max() < 1e-3
+    else:
+        assert np.median(e) < 1e-4, np.median(e)
+        assert np.abs(p - p1).max() < 5e-2, np.abs(p - p1).max()
+    # and against the full two-pass form: the bodies of the split part get the same bits (same two launches' order)
+    out2 = run_ranks(world, ic, steps, split=True, split_pct=100)
+    p2, v2, a2 = merge(out2, n)
+    assert np.abs(p - p2).max() < (1e-3 if steps == 1 else 5e-2)
 
 
 def test_dd_per_destination_let_is_smaller_and_equivalent():

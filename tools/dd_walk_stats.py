@@ -12,11 +12,12 @@ ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--n", type=int, default=8_000_000)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--split", action="store_true")
+ap.add_argument("--split-pct", type=int, default=0)
 a = ap.parse_args()
 pkg = bhpkg.load()
 from nbody_barnes_hut_cuda_amd import _lib as L
 ic = pkg.plummer(a.n, seed=42)
-o = L.BhRankOpts(); L.lib.bh_rank_default_opts(C.byref(o)); o.split = int(a.split)
+o = L.BhRankOpts(); L.lib.bh_rank_default_opts(C.byref(o)); o.split = int(a.split); o.split_pct = a.split_pct
 g = C.c_void_p()
 dev = (C.c_int * a.world)(*([0] * a.world))
 assert L.lib.bh_create_group(C.byref(g), a.world, dev, a.n, None, C.byref(o), 0) == 0
@@ -38,12 +39,14 @@ for q in range(a.world):
         t = tot.setdefault(name, [0, 0, 0])
         t[0] += ws.waves; t[1] += ws.blocks; t[2] += ws.pairs
 if a.split:
-    print("rank   own pass alone ms   remote pass alone ms   both at once ms (two streams)")
+    part = 0 < a.split_pct < 100
+    print("rank   own pass alone ms   remote pass alone ms   " + ("one pass of the other bodies   that and the remote pass at once"
+                                                                   if part else "both at once ms (two streams)"))
     for q in range(a.world):
         ctx = L.lib.bh_rank_ctx(L.lib.bh_group_rank(g, q))
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 4)()
         assert L.lib.bh_dd_pass_times(ctx, ms) == 0
-        print(f"{q:4d} {ms[0]:14.3f} {ms[1]:20.3f} {ms[2]:18.3f}")
+        print(f"{q:4d} {ms[0]:14.3f} {ms[1]:20.3f} {ms[2]:18.3f}" + (f" {ms[3]:30.3f}" if part else ""))
 for k, t in tot.items():
     print(f"all ranks, {k}: blocks/wave {t[1] / t[0]:.1f} pairs/wave {t[2] / t[0]:.1f}")
 L.lib.bh_destroy_group(g)
