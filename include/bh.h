@@ -420,7 +420,8 @@ typedef struct bh_rank_opts {
   int32_t mig_cap;  /* emigrant slots of the X2 buffers; 0 = min(max(4096, n_cap / 2), 4 n_cap / world)        */
   int32_t let_cap;  /* records per LET segment; 0 = 516 + n_cap                                                */
   int32_t let_mode; /* X4: 1 = per-destination segments, all-to-all (default); 0 = one union segment, all-gather */
-  int32_t split;    /* -1 = automatic (default): 1 when world > 1, else 0;  0 = one force pass after X4;  1 = two passes
+  int32_t split;    /* -1 = automatic (default): 1 when world > 1 and the rank's capacity is >= 400,000 bodies (its launches
+                       fill the GPU), else 0;  0 = one force pass after X4;  1 = two passes
                        for the first split_pct per cent of the rank's bodies — own pieces on a side stream while the
                        LET is marked, exported and exchanged, remote pieces after X4 — and one pass after X4 for the
                        rest: X4 leaves the critical path for the price of two passes on a fraction of the bodies   */

@@ -631,7 +631,9 @@ static void rank_common_init(bh_rank* r, const bh_comm* comm, const bh_rank_plan
   r->comm = *comm;
   r->plan = *plan;
   r->o = *o;
-  if (r->o.split < 0) r->o.split = comm->world > 1 ? 1 : 0;  // two passes hide X4; one rank has nothing remote
+  // two passes hide X4 — where a rank's launches fill the GPU: a rank of the strong-scaling sizes (125,000 bodies) runs
+  // three launches of some tens of microseconds each instead of one; one rank has nothing remote
+  if (r->o.split < 0) r->o.split = (comm->world > 1 && plan->n_cap >= 400000) ? 1 : 0;
   r->stride = plan->stride0;
   r->mig_stride = plan->mig_cap < 4096 ? plan->mig_cap : 4096;
   if (o->log) r->log = new (std::nothrow) std::vector<int32_t>();

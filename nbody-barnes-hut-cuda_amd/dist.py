@@ -261,10 +261,11 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
         return e.download_order()
 
 
-# Force passes per step when the caller does not choose: None = the library's rule (bh_rank_opts.split -1): two passes
-# with more than one rank — own pieces on a side stream while the LET is marked, exported and exchanged, then the
-# remote pass (0.78 + 0.47 ms of force kernels against 1.22 for one pass at 8 x 1M, each measured with the GPU to
-# itself: profiles/r05_dd/pass_times.txt; X4 is off the critical path) — and one pass with one rank.
+# Force passes per step when the caller does not choose: None = the library's rule (bh_rank_opts.split -1): with more
+# than one rank and ranks large enough to fill the GPU (capacity >= 400,000 bodies) the walk of the first 30 % of a
+# rank's bodies is split in two passes — own pieces on a side stream while the LET is marked, exported and exchanged,
+# remote pieces after X4, beside the one pass of the other bodies (profiles/r05_dd/split_vs_one_pass.txt) —, else one
+# pass after X4.
 SPLIT_DEFAULT = None
 
 # X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
@@ -290,7 +291,7 @@ class DomainStepper:
         self.pkg, self.comm = pkg, comm
         if split is None:
             split = SPLIT_DEFAULT
-        self.split = (comm.world > 1) if split is None else bool(split)
+        self.split = None if split is None else bool(split)   # None: the library's rule, read back below
         self.let_mode = LET_MODE_DEFAULT if let_mode is None else int(let_mode)
         self.world, self.rank = comm.world, comm.rank
         P, r = self.world, self.rank
@@ -309,7 +310,8 @@ class DomainStepper:
             o.mig_cap = min(max(4096, int(o.n_cap * mig_frac)), 4 * o.n_cap // P)
         if let_cap:
             o.let_cap = int(let_cap)
-        o.let_mode, o.split, o.log = self.let_mode, int(self.split), int(bool(mig_log))
+        o.let_mode, o.log = self.let_mode, int(bool(mig_log))
+        o.split = -1 if self.split is None else int(self.split)
         o.split_pct = int(split_pct)
         o.serial = int(isinstance(comm, LocalComm))   # ranks of one process on one GPU: no side stream (bh_dd_set_serial)
         self.params = params if params is not None else pkg.default_params(**kw)
@@ -317,6 +319,8 @@ class DomainStepper:
         st = L.lib.bh_rank_query(n, P, C.byref(o), C.byref(plan))
         if st != 0:
             raise pkg.BhError(st, "bh_rank_query")
+        if self.split is None:   # (bh_rank_opts.split -1: two passes when the rank's launches fill the GPU)
+            self.split = P > 1 and plan.n_cap >= 400000
         self.stream = stream if stream is not None else torch.cuda.Stream(device)
         bufs = None
         self._buffers = []
