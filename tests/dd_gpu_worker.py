@@ -17,13 +17,15 @@ import bhpkg  # noqa: E402
 
 def main():
     out_path, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    split = {"one": False, "two": True, "auto": None}[sys.argv[4] if len(sys.argv) > 4 else "auto"]
+    split_pct = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     dist.init_process_group("gloo")
     torch.cuda.set_device(0)
     pkg = bhpkg.load()
     from nbody_barnes_hut_cuda_amd import dist as bhdist
     world, rank = dist.get_world_size(), dist.get_rank()
     ic = pkg.plummer(n, seed=21)
-    st = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), 0)
+    st = bhdist.DomainStepper(pkg, ic, bhdist.TorchComm(), 0, split=split, split_pct=split_pct)
     st.step(steps)
     ids, posm, vel, acc = st.local_state()
     flags = st.e.stats().status_flags

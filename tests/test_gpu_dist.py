@@ -100,21 +100,42 @@ def test_bench_two_ranks_domain_fallback_is_collective():
     assert "replicated" in out["config"]["parallelism"]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_domain_stepper_multiprocess_one_gpu(world, tmp_path):
-    """the real multi-process flow of the domain-decomposed step (torch.distributed, one process and
-    one stream per rank) with `world` ranks sharing this one GPU over the gloo backend; rank 0
-    compares the gathered state with a single-context run (tests/dd_gpu_worker.py)"""
+@pytest.mark.parametrize("world,split,pct", [(2, "one", 0), (3, "one", 0), (2, "two", 0), (3, "two", 100), (3, "two", 50)])
+def test_domain_stepper_multiprocess_one_gpu(world, split, pct, tmp_path):
+    """the real multi-process flow of the domain-decomposed step (torch.distributed, one process per rank, every rank
+    with its OWN main and side stream — the in-process tests serialise a rank's launches on one stream) with `world`
+    ranks sharing this one GPU over the gloo backend; one pass, the default partial two-pass form (own pass of the
+    first 30 % beside the LET kernels and X4, then their remote pass beside the one pass of the rest: two launches at
+    once that share one fold) and every body in two passes; rank 0 compares the gathered state with a single-context
+    run (tests/dd_gpu_worker.py)"""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     out = tmp_path / "dd.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dd_gpu_worker.py"), str(out), "60000", "6"]
+           os.path.join(ROOT, "tests", "dd_gpu_worker.py"), str(out), "60000", "6", split, str(pct)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(out.read_text())
     assert res["world"] == world and res["owned_once"] and res["flags"] == 0
+    assert res["max_dpos"] < 5e-2, res
+    assert res["acc_rel_median"] < 1e-4, res
+
+
+def test_domain_stepper_multiprocess_large_ranks_two_launches_at_once(tmp_path):
+    """2 processes x 500,000 bodies: the sizes at which the one pass of the unsplit 70 % is a MIXED launch that starts
+    at a group offset (force_mixed_kernel g0) on the main stream while the remote pass of the first 30 % runs on the
+    side stream — really at once here (own streams per process) — and both integrate into one shared fold"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = tmp_path / "dd.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dd_gpu_worker.py"), str(out), "1000000", "4", "two", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(out.read_text())
+    assert res["world"] == 2 and res["owned_once"] and res["flags"] == 0
     assert res["max_dpos"] < 5e-2, res
     assert res["acc_rel_median"] < 1e-4, res
 
