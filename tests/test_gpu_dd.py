@@ -364,6 +364,48 @@ def test_ranks_given_arbitrary_subsets_of_the_bodies():
     assert np.median(e) < 2e-6 and e.max() < 2e-3, (np.median(e), e.max())
 
 
+def test_group_reupload_starts_from_scratch():
+    """bh_group_upload / bh_dd_upload a second time: the boundaries, counts and drift estimate of the first run mean
+    nothing for the new bodies (round-4 advisor finding: the splitter keys of the old run survived and classified the
+    new bodies under a new cube) — the second run must be bit-identical to the same run in a fresh group."""
+    import ctypes as C
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import _lib as L
+    n, world, K = 80_000, 4, 4
+    ic1 = pkg.plummer(n, seed=2)
+    ic2 = pkg.disc(n, seed=9)          # another distribution under another cube
+    F = L._F
+
+    def run(g, ic):
+        assert L.lib.bh_group_upload(g, *[np.ascontiguousarray(a).ctypes.data_as(F) for a in ic]) == 0
+        assert L.lib.bh_step_group(g, K) == 0 and L.lib.bh_group_sync(g) == 0
+        out = [np.full(n, np.nan, np.float32) for _ in range(6)]
+        assert L.lib.bh_group_download(g, *[a.ctypes.data_as(F) for a in out]) == 0
+        return np.stack(out, 1)
+
+    dev = (C.c_int * world)(*([0] * world))
+    g = C.c_void_p()
+    assert L.lib.bh_create_group(C.byref(g), world, dev, n, None, None, 0) == 0
+    try:
+        run(g, ic1)
+        second = run(g, ic2)
+        info = np.zeros(8, np.int32)
+        L.lib.bh_dd_get_info(L.lib.bh_rank_ctx(L.lib.bh_group_rank(g, 0)), info.ctypes.data_as(C.POINTER(C.c_int32)))
+    finally:
+        L.lib.bh_destroy_group(g)
+    g2 = C.c_void_p()
+    assert L.lib.bh_create_group(C.byref(g2), world, dev, n, None, None, 0) == 0
+    try:
+        fresh = run(g2, ic2)
+        info2 = np.zeros(8, np.int32)
+        L.lib.bh_dd_get_info(L.lib.bh_rank_ctx(L.lib.bh_group_rank(g2, 0)), info2.ctypes.data_as(C.POINTER(C.c_int32)))
+    finally:
+        L.lib.bh_destroy_group(g2)
+    assert np.isfinite(second).all()
+    assert np.array_equal(second, fresh)
+    assert info[2] == info2[2]          # steps in which the boundaries moved: counted from the second upload
+
+
 def test_group_rank_local_failure_releases_the_other_ranks():
     """a rank that fails on its own AFTER the last exchange of a step (here: bh_group_upload never ran, so phase 1
     fails everywhere — and a group whose rank 1 alone was never given bodies) must not leave the other library
