@@ -125,6 +125,7 @@ struct bh_dd_state {
   u32* abs_done;   // ... of dd_absorb_flag_kernel
   int* arrive;     // [64] immigrants per rank of the current round (left at zero by the kernel)
   int absorb_seq;  // sequence number of the last dd_absorb_kernel launch
+  int let_seq;     // ... of the last dd_validate_kernel launch (host[70]: the received X4 headers are in host_rows)
 };
 
 namespace {
@@ -1382,8 +1383,24 @@ __global__ __launch_bounds__(256) void dd_export_pd_kernel(const bh_frec* __rest
 // never opened) and BH_FLAG_DD_LET_INVALID is raised — a malformed or partially written segment then costs a
 // wrong step that the caller is told about, never an out-of-bounds fetch.  (Cycles inside a segment are
 // impossible to rule out locally; the walk's pop budget, BH_FLAG_TRAVERSAL_LIMIT, bounds them.)
+// Block 0 also hands the host what it decides the step on: records 0 .. 3 (header + needs row, 128 bytes) of every
+// received segment go to pinned memory with write-through stores, then a sequence number (bh_dd_let_check polls it).
+// A device-to-host copy command for these 1 KB sat on the stream for 20 us between X4 and this kernel
+// (profiles/r05_dd/step_timeline_world1_rccl.txt).
 __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ pool, int seg_base, int stride,
-                                                          int world, int me, bh_devinfo* __restrict__ info) {
+                                                          int world, int me, bh_devinfo* __restrict__ info,
+                                                          int* __restrict__ host_rows, int* __restrict__ host_seq,
+                                                          int seq) {
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < world * 32; i += 256) {
+      const int q = i >> 5, dw = i & 31;
+      const int v = reinterpret_cast<const int*>(pool)[((size_t)seg_base + (size_t)q * stride) * 8 + dw];
+      __hip_atomic_store(host_rows + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's row words have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)world * stride) return;
   const int q = (int)(t / stride), k = (int)(t - (long long)q * stride);
@@ -1865,7 +1882,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
     ok = ok && hipStreamCreateWithPriority(&d->stream_own, hipStreamNonBlocking, least) == hipSuccess;
   }
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
-  if (ok) memset(d->host, 0, (64 + 8) * sizeof(int));
+  if (ok) memset(d->host, 0, (64 + 8) * sizeof(int));  // [64..67] migration results, [68] their sequence number, [70] X4 headers'
   ok = ok && hipHostMalloc((void**)&d->host_rows, 64 * 32 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->wmask, ((size_t)c->rec_cap + 1 + 64) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->list_e, ((size_t)n_cap + 64) * 4) == hipSuccess;
@@ -2170,18 +2187,17 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
   if (stride < kSegBlocks0 || stride > d->let_cap || (stride & 1)) return BH_ERR_BAD_ARG;
-  // the segment headers (records each rank needed) go to the host for bh_dd_let_check
-  BH_HIP(c, hipMemcpy2DAsync(d->host_rows, 128, reinterpret_cast<const char*>(d->pool) + (size_t)d->seg_base * 32,
-                             (size_t)stride * sizeof(bh_frec), 128, (size_t)d->world, hipMemcpyDeviceToHost,
-                             c->stream));
-  BH_HIP(c, hipEventRecord(d->ev_let, c->stream));
-  d->let_copy_pending = true;
+  // the segment headers (records each rank needed) go to the host for bh_dd_let_check: written to pinned memory by
+  // the validation kernel's first block, announced by a sequence number in d->host[70]
   {
     const long long recs = (long long)d->world * stride;
+    d->let_seq++;
     dd_validate_kernel<<<(unsigned)((recs + 255) / 256), 256, 0, c->stream>>>(d->pool, d->seg_base, stride, d->world,
-                                                                            d->rank, c->info);
+                                                                            d->rank, c->info, d->host_rows,
+                                                                            d->host + 70, d->let_seq);
     BH_HIP(c, hipGetLastError());
   }
+  d->let_copy_pending = true;
   if (d->split) {  // same structure as the own pass's tree: re-emit the records only
     BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_top1, 0));
     dd_top_emit_kernel<<<(kTopCap + 255) / 256, 256, 0, c->stream>>>(
@@ -2250,13 +2266,22 @@ int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts) {
   if (!c || !c->dd) return BH_ERR_BAD_ARG;
   bh_dd_state* d = c->dd;
   if (!d->let_copy_pending) return BH_ERR_ORDER;
-  // (polled: hipEventSynchronize wakes the host tens of microseconds after the event — with one force pass per step
-  // that hole sits on the critical path, between the top tree and the force launch; bounded, then the blocking wait)
+  // (polled pinned word, as the migration's result: a blocking wait wakes the host tens of microseconds late, and this
+  // wait sits between X4 and the force launch; bounded, then the stream wait decides)
   {
-    hipError_t q = hipErrorNotReady;
-    for (long spin = 0; spin < 2000000L && q == hipErrorNotReady; spin++) q = hipEventQuery(d->ev_let);
-    if (q == hipErrorNotReady) q = hipEventSynchronize(d->ev_let);
-    BH_HIP(c, q);
+    volatile int* hs = d->host + 70;
+    bool seen = false;
+    for (long spin = 0; spin < 400000000L; spin++) {
+      if (__atomic_load_n(hs, __ATOMIC_ACQUIRE) == d->let_seq) {
+        seen = true;
+        break;
+      }
+      if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(c->stream) != hipErrorNotReady) break;
+    }
+    if (!seen) {
+      BH_HIP(c, hipStreamSynchronize(c->stream));
+      if (__atomic_load_n(hs, __ATOMIC_ACQUIRE) != d->let_seq) return BH_ERR_HIP;
+    }
   }
   d->let_copy_pending = false;
   // counts[q] = the most records rank q needed for any receiver (its needs row: every rank holds the same matrix,
