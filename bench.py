@@ -538,8 +538,8 @@ def main():
             ws = eng.force_walk_stats()          # the walk's event counters + in-kernel clock, counted now
             props = torch.cuda.get_device_properties(local_rank)
             issue = issue_roofline(ws, 4 * props.multi_processor_count, avg_force_ms)
-            # what the launch does with the GPU's wave slots (7 per SIMD: the walk kernels use 94 scalar registers)
-            issue["residency"] = residency_from_trace(eng.force_launch_trace(), 4 * props.multi_processor_count * 7)
+            # what the launch does with the GPU's wave slots (8 per SIMD: the walk kernels use 80 scalar registers)
+            issue["residency"] = residency_from_trace(eng.force_launch_trace(), 4 * props.multi_processor_count * 8)
             groups = (n_total + 63) // 64
             tail = 4 * props.multi_processor_count * 7 // 3
             if groups > 2 * tail:
@@ -549,7 +549,7 @@ def main():
                           "ones leave")
             else:
                 launch = (f"force_coop_kernel<FUSE> (csrc/bh_force.hip): {groups} groups, "
-                          f"{8 if groups * 8 <= 4 * props.multi_processor_count * 7 else 4} waves per group "
+                          f"{8 if groups * 8 <= 4 * props.multi_processor_count * 8 else 4} waves per group "
                           "(cooperative level-by-level walk)")
             # useful arithmetic of the recurrence (ref:205-213): 20 flop per interaction TAKEN by a body (accepted
             # cells V - O and body interactions P: 3 sub, 5 for d2 + eps2, rsq, 2 for the MAC, 3 for f, 6 for the

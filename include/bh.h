@@ -100,7 +100,7 @@ typedef struct bh_params {
                             64-body groups of the force walk are more compact (-5 % force time).  30-bit keys
                             are always Morton (reference-literal code)                                */
   int32_t force_coop;    /* waves that share the walk of one group of bodies (round 4): 0 = by context size — 8 while
-                            eight per group fit the GPU at once (~57,000 bodies), 4 up to ~305,000 bodies, above that
+                            eight per group fit the GPU at once (65,536 bodies: 8 waves per SIMD), 4 up to ~305,000 bodies, above that
                             one wave per group except for the last ~2,400 groups of the launch, which get four (the
                             short jobs fill the wave slots the long ones leave: DESIGN.md §4) —, 1 = one wave per
                             group throughout (the depth-first walk), 2..8 = that many for every group.  Results are

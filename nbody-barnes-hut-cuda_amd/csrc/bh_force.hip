@@ -25,8 +25,8 @@
 //   * children of a cell are one contiguous, 64-byte-aligned block of digest pairs, so an opened cell costs
 //     two or four back-to-back scalar loads and up to 4 packed pair evaluations;
 //   * blockIdx is remapped (block_chunk) so that the waves of an XCD share parts of the tree in its private L2;
-//   * round 4: a launch is judged by what it does with the GPU's wave slots (bh_force_launch_trace).  The walk lives
-//     in 78 scalar registers (7 waves per SIMD); K waves of one workgroup can share the walk of ONE group level by
+//   * a launch is judged by what it does with the GPU's wave slots (bh_force_launch_trace).  The walk lives in 64
+//     scalar registers — a window of three record pairs — so that a SIMD holds 8 waves of it (round 4: 78 / 7); K waves of one workgroup can share the walk of ONE group level by
 //     level (coop_traverse_asm / force_coop_kernel: launches that do not fill the GPU), and a launch that does fill
 //     it walks its last groups that way so that short jobs fill the slots the long ones leave (force_mixed_kernel).
 // force_kernel<STRICT, COUNT> below is the plain per-record loop on the canonical 32-byte records (bit-exact
@@ -425,15 +425,29 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // Code:  PRO(q) = MAC(q)              entry of a block of 2q+1 or 2q+2 children
 //        SEG(q) = FORCE(q) || MAC(q-1)   q = 3..1;  SEG(0) = FORCE(0);  SEGm(q) = the same with the open masks
 //        ARMS(q)= pushes of pair q, then SEGm(q)
-// Fixed registers inside the block (round 4: everything below s88, see BH_WALK_SGPRS): s[24:87] record window (pair
-// p at s[24+16p..]), s10-s23 state; v[16:17] = (px,py), v[18:19] = (pz,-), v[20:21] = (eps2,eps2); pair sets (even /
-// odd pairs) d = v[22:27] / v[30:35], rinv = v[28:29] / v[36:37]; the open masks live in the window's dead dwords
-// (the `first` fields, which the walk never reads: s[34:35], s[66:67] / s[50:51], s[82:83] — written by v_cmp after
-// the block's loads have landed, dead before the next block's loads are issued); v[38:39] d2, v[40:41] f, v[42:47] six
+// Fixed registers inside the block (everything below s74, see BH_WALK_SGPRS): s[24:71] record window of three pair
+// slots, s[72:73] a mask pair, s10-s23 state; v[16:17] = (px,py), v[18:19] = (pz,-), v[20:21] = (eps2,eps2); pair sets
+// (even / odd pairs) d = v[22:27] / v[30:35], rinv = v[28:29] / v[36:37]; the open masks live in the window's dead
+// dwords (the `first` fields, which the walk never reads) and in s[72:73] — which pair uses which: BH_S0 .. BH_S3
+// below —, written by v_cmp after the records have landed; v[38:39] d2, v[40:41] f, v[42:47] six
 // partial accumulators, v48 / v50 / v51 cross-lane stack (link, mask lo, mask hi), s10 / s[22:23] its top entry;
 // EXEC = the lane mask of the entry in hand, written when the entry is popped.
-#define BH_S0 "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v28", "v29", "s[34:35]", "s[66:67]"
-#define BH_S1 "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v36", "v37", "s[50:51]", "s[82:83]"
+// Round 5: a window of THREE pairs, s[24:71] (pair slots A = s[24:39], C = s[40:55], B = s[56:71]) + one mask pair
+// s[72:73]: the walk ends at s73 and a SIMD holds EIGHT waves of it (tools/ubench_occ.hip; one wave more measured -10 %
+// force time between six and seven, profiles/r05_experiments/).  A block of 7-8 children loads its pairs 3, 2, 1 into
+// A, B, C, evaluates pair 3 first as before, and fetches pair 0 into slot A once pair 3's registers are dead (after
+// the position of its force half's mask instruction); the wait sits in front of pair 0's first use, a segment and
+// a half later.  Each pair's two open masks live where nothing can overwrite them while they are alive:
+//   pair 3: s[34:35] (slot A's dead `first` dwords while pair 3 sits there), s[72:73]
+//   pair 2: s[66:67] (its own dead dwords), s[50:51] (pair 1's: written by pair 1's own compare only later)
+//   pair 1: s[50:51], s[72:73]
+//   pair 0: s[34:35] (after its records have landed), s[66:67]
+#define BH_V0 "v[22:23]", "v[24:25]", "v[26:27]", "v[28:29]", "v28", "v29"
+#define BH_V1 "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v36", "v37"
+#define BH_S0 BH_V0, "s[34:35]", "s[66:67]"  /* pair 0 */
+#define BH_S2 BH_V0, "s[66:67]", "s[50:51]"  /* pair 2 */
+#define BH_S1 BH_V1, "s[50:51]", "s[72:73]"  /* pair 1 */
+#define BH_S3 BH_V1, "s[34:35]", "s[72:73]"  /* pair 3 */
 // MAC of the pair (X, Y, Z, THR0, THR1) into set (DX, DY, DZ, R, R0, R1, MA, MB)
 #define BH_M1(DX, X) "v_pk_add_f32 " DX ", " X ", v[16:17] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
 #define BH_M2(DY, Y) "v_pk_add_f32 " DY ", " Y ", v[16:17] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
@@ -458,16 +472,20 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_FA(D, A) "v_pk_fma_f32 " A ", v[40:41], " D ", " A "\n"
 // (STATS: vcc_lo counts the pairs in which every active lane opens BOTH records — their force half is skipped, BH_ARMS_)
 #define BH_FM(MA, MB) "v_cndmask_b32_e64 v40, v40, 0, " MA "\n v_cndmask_b32_e64 v41, v41, 0, " MB "\n"
-#define BH_SEG_(LBL, MASK, qm, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1) \
-  LBL ":\n"                                                                                               \
-  BH_M1(DX, X) BH_F1(GM, FR) BH_M2(DY, Y) BH_F2(FR) BH_M3(DZ, Z) BH_F3(FR) BH_M4(DX) MASK(FMA, FMB)       \
+// PRE: in front of the segment's first instruction; MID: behind the position of the mask instruction (the last read
+// of pair q's scalar registers) — the late fetch of pair 0 (BH_LATE_LOAD) and the wait for it (BH_LATE_WAIT)
+#define BH_SEG_(LBL, MASK, PRE, MID, qm, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM, DX, DY, DZ, R, R0, R1, MA, MB, X, Y, Z, T0, T1) \
+  LBL ":\n" PRE                                                                                           \
+  BH_M1(DX, X) BH_F1(GM, FR) BH_M2(DY, Y) BH_F2(FR) BH_M3(DZ, Z) BH_F3(FR) BH_M4(DX) MASK(FMA, FMB) MID   \
   BH_M5(DY) BH_FA(FDX, "v[42:43]") BH_M5(DZ) BH_FA(FDY, "v[44:45]") BH_M7(MA, T0) BH_FA(FDZ, "v[46:47]")  \
   BH_M8(MB, T1) BH_M9(R0, R1) BH_CHK(qm, MA, MB)
 #define BH_NOMASK(MA, MB) ""
-#define BH_SEG(q, qm, ...) BH_X(BH_SEG_, "L_seg" #q "_%=", BH_NOMASK, qm, __VA_ARGS__)
+#define BH_LATE_LOAD "s_load_dwordx16 s[24:39], s[20:21], s18 offset:0\n"
+#define BH_LATE_WAIT "s_waitcnt lgkmcnt(0)\n"
+#define BH_SEG(q, qm, PRE, MID, ...) BH_X(BH_SEG_, "L_seg" #q "_%=", BH_NOMASK, PRE, MID, qm, __VA_ARGS__)
 #define BH_STAT_MASKED ".if %c[stats]\n s_add_u32 s15, s15, 1\n .endif\n"
-#define BH_SEGM(q, qm, ...)                                                                              \
-  "L_segm" #q "_%=:\n" BH_STAT_MASKED BH_X(BH_SEG_, "L_segmx" #q "_%=", BH_FM, qm, __VA_ARGS__)           \
+#define BH_SEGM(q, qm, PRE, MID, ...)                                                                    \
+  "L_segm" #q "_%=:\n" BH_STAT_MASKED BH_X(BH_SEG_, "L_segmx" #q "_%=", BH_FM, PRE, MID, qm, __VA_ARGS__) \
   "s_branch L_seg" #qm "_%=\n"
 #define BH_LAST_(LBL, MASK, FDX, FDY, FDZ, FR, FR0, FR1, FMA, FMB, GM)                                   \
   LBL ":\n" BH_F1(GM, FR) BH_F2(FR) BH_F3(FR) MASK(FMA, FMB) BH_FA(FDX, "v[42:43]") BH_FA(FDY, "v[44:45]") \
@@ -567,7 +585,7 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 // Both records opened: if every active lane opens both (a pair high above the group: 3.7 % of all pairs at 1M
 // bodies, bh_walk_stats.no_taker_pairs), nobody takes a monopole and the pair's force half — 6 packed
 // instructions and the two v_cndmask — is skipped: on to the MAC of the next pair (SKIP = its entry) or to the pop.
-#define BH_ARMS_(q, SKIP, MA, MALO, MAHI, MB, MBLO, MBHI, F0, M0, F1, M1)                                 \
+#define BH_ARMS_(q, SKIP, PRESKIP, MA, MALO, MAHI, MB, MBLO, MBHI, F0, M0, F1, M1)                        \
   "L_push" #q "_%=:\n"                                                                                    \
   "s_cmp_eq_u64 " MA ", 0\n"                                                                              \
   "s_cbranch_scc1 L_pushB" #q "_%=\n" BH_PUSH1(F0, M0, MALO, MAHI)                                         \
@@ -577,29 +595,40 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
   "s_xor_b64 s[12:13], s[12:13], exec\n"                                                                  \
   "s_cbranch_scc1 L_segm" #q "_%=\n"                                                                      \
   ".if %c[stats]\n s_add_u32 vcc_lo, vcc_lo, 1\n .endif\n"                                                \
-  "s_branch " SKIP "_%=\n"                                                                                \
+  PRESKIP "s_branch " SKIP "_%=\n"                                                                        \
   "L_pushB" #q "_%=:\n" BH_PUSH1(F1, M1, MBLO, MBHI)                                                      \
   "s_branch L_segm" #q "_%=\n"
-// pair p of the window: x s[24+16p:25+16p], y +2, z +4, gm +6, thr2 +8/+9, first +10/+11 (dead: the open masks), meta +12/+13, link +14/+15
+// a pair slot: x at +0:1, y +2, z +4, gm +6, thr2 +8/+9, first +10/+11 (dead: open masks), meta +12/+13, link +14/+15.
+// Slot A = s[24:39] holds pair 0 — or pair 3 of a block of 7-8 children until pair 0 is fetched behind it —, slot C =
+// s[40:55] pair 1, slot B = s[56:71] pair 2.
 #define BH_P0 "s[24:25]", "s[26:27]", "s[28:29]", "s32", "s33"
 #define BH_P1 "s[40:41]", "s[42:43]", "s[44:45]", "s48", "s49"
 #define BH_P2 "s[56:57]", "s[58:59]", "s[60:61]", "s64", "s65"
-#define BH_P3 "s[72:73]", "s[74:75]", "s[76:77]", "s80", "s81"
+#define BH_P3 BH_P0
 #define BH_PRO_SMALL BH_PRO(0, BH_S0, BH_P0) BH_PRO(1, BH_S1, BH_P1)
-#define BH_PRO_BIG BH_PRO(2, BH_S0, BH_P2) "L_pro3_%=:\n" BH_MAC(3, BH_S1, BH_P3)
+#define BH_PRO_BIG BH_PRO(2, BH_S2, BH_P2) "L_pro3_%=:\n" BH_MAC(3, BH_S3, BH_P3)
 #define BH_SEG_ALL                                                                                       \
-  BH_SEG(3, 2, BH_S1, "s[78:79]", BH_S0, BH_P2) BH_SEG(2, 1, BH_S0, "s[62:63]", BH_S1, BH_P1)             \
-  BH_SEG(1, 0, BH_S1, "s[46:47]", BH_S0, BH_P0) BH_LAST("L_seg0_%=", BH_NOMASK, BH_S0, "s[30:31]")
+  BH_SEG(3, 2, "", BH_LATE_LOAD, BH_S3, "s[30:31]", BH_S2, BH_P2)                                         \
+  BH_SEG(2, 1, "", "", BH_S2, "s[62:63]", BH_S1, BH_P1)                                                   \
+  BH_SEG(1, 0, BH_LATE_WAIT, "", BH_S1, "s[46:47]", BH_S0, BH_P0)                                         \
+  BH_LAST("L_seg0_%=", BH_NOMASK, BH_S0, "s[30:31]")
 #define BH_SEGM_ALL                                                                                      \
-  BH_SEGM(3, 2, BH_S1, "s[78:79]", BH_S0, BH_P2) BH_SEGM(2, 1, BH_S0, "s[62:63]", BH_S1, BH_P1)           \
-  BH_SEGM(1, 0, BH_S1, "s[46:47]", BH_S0, BH_P0)                                                          \
+  BH_SEGM(3, 2, "", BH_LATE_LOAD, BH_S3, "s[30:31]", BH_S2, BH_P2)                                        \
+  BH_SEGM(2, 1, "", "", BH_S2, "s[62:63]", BH_S1, BH_P1)                                                  \
+  BH_SEGM(1, 0, BH_LATE_WAIT, "", BH_S1, "s[46:47]", BH_S0, BH_P0)                                        \
   "L_segm0_%=:\n" BH_STAT_MASKED BH_LAST("L_segmx0_%=", BH_FM, BH_S0, "s[30:31]") BH_POP_TAIL
-#define BH_MK0 "s[34:35]", "s34", "s35", "s[66:67]", "s66", "s67"  // open masks of set 0 (even pairs)
-#define BH_MK1 "s[50:51]", "s50", "s51", "s[82:83]", "s82", "s83"  // set 1 (odd pairs)
+#define BH_MK0 "s[34:35]", "s34", "s35", "s[66:67]", "s66", "s67"  // the open masks of pair 0
+#define BH_MK2 "s[66:67]", "s66", "s67", "s[50:51]", "s50", "s51"  // pair 2
+#define BH_MK1 "s[50:51]", "s50", "s51", "s[72:73]", "s72", "s73"  // pair 1
+#define BH_MK3 "s[34:35]", "s34", "s35", "s[72:73]", "s72", "s73"  // pair 3
 #define BH_ARMS(...) BH_X(BH_ARMS_, __VA_ARGS__)
+// (a pair nobody takes skips its force half: the skip of pair 3 issues the late fetch that half would have issued, the
+// skip of pair 1 waits for it in front of pair 0's entry)
 #define BH_ARMS_ALL                                                                                      \
-  BH_ARMS(3, "L_pro2", BH_MK1, "s86", "s84", "s87", "s85") BH_ARMS(2, "L_pro1", BH_MK0, "s70", "s68", "s71", "s69") \
-  BH_ARMS(1, "L_pro0", BH_MK1, "s54", "s52", "s55", "s53") BH_ARMS(0, "L_tail", BH_MK0, "s38", "s36", "s39", "s37")
+  BH_ARMS(3, "L_pro2", BH_LATE_LOAD, BH_MK3, "s38", "s36", "s39", "s37")                                  \
+  BH_ARMS(2, "L_pro1", "", BH_MK2, "s70", "s68", "s71", "s69")                                            \
+  BH_ARMS(1, "L_pro0", BH_LATE_WAIT, BH_MK1, "s54", "s52", "s55", "s53")                                  \
+  BH_ARMS(0, "L_tail", "", BH_MK0, "s38", "s36", "s39", "s37")
 // end of a block: pop the next one (the test of L_pop folded into the loop-back branch)
 #define BH_POP_TAIL                                                                                      \
   ".if %c[coop]\n s_cmp_eq_u32 s14, 0\n s_cbranch_scc1 L_centry_%=\n s_branch L_cpop_%=\n .else\n"           \
@@ -617,9 +646,6 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
 #define BH_DISPATCH_SMALL                                                                                \
   BH_STAT_WAIT                                                                                           \
   "s_cmp_gt_u32 s19, 2\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro1_%=\n"
-#define BH_DISPATCH_BIG                                                                                  \
-  BH_STAT_WAIT                                                                                           \
-  "s_cmp_gt_u32 s19, 6\n s_waitcnt lgkmcnt(0)\n s_cbranch_scc1 L_pro3_%=\n"
 
 // One child block, from the stack entry in s18 (link) / EXEC (lane mask) to the jump back for the next entry:
 // shared by the depth-first walk (fast_traverse_asm) and the cooperative level-by-level walk (coop_traverse_asm).
@@ -635,23 +661,34 @@ __device__ __forceinline__ bool fast_traverse(cfloat_t* frec, int root, u64 m0, 
       "s_sub_u32 s17, s17, 1\n"                                                                          \
       "s_cbranch_scc1 L_done_%=\n"                                                                       \
       ".endif\n"                                                                                         \
-      "s_load_dwordx16 s[24:39], s[20:21], s18 offset:0\n"                                               \
-      "s_load_dwordx16 s[40:55], s[20:21], s18 offset:64\n"                                              \
+      "s_load_dwordx16 s[40:55], s[20:21], s18 offset:64\n"   /* slot C: pair 1 of every block */        \
+      "s_cmp_gt_u32 s19, 6\n"                                                                            \
+      "s_cbranch_scc1 L_four_%=\n"                                                                       \
+      "s_load_dwordx16 s[24:39], s[20:21], s18 offset:0\n"    /* slot A: pair 0 */                       \
       ".if %c[stats]\n"                                                                                  \
       "s_add_u32 s17, s17, 1\n"   /* blocks popped */                                                    \
       "s_add_u32 s11, s19, 1\n"                                                                          \
       "s_lshr_b32 s11, s11, 1\n"                                                                         \
-      "s_min_u32 s11, s11, 4\n"                                                                          \
       "s_add_u32 s16, s16, s11\n"  /* pairs evaluated */                                                 \
       ".endif\n"                                                                                         \
       "s_cmp_gt_u32 s19, 4\n"                                                                            \
       "s_cbranch_scc1 L_big_%=\n"                                                                        \
       BH_DISPATCH_SMALL                                                                                  \
       BH_PRO_SMALL                                                                                       \
-      "L_big_%=:\n"                                                                                      \
+      "L_four_%=:\n"              /* 7-8 children: pair 3 into slot A, pair 0 follows it there (BH_LATE_LOAD) */ \
+      "s_load_dwordx16 s[24:39], s[20:21], s18 offset:192\n"                                             \
       "s_load_dwordx16 s[56:71], s[20:21], s18 offset:128\n"                                             \
-      "s_load_dwordx16 s[72:87], s[20:21], s18 offset:192\n"                                             \
-      BH_DISPATCH_BIG                                                                                    \
+      ".if %c[stats]\n"                                                                                  \
+      "s_add_u32 s17, s17, 1\n"                                                                          \
+      "s_add_u32 s16, s16, 4\n"                                                                          \
+      ".endif\n"                                                                                         \
+      BH_STAT_WAIT                                                                                       \
+      "s_waitcnt lgkmcnt(0)\n"                                                                           \
+      "s_branch L_pro3_%=\n"                                                                             \
+      "L_big_%=:\n"               /* 5-6 children */                                                     \
+      "s_load_dwordx16 s[56:71], s[20:21], s18 offset:128\n"                                             \
+      BH_STAT_WAIT                                                                                       \
+      "s_waitcnt lgkmcnt(0)\n"                                                                           \
       BH_PRO_BIG                                                                                         \
       BH_SEG_ALL                                                                                         \
       "L_tail_%=:\n"                                                                                     \
@@ -728,8 +765,7 @@ __device__ __forceinline__ bool fast_traverse_asm(const float* frec, int root, u
         "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
         "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
         "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
-        "s85", "s86", "s87", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
+        "s70", "s71", "s72", "s73", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
         "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
         "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
   if (STATS) {
@@ -906,10 +942,11 @@ __device__ __forceinline__ void trace_row(u32* tr, int row, u32 t0) {
   r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
 }
 
-// BH_WALK_SGPRS: 7 waves per SIMD instead of 6 — a gfx950 SIMD holds floor(800 / (16-aligned SGPR count + 16)) waves
-// (tools/ubench_occ.hip: highest register s72 -> 8 waves, s76 .. s88 -> 7, s92 and above -> 6); the walk's registers
-// end at s87 and the compiler keeps the rest of the kernel below that too
-#define BH_WALK_SGPRS __attribute__((amdgpu_num_sgpr(96)))
+// BH_WALK_SGPRS: a gfx950 SIMD holds floor(800 / (16-aligned SGPR count + 16)) waves (tools/ubench_occ.hip: highest
+// register s72 -> 8 waves, s76 .. s88 -> 7, s92 and above -> 6).  Round 4: the walk in s10 .. s87 -> 7 waves.  Round 5:
+// a three-pair record window, the walk in s10 .. s73, 80 scalar registers for the whole kernel -> 8 waves (the
+// compiler's own values live in VGPR lanes across the walk: 62 spilled SGPRs, 64 VGPRs, no scratch)
+#define BH_WALK_SGPRS __attribute__((amdgpu_num_sgpr(80)))
 template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const float* __restrict__ frec_g,
                                                          const float4* posm,  // (FUSE: fz.posm is the same buffer)
@@ -1107,8 +1144,7 @@ __device__ __forceinline__ bool coop_traverse_asm(const float* frec, u32 cur, u3
         "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39",
         "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",
         "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
-        "s85", "s86", "s87", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
+        "s70", "s71", "s72", "s73", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27",
         "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
         "v43", "v44", "v45", "v46", "v47", "v48", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
   // s16 = the largest child count met (an unsplit cell of thousands of bodies: up to n < 2^29) | bit 30: the wave's
@@ -1401,7 +1437,9 @@ static int force_group(const bh_ctx* c, int bodies) {
   return bodies <= 20 * 1024 ? 16 : (bodies <= 56 * 1024 ? 32 : 64);
 }
 
-constexpr int kWalkWaves = 7;  // resident waves per SIMD of the walk kernels (BH_WALK_SGPRS)
+constexpr int kWalkWaves = 8;  // resident waves per SIMD of the walk kernels (BH_WALK_SGPRS: 80 scalar registers)
+constexpr int kTailWaves = 7;  // ... the cooperative tail of a mixed launch is sized with (round 4's figure; with eight
+                               // the fused 1M launch measures 1.2 % slower, 500k and 2M alike: profiles/r05_experiments/)
 // Groups at the end of a launch that are walked by four waves each (force_mixed_kernel; a launch of fewer groups is
 // cooperative throughout): the short jobs have to refill what the long ones free while they drain — a third of the
 // resident waves' worth of groups, whatever the launch size (same-box sweep at 1M bodies, force ms for 0 / 2,048 /
@@ -1409,7 +1447,7 @@ constexpr int kWalkWaves = 7;  // resident waves per SIMD of the walk kernels (B
 // 500,000 bodies: 0.692 / 0.601 / - / 0.604 / - / 0.605; 2M: 2.252 / 2.187 / - / 2.177 / - / 2.178; theta 0.3 at 1M:
 // 3.533 / 3.245 / - / 3.220 / - / 3.232 — profiles/r04_drain/).
 static long long force_tail_groups(const bh_ctx* c) {
-  long long T = (long long)c->num_cus * 4 * kWalkWaves / 3;
+  long long T = (long long)c->num_cus * 4 * kTailWaves / 3;
 #ifdef BH_STUDY
   static const int env_tail = getenv("BH_FORCE_TAIL") ? atoi(getenv("BH_FORCE_TAIL")) : -1;
   if (env_tail >= 0) T = env_tail;

@@ -8,7 +8,7 @@ pkg = bhpkg.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 theta = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-e = pkg.Engine(n, theta=theta)
+e = pkg.Engine(n, theta=theta, force_coop=int(os.environ.get("BH_COOP", "0")))
 e.upload(*pkg.plummer(n, seed=42))
 e.step(3)
 e.tree_stages()
