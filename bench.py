@@ -15,6 +15,9 @@ import os
 import sys
 import time
 
+# RCCL between processes needs dmabuf IPC on this driver (hipIpcGetMemHandle fails otherwise); harmless at N = 1
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -381,6 +384,8 @@ def main():
         comm, ok = None, 1.0
         try:
             comm = bhdist.RcclComm(local_rank)
+            if not comm.check():   # collective; a transport that misdelivers is as good as none
+                raise RuntimeError("bh_comm_check failed")
         except Exception as ex:  # noqa: BLE001 - decided collectively below
             print(f"[bench rank {rank}] RCCL transport unavailable: {ex!r}", file=sys.stderr, flush=True)
             ok = 0.0

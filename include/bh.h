@@ -407,6 +407,10 @@ typedef struct bh_comm { /* how a rank's buffers travel.  Functions return 0 or 
 int bh_comm_rccl_from(bh_comm* out, void* nccl_comm, int world, int rank);
 int bh_comm_rccl_unique_id(void* id128);
 int bh_comm_rccl_init_rank(bh_comm* out, const void* id128, int world, int rank, int device);
+/* Collective self-test of any transport on the calling thread's current device: one all-gather and one all-to-all
+   of known words, checked on the host.  BH_OK, or BH_ERR_COMM if a call failed or a chunk arrived in the wrong
+   place.  bench.py and bh_bench run it once after building the RCCL transport. */
+int bh_comm_check(const bh_comm* comm);
 /* in-process transport: `world` ranks of one process (host threads), device-to-device copies ordered by events */
 typedef struct bh_hub bh_hub;
 int bh_hub_create(bh_hub** out, int world);

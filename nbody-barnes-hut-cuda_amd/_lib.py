@@ -184,6 +184,7 @@ SYMBOLS = [
     ("bh_comm_rccl_from", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int]),
     ("bh_comm_rccl_unique_id", C.c_int, [_P]),
     ("bh_comm_rccl_init_rank", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int, C.c_int]),
+    ("bh_comm_check", C.c_int, [C.POINTER(BhComm)]),
     ("bh_hub_create", C.c_int, [C.POINTER(_P), C.c_int]),
     ("bh_comm_hub", C.c_int, [C.POINTER(BhComm), _P, C.c_int]),
     ("bh_hub_abort", None, [_P]),

@@ -2339,9 +2339,10 @@ int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* c
       if (fits) *fits = 0;
       return counts == own_counts ? BH_ERR_DOMAIN_LEFT : BH_OK;
     }
-  // (one rank: the remote pass walks nothing but the top record, and a launch that short integrates slower than the
-  // streaming kernel does — 0.100 against 0.055 + 0.021 ms at 1M bodies)
-  return dd_force_impl(c, c->dd->world > 1);
+  // (one rank in two passes: the remote pass walks nothing but the top record, and a launch that short integrates
+  // slower than the streaming kernel does — 0.100 against 0.055 + 0.021 ms at 1M bodies; one pass integrates as
+  // bh_step's launch does)
+  return dd_force_impl(c, c->dd->world > 1 || !c->dd->split);
 }
 
 int bh_dd_phase_end(bh_ctx* c, void* send_x1) {

@@ -529,6 +529,48 @@ int bh_comm_rccl_init_rank(bh_comm* out, const void* id128, int world, int rank,
   return s;
 }
 
+// One all-gather and one all-to-all of known words through `comm` on the current device, checked on the host: a
+// transport that delivers wrong chunks (or fails) is found before a step depends on it.  Collective: every rank
+// of the comm calls it; every rank sees the same verdict only if the transport works, so callers that want to
+// fall back together reduce the result over their own channel.
+int bh_comm_check(const bh_comm* comm) {
+  if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || !comm->all_gather || !comm->all_to_all)
+    return BH_ERR_BAD_ARG;
+  const int P = comm->world, r = comm->rank, W = 64;  // 64 words per chunk
+  const size_t words = (size_t)P * W;
+  std::vector<uint32_t> h(words), back(2 * words);
+  uint32_t* d = nullptr;  // [send all-to-all: P chunks][recv all-gather: P chunks][recv all-to-all: P chunks]
+  hipStream_t st = nullptr;
+  if (hipMalloc(&d, 3 * words * sizeof(uint32_t)) != hipSuccess) return BH_ERR_OOM;
+  int ret = BH_ERR_COMM;
+  do {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+    for (int q = 0; q < P; q++)  // chunk q of my send: (me, q, word)
+      for (int w = 0; w < W; w++) h[(size_t)q * W + w] = 0x5a000000u | (uint32_t)r << 16 | (uint32_t)q << 8 | (uint32_t)w;
+    if (hipMemcpyAsync(d, h.data(), words * 4, hipMemcpyHostToDevice, st) != hipSuccess) break;
+    if (hipMemsetAsync(d + words, 0, 2 * words * 4, st) != hipSuccess) break;
+    // all-gather: everybody's chunk 0
+    if (comm->all_gather(comm->user, d + words, d, (int64_t)W * 4, st)) break;
+    if (comm->all_to_all(comm->user, d + 2 * words, d, (int64_t)W * 4, st)) break;
+    if (hipMemcpyAsync(back.data(), d + words, 2 * words * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+    if (hipStreamSynchronize(st) != hipSuccess) break;
+    bool ok = true;
+    for (int q = 0; q < P && ok; q++)
+      for (int w = 0; w < W; w++) {
+        const uint32_t ag = 0x5a000000u | (uint32_t)q << 16 | 0u << 8 | (uint32_t)w;           // rank q's chunk 0
+        const uint32_t aa = 0x5a000000u | (uint32_t)q << 16 | (uint32_t)r << 8 | (uint32_t)w;  // rank q's chunk `me`
+        if (back[(size_t)q * W + w] != ag || back[words + (size_t)q * W + w] != aa) {
+          ok = false;
+          break;
+        }
+      }
+    ret = ok ? BH_OK : BH_ERR_COMM;
+  } while (false);
+  if (st) (void)hipStreamDestroy(st);
+  (void)hipFree(d);
+  return ret;
+}
+
 int bh_hub_create(bh_hub** out, int world) {
   if (!out || world < 1 || world > kMaxWorld) return BH_ERR_BAD_ARG;
   bh_hub* h = new (std::nothrow) bh_hub();
@@ -976,6 +1018,7 @@ int bh_create_group(bh_group** out, int ngpus, const int* devices, int64_t n_tot
     if (devices[q] < 0 || devices[q] >= ndev) return BH_ERR_NO_DEVICE;
     for (int k = 0; k < q; k++) distinct = distinct && devices[k] != devices[q];
   }
+  const bool chosen_here = transport == 0;
   if (transport == 0) transport = distinct ? 1 : 2;
   if (transport == 1 && !distinct) return BH_ERR_BAD_ARG;  // RCCL refuses two ranks on one device
   bh_group* g = new (std::nothrow) bh_group();
@@ -993,28 +1036,30 @@ int bh_create_group(bh_group** out, int ngpus, const int* devices, int64_t n_tot
     bh_rank_default_opts(&g->o);
   g->ranks.assign(ngpus, nullptr);
   int s = BH_OK;
-  if (transport == 1) {
-    rccl_api* a = rccl();
-    if (!a) {
-      delete g;
-      return BH_ERR_COMM;
-    }
-    g->nccl.assign(ngpus, nullptr);
-    if (a->CommInitAll(g->nccl.data(), ngpus, devices)) {
-      g->nccl.clear();
-      delete g;
-      return BH_ERR_COMM;
-    }
-  } else {
-    s = bh_hub_create(&g->hub, ngpus);
-    if (s) {
-      delete g;
-      return s;
-    }
+  auto make_hub = [&]() {
+    const int s1 = bh_hub_create(&g->hub, ngpus);
+    if (s1) return s1;
     if (distinct)  // copies between devices: peer access where the platform offers it
       for (int q = 0; q < ngpus; q++)
         for (int k = 0; k < ngpus; k++)
           if (k != q && hipSetDevice(devices[q]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[k], 0);
+    return (int)BH_OK;
+  };
+  if (transport == 1) {
+    rccl_api* a = rccl();
+    g->nccl.assign(ngpus, nullptr);
+    if (!a || a->CommInitAll(g->nccl.data(), ngpus, devices)) {
+      g->nccl.clear();
+      if (!chosen_here) {  // the caller asked for RCCL
+        delete g;
+        return BH_ERR_COMM;
+      }
+      transport = 2;
+    }
+  }
+  if (transport == 2 && (s = make_hub()) != BH_OK) {
+    delete g;
+    return s;
   }
   g->stream.assign(ngpus, nullptr);
   if (!distinct)
@@ -1038,6 +1083,30 @@ int bh_create_group(bh_group** out, int ngpus, const int* devices, int64_t n_tot
     k->th = std::thread(worker_main, k, devices[q]);
   }
   if (!distinct) g->o.serial = 1;  // ranks that share a GPU: one stream each, own pass included (bh_dd_set_serial)
+  if (!g->hub) {  // RCCL: move known words through it once before any step depends on it
+    s = g->run_all([g](int q) {
+      bh_comm c;
+      memset(&c, 0, sizeof(c));
+      int s1 = rccl_fill(&c, g->nccl[q], false, g->P, q);
+      if (s1) return s1;
+      s1 = bh_comm_check(&c);
+      c.release(c.user);
+      return s1;
+    });
+    if (s && chosen_here) {  // nobody asked for RCCL by name: device copies between the ranks' threads instead
+      rccl_api* a = rccl();
+      for (nccl_comm_t& c : g->nccl) {
+        if (c && a) (void)a->CommDestroy(c);
+        c = nullptr;
+      }
+      g->nccl.clear();
+      s = make_hub();
+    }
+    if (s) {
+      bh_destroy_group(g);
+      return s;
+    }
+  }
   s = g->run_all([g](int q) {
     bh_comm c;
     memset(&c, 0, sizeof(c));

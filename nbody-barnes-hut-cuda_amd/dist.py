@@ -207,6 +207,10 @@ class RcclComm(_Comm):
         if st != 0:
             raise RuntimeError(f"bh_comm_rccl_init_rank: {L.lib.bh_strerror(st).decode()}")
 
+    def check(self):
+        """bh_comm_check: one all-gather and one all-to-all of known words through this transport (collective)"""
+        return _lib().lib.bh_comm_check(C.byref(self._c)) == 0
+
     def bh_comm(self):
         return self._c
 

@@ -100,6 +100,7 @@ static int run_group(int N, int frames, int warmup, bool quiet, const bh_params&
 }
 
 int main(int argc, char** argv) {
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // RCCL between devices wants dmabuf IPC on this driver; set before any HIP call
   int N = 500000;  // ref:31
   int gpus = 0;
   bool dist = false;

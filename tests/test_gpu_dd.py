@@ -650,3 +650,78 @@ def test_dd_malformed_let_record_is_closed_and_reported(how):
     assert CorruptingComm.hits >= 1
     assert res[0][0] == -8 and res[0][1] & 64, res        # BH_ERR_DEVICE_FLAG, BH_FLAG_DD_LET_INVALID
     assert res[1] [0] == 0 and res[1][1] == 0, res        # the other rank saw well-formed segments
+
+
+def test_transport_self_check_passes_on_the_hub_and_catches_a_misdelivering_transport():
+    """bh_comm_check (what bench.py / bh_create_group run before the first step over RCCL): known words through
+    one all-gather and one all-to-all.  The in-process hub with 3 ranks passes; a caller-callback transport whose
+    all-to-all delivers chunk `rank + 1` instead of chunk `rank` returns BH_ERR_COMM (-9) on every rank."""
+    import ctypes as C
+    import torch
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    L = pkg._lib
+    world = 3
+    group = bhdist.LocalGroup(world)
+    res = {}
+
+    def hub_rank(r):
+        torch.cuda.set_device(0)
+        c = bhdist.LocalComm(group, r).bh_comm()
+        res["hub", r] = L.lib.bh_comm_check(C.byref(c))
+        c.release(c.user)
+
+    th = [threading.Thread(target=hub_rank, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert [res["hub", r] for r in range(world)] == [0] * world
+
+    # a transport built from plain callbacks on raw pointers (no tensor registry): copies by hipMemcpy through torch
+    slots, bar = [None] * world, threading.Barrier(world)
+
+    def view(ptr, nbytes):
+        return torch.as_tensor(_DevBytes(ptr, nbytes), device="cuda:0")
+
+    def make(r, shift):
+        def ag(user, recv, send, nb, st):
+            torch.cuda.synchronize()   # (the check's own stream does not order with torch's)
+            slots[r] = view(send, nb * world)
+            bar.wait()
+            out = view(recv, nb * world)
+            for q in range(world):
+                out[q * nb:(q + 1) * nb].copy_(slots[q][:nb])
+            torch.cuda.synchronize()
+            bar.wait()
+            return 0
+
+        def a2a(user, recv, send, nb, st):
+            torch.cuda.synchronize()
+            slots[r] = view(send, nb * world)
+            bar.wait()
+            out = view(recv, nb * world)
+            me = (r + shift) % world
+            for q in range(world):
+                out[q * nb:(q + 1) * nb].copy_(slots[q][me * nb:(me + 1) * nb])
+            torch.cuda.synchronize()
+            bar.wait()
+            return 0
+        fa, fb = L.COMM_FN(ag), L.COMM_FN(a2a)
+        return L.BhComm(world, r, None, fa, fb, L.COMM_RELEASE_FN()), (fa, fb)
+
+    for shift, want in ((0, 0), (1, -9)):
+        def cb_rank(r, shift=shift):
+            torch.cuda.set_device(0)
+            c, keep = make(r, shift)
+            res[shift, r] = L.lib.bh_comm_check(C.byref(c))
+        th = [threading.Thread(target=cb_rank, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert [res[shift, r] for r in range(world)] == [want] * world
+
+
+class _DevBytes:
+    """a raw device range as something torch.as_tensor accepts (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
