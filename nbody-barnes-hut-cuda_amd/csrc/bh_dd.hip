@@ -445,6 +445,46 @@ __global__ __launch_bounds__(1024) void dd_split_kernel(const float* __restrict_
 // immigrants (round 2: six launches).  All orders are by body index / (rank, slot): deterministic.
 constexpr int kClsTile = 1024;  // bodies per block of the classify / compact kernels (256 threads x 4 rounds)
 
+// Exclusive scan of nb per-block counts by ONE block of 256 threads (the block a bh_last_block hand-off elected):
+// bbase[b] = counts of blocks before b; returns the total on every thread.  Every thread takes a run of consecutive
+// counts — all loads in flight at once —, one shuffle scan per wave, the four wave sums through LDS (round 4: chunks
+// of 256 through a Hillis-Steele scan in LDS, ~19 barriers per chunk, on the critical path of every rank-step).
+__device__ __forceinline__ int last_block_scan(const int* bcnt, int* __restrict__ bbase, int nb) {
+  __shared__ int wtot[4];
+  constexpr int kRun = 8;
+  int run_carry = 0;
+  for (int c0 = 0; c0 < nb; c0 += 256 * kRun) {
+    int v[kRun], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kRun; k++) {
+      const int b = c0 + (int)threadIdx.x * kRun + k;
+      v[k] = b < nb ? bh_collect_i32(bcnt + b) : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kRun; k++) sum += v[k];
+    int inc = sum;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int u = __shfl_up(inc, dd, 64);
+      if (lane >= dd) inc += u;
+    }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    int pre = run_carry + inc - sum;
+    for (int w2 = 0; w2 < wv; w2++) pre += wtot[w2];
+#pragma unroll
+    for (int k = 0; k < kRun; k++) {
+      const int b = c0 + (int)threadIdx.x * kRun + k;
+      if (b < nb) bbase[b] = pre;
+      pre += v[k];
+    }
+    run_carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+  }
+  return run_carry;
+}
+
 // kept[i] = 1 if body i stays (owner(key under the new cube) == me); bcnt[b] = emigrants of block b; the block
 // that finishes last turns the counts into exclusive bases and writes the X2 header:
 //   [0] emigrants found, [1] kept, [2] sent, [3] bodies still held  (+ 4 zero words)
@@ -487,30 +527,10 @@ __global__ __launch_bounds__(256) void dd_classify_kernel(const float4* __restri
   }
   __syncthreads();
   if (!s_last) return;
-  // exclusive scan of the block counts by this one block (<= n_cap / 1024 + 1 entries)
-  __shared__ int carry;
-  __shared__ int part[256];
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
   const int nb = (int)gridDim.x;
-  for (int c0 = 0; c0 < nb; c0 += 256) {
-    const int b = c0 + (int)threadIdx.x;
-    const int v = b < nb ? bh_collect_i32(bcnt + b) : 0;
-    part[threadIdx.x] = v;
-    __syncthreads();
-    for (int dd = 1; dd < 256; dd <<= 1) {  // Hillis-Steele inclusive scan
-      const int u = (int)threadIdx.x >= dd ? part[threadIdx.x - dd] : 0;
-      __syncthreads();
-      part[threadIdx.x] += u;
-      __syncthreads();
-    }
-    if (b < nb) bbase[b] = carry + part[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry += part[255];
-    __syncthreads();
-  }
+  const int run_carry = last_block_scan(bcnt, bbase, nb);
   if (threadIdx.x == 0) {
-    const int found = carry;
+    const int found = run_carry;
     const int sent = min(found, limit);
     bbase[nb] = found;
     if (ddi12) *ddi12 = found;
@@ -632,27 +652,7 @@ __global__ __launch_bounds__(256) void dd_absorb_flag_kernel(const float4* __res
   }
   __syncthreads();
   if (!s_last) return;
-  __shared__ int carry;
-  __shared__ int part[256];
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  const int nb = (int)gridDim.x;
-  for (int c0 = 0; c0 < nb; c0 += 256) {
-    const int b = c0 + tid;
-    const int v = b < nb ? bh_collect_i32(bcnt + b) : 0;
-    part[tid] = v;
-    __syncthreads();
-    for (int dd = 1; dd < 256; dd <<= 1) {
-      const int u = tid >= dd ? part[tid - dd] : 0;
-      __syncthreads();
-      part[tid] += u;
-      __syncthreads();
-    }
-    if (b < nb) bbase[b] = carry + part[tid] - v;
-    __syncthreads();
-    if (tid == 255) carry += part[255];
-    __syncthreads();
-  }
+  (void)last_block_scan(bcnt, bbase, (int)gridDim.x);
   if (tid < world) {
     const int held = reinterpret_cast<const int*>(g + (size_t)tid * f4)[3];
     const int a = __hip_atomic_load(arrive + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
