@@ -426,13 +426,13 @@ typedef struct bh_rank_opts {
   int32_t let_mode; /* X4: 1 = per-destination segments, all-to-all (default); 0 = one union segment, all-gather */
   int32_t split;    /* -1 = automatic (default): 1 when world > 1 and the rank's capacity is >= 400,000 bodies (its launches
                        fill the GPU), else 0;  0 = one force pass after X4;  1 = two passes
-                       for the first split_pct per cent of the rank's bodies — own pieces on a side stream while the
-                       LET is marked, exported and exchanged, remote pieces after X4 — and one pass after X4 for the
-                       rest: X4 leaves the critical path for the price of two passes on a fraction of the bodies   */
+                       for the first split_pct per cent of the rank's bodies — own pieces on a side stream, launched
+                       behind the LET export, while X4 is in flight; remote pieces after X4 — and one pass after X4 for
+                       the rest: X4 leaves the critical path for the price of two passes on a fraction of the bodies  */
   int32_t log;      /* 1 = keep (emigrants, boundary action) per step for bh_rank_read_log: synchronises, tests  */
   int32_t serial;   /* 1 = bh_dd_set_serial (ranks sharing one GPU)                                               */
   int32_t split_pct; /* two-pass steps: per cent of the bodies whose walk is split (bh_dd_set_split_percent); 0 = default
-                        (30), 100 = every body in two passes                                                        */
+                        (20), 100 = every body in two passes                                                        */
   int32_t reserved[8];
 } bh_rank_opts;
 typedef struct bh_rank_plan { /* bh_rank_query: the resolved capacities and the byte sizes of the eight buffers */

@@ -32,12 +32,14 @@
 // The stitched pool [local tree + body digests | two top trees | world x LET segment] is the same canonical octree a
 // single GPU builds; the unchanged force walk traverses it from a top-tree root.
 //
-// Force passes: one pass over the stitched tree after X4, or — the default with more than one rank — two: the own
-// pieces (two thirds of the pair work; they need nothing from other ranks) on a low-priority side stream right after
-// X3, with the other ranks' pieces as null records and every top cell carrying this rank's share of its mass, while
-// the main stream marks / exports the LET and runs X4; then the mirror image (top tree re-emitted from the first one's
-// structure), whose launch adds the own pass's accelerations, integrates and folds this rank's min / max.  Both passes
-// apply the same MAC to the same cells, so the split is exact up to summation order.
+// Force passes: one pass over the stitched tree after X4, or — the default with more than one rank, for the first
+// split_pct per cent of the rank's bodies — two: the own pieces (two thirds of the pair work; they need nothing from
+// other ranks) on a side stream, launched behind the LET export, with the other ranks' pieces as null records and
+// every top cell carrying this rank's share of its mass, while the main stream runs X4; then the mirror image (top
+// tree re-emitted from the first one's structure), whose launch adds the own pass's accelerations — beside the ONE
+// pass of the other bodies; both integrate and fold this rank's min / max.  Both passes apply the same MAC to the
+// same cells, so the split is exact up to summation order.  The side stream is created with a CU mask
+// (dd_make_side_stream: why, and what was measured).
 //
 // Safety: every walk over imported records is bounded; dd_validate_kernel closes malformed imported records before
 // anything walks them (BH_FLAG_DD_LET_INVALID); an X4 segment that does not fit is sent closed (pieces unopenable)
@@ -102,12 +104,14 @@ struct bh_dd_state {
   int4* top_ci;    // [2][2 kTopMax + 8] per top record: branching level (-1: piece), child offset / slot, count
   float4* acc2;    // [n_cap] accelerations of the remote pass (the own pass writes the context's acc)
   hipEvent_t ev_x3, ev_top1, ev_own;
-  hipStream_t stream_own;  // lowest priority: the own pass is background work behind the LET export and X4
+  hipStream_t stream_own;  // the side stream of the two-pass forms: restricted to all but kReserveCus compute units, so that
+                           // what the main stream launches while a pass holds the GPU (X4's kernel, the validation, the
+                           // top trees) finds free units at once (dd_make_side_stream)
   bool split;      // two-pass force: own pieces while X4 is in flight, remote pieces after it
   bool serial;     // the own pass runs on the context's main stream instead of the side stream (bh_dd_set_serial: ranks
                    // that share one GPU in a rehearsal — their side streams would overlap each other's work)
   int* host;       // pinned: [world] LET counts, [64 .. 67] migration results, [68] their sequence number
-  hipEvent_t ev_let;
+  hipEvent_t ev_let;  // the LET export of this step has finished (main stream): the own pass may take the GPU
   bool let_copy_pending;
   int* host_rows;  // pinned: [world][32] header + needs row (records 0..3) of every received X4 segment
   int let_mode;    // 0: X4 is an all-gather of the union every other rank may open; 1: per-destination segments
@@ -1755,6 +1759,35 @@ __global__ __launch_bounds__(256) void dd_pack_ids_kernel(const float* __restric
   } while (0)
 
 // the most a rebalance shifts a rank's share against its drift: 0.8 of the tolerance band (bodies)
+// The side stream of the two-pass forms.  Measured on an MI355X (profiles/r05_dd/split_timeline_*): a kernel the
+// main stream launches while a launch of the side stream holds every wave slot is not served before that launch has
+// handed out its last workgroup, whatever the streams' priorities — dd_let_scan_kernel, 5 us of work, took 302 us
+// beside the own pass.  So (a) the own pass is enqueued behind the LET export (bh_dd_phase_let) and hides X4 only,
+// and (b) the side stream leaves kReserveCus compute units to the main stream (a CU mask; bits are dealt to the XCDs in
+// turn, so clearing the highest ones takes the same number of units from every XCD): X4's kernel, the validation and
+// the top-tree kernels start at once on them.  Without CU-mask support: a lowest-priority stream, as round 4.
+constexpr int kReserveCus = 16;
+static bool dd_make_side_stream(const bh_ctx* c, hipStream_t* out) {
+  int reserve = kReserveCus;
+#ifdef BH_STUDY
+  if (getenv("BH_DD_RESERVE_CUS")) reserve = atoi(getenv("BH_DD_RESERVE_CUS"));
+#endif
+  const int cus = c->num_cus;
+  if (reserve > 0 && cus > 2 * reserve) {
+    uint32_t mask[32];
+    const int words = (cus + 31) / 32;
+    if (words <= 32) {
+      for (int w = 0; w < words; w++) mask[w] = 0;
+      for (int b = 0; b < cus - reserve; b++) mask[b >> 5] |= 1u << (b & 31);
+      if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask) == hipSuccess) return true;
+      (void)hipGetLastError();
+    }
+  }
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, least) == hipSuccess;
+}
+
 static long long dd_drift_cap(const bh_dd_state* d) {
   return (long long)(0.8 * (double)kSplitTolerance * (double)d->n_total / (double)d->world);
 }
@@ -1876,11 +1909,7 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipEventCreateWithFlags(&d->ev_own, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_top1, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->ev_x4, hipEventDisableTiming) == hipSuccess;
-  {
-    int least = 0, greatest = 0;
-    ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-    ok = ok && hipStreamCreateWithPriority(&d->stream_own, hipStreamNonBlocking, least) == hipSuccess;
-  }
+  ok = ok && dd_make_side_stream(c, &d->stream_own);
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
   if (ok) memset(d->host, 0, (64 + 8) * sizeof(int));  // [64..67] migration results, [68] their sequence number, [70] X4 headers'
   ok = ok && hipHostMalloc((void**)&d->host_rows, 64 * 32 * sizeof(int)) == hipSuccess;
@@ -2152,13 +2181,9 @@ int bh_dd_set_let_mode(bh_ctx* c, int mode) {
   return BH_OK;
 }
 
-// Own pass of the two-pass force, on the side stream: it needs only the gathered piece descriptors and
-// the local tree, so it runs while the LET marking/export kernels and the X4 all-gather occupy the main
-// stream.  Top tree of this pass: other ranks' pieces are null records, top cells carry this rank's
-// share of their mass (bh_dd_top builds the mirror image for the remote pass).
-int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
-  if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
-  if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
+// first half: what needs nothing but X3 — the own pass's top tree (one block) and the zeroes bh_dd_download adds for
+// the bodies that get no remote pass — goes to the side stream at once, beside the LET kernels
+static int dd_force_local_prepare(bh_ctx* c, const void* gathered_x3) {
   bh_dd_state* d = c->dd;
   d->split = true;
   hipStream_t so = d->serial ? c->stream : d->stream_own;
@@ -2172,14 +2197,38 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
   BH_HIP(c, hipGetLastError());
   BH_HIP(c, hipEventRecord(d->ev_top1, so));  // the remote pass re-emits from this tree's scratch
   // Partial two-pass step (split_pct < 100): only the first bodies' walk is split — their own pass lasts as long as
-  // the LET export and X4 take —, the others wait for X4 and are walked in ONE pass: the exchange is hidden and the
-  // price of two passes (a second drain, the top levels twice) is paid for a fraction of the bodies.
+  // X4 takes —, the others wait for X4 and are walked in ONE pass: the exchange is hidden and the price of two
+  // passes (a second drain, the top levels twice) is paid for a fraction of the bodies.
   d->own_hi = d->split_pct >= 100 ? c->n : (int)((long long)c->n * d->split_pct / 100) / 256 * 256;
-  if (d->own_hi > 0) BH_HIP(c, bhk_force_root(c, 0, d->own_hi, d->top_base2, so, c->acc));
   if (d->own_hi < c->n)  // (bh_dd_download adds the two partial accelerations: none of a remote pass beyond own_hi)
     BH_HIP(c, hipMemsetAsync(d->acc2 + d->own_hi, 0, (size_t)(c->n - d->own_hi) * sizeof(float4), so));
+  return BH_OK;
+}
+// second half: the launch that fills the GPU.  after_let: behind what the main stream holds at this point (the LET
+// export) — a saturating launch of the side stream starves whatever the main stream launches after it
+// (dd_make_side_stream), so the own pass hides X4 and not the LET kernels.
+static int dd_force_local_launch(bh_ctx* c, bool after_let) {
+  bh_dd_state* d = c->dd;
+  hipStream_t so = d->serial ? c->stream : d->stream_own;
+  if (after_let && so != c->stream) {
+    BH_HIP(c, hipEventRecord(d->ev_let, c->stream));
+    BH_HIP(c, hipStreamWaitEvent(so, d->ev_let, 0));
+  }
+  if (d->own_hi > 0) BH_HIP(c, bhk_force_root(c, 0, d->own_hi, d->top_base2, so, c->acc));
   BH_HIP(c, hipEventRecord(d->ev_own, so));
   return BH_OK;
+}
+
+// Own pass of the two-pass force, on the side stream: it needs only the gathered piece descriptors and
+// the local tree, so it runs while the X4 exchange occupies the main stream.  Top tree of this pass: other
+// ranks' pieces are null records, top cells carry this rank's share of their mass (bh_dd_top builds the mirror
+// image for the remote pass).  Called on its own, the pass is launched at once; bh_dd_phase_let puts it behind
+// the LET export.
+int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
+  if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
+  const int s = dd_force_local_prepare(c, gathered_x3);
+  return s ? s : dd_force_local_launch(c, false);
 }
 
 int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
@@ -2315,11 +2364,20 @@ int bh_dd_phase_tree(bh_ctx* c, const void* gathered_x2, int limit, void* send_x
 }
 
 int bh_dd_phase_let(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride, int own_pass) {
+  if (!c || !c->dd || !gathered_x3 || !send_x4) return BH_ERR_BAD_ARG;
+  if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
+  bool after_let = true;
+#ifdef BH_STUDY
+  if (getenv("BH_DD_OWN_AT_ONCE")) after_let = false;  // round 4 / early round 5: the own pass beside the LET kernels
+#endif
   if (own_pass) {
-    const int s = bh_dd_force_local(c, gathered_x3);
+    int s = dd_force_local_prepare(c, gathered_x3);
+    if (!s && !after_let) s = dd_force_local_launch(c, false);
     if (s) return s;
   }
-  return bh_dd_let_pack(c, gathered_x3, send_x4, stride);
+  int s = bh_dd_let_pack(c, gathered_x3, send_x4, stride);
+  if (!s && own_pass && after_let) s = dd_force_local_launch(c, true);
+  return s;
 }
 
 // The fit of every rank's LET is looked at BEFORE the last force pass is launched (the headers of the received
@@ -2404,7 +2462,7 @@ int bh_dd_pass_times(bh_ctx* c, float ms[4]) {
   BH_HIP(c, hipEventElapsedTime(&ms[0], e[0], e[1]));
   BH_HIP(c, hipEventElapsedTime(&ms[1], e[1], e[2]));
   if (partial) BH_HIP(c, hipEventElapsedTime(&ms[2], e[2], e[3]));
-  // two launches at once: the first on the low-priority side stream, the second on the main stream
+  // two launches at once: the first on the side stream, the second on the main stream
   BH_HIP(c, hipEventRecord(e[0], c->stream));
   BH_HIP(c, hipStreamWaitEvent(d->stream_own, e[0], 0));
   if (partial) {

@@ -731,9 +731,10 @@ int bh_rank_create(bh_rank** out, const bh_comm* comm, int64_t n_total, const bh
                          plan.sz.pool_records);
   if (!s) s = bh_dd_set_let_mode(r->ctx, o.let_mode);
   if (!s && o.serial) s = bh_dd_set_serial(r->ctx, 1);
-  // two-pass steps split the walk of the first 30 % of a rank's bodies unless told otherwise: their own pass lasts
-  // ~0.3 ms at 1M bodies per rank, as long as the LET export + an X4 of up to ~0.2 ms
-  if (!s) s = bh_dd_set_split_percent(r->ctx, o.split_pct <= 0 ? 30 : (o.split_pct > 100 ? 100 : o.split_pct));
+  // two-pass steps split the walk of the first 20 % of a rank's bodies unless told otherwise: their own pass — launched
+  // behind the LET export, beside X4 — lasts ~0.2 ms at 1M bodies per rank, an X4 of up to ~0.2 ms disappears behind it,
+  // and every 10 % cost ~0.03 ms of extra walk
+  if (!s) s = bh_dd_set_split_percent(r->ctx, o.split_pct <= 0 ? 20 : (o.split_pct > 100 ? 100 : o.split_pct));
   if (s) {
     r->comm.release = nullptr;
     bh_rank_destroy(r);

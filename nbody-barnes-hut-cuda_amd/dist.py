@@ -266,14 +266,14 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
 
 
 # Force passes per step when the caller does not choose: None = the library's rule (bh_rank_opts.split -1): with more
-# than one rank and ranks large enough to fill the GPU (capacity >= 400,000 bodies) the walk of the first 30 % of a
-# rank's bodies is split in two passes — own pieces on a side stream while the LET is marked, exported and exchanged,
-# remote pieces after X4, beside the one pass of the other bodies (profiles/r05_dd/split_vs_one_pass.txt) —, else one
-# pass after X4.
+# than one rank and ranks large enough to fill the GPU (capacity >= 400,000 bodies) the walk of the first 20 % of a
+# rank's bodies is split in two passes — own pieces on a side stream behind the LET export, while X4 is in flight;
+# remote pieces after X4, beside the one pass of the other bodies (profiles/r05_dd/split_vs_one_pass.txt,
+# two_stream_overlap_world1.txt) —, else one pass after X4.
 SPLIT_DEFAULT = None
 
 # X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
-# (let_mode=0: the all-gather of one union segment per rank; tools/dd_debug.py --let-mode 0 for A/B)
+# (let_mode=0: the all-gather of one union segment per rank)
 LET_MODE_DEFAULT = 1
 
 BUFFER_NAMES = ("x1s", "x1r", "x2s", "x2r", "x3s", "x3r", "lets", "pool")
