@@ -2231,11 +2231,27 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
   return s ? s : dd_force_local_launch(c, false);
 }
 
+#ifdef BH_STUDY
+// study builds: BH_DD_FAKE_X4_US=<us> makes X4 last that much longer on the main stream — one idle wave, as an
+// exchange over the links would leave the GPU — so that what a side-stream pass hides can be timed at world size 1
+// (tools/r5_fake_x4.sh)
+__global__ void dd_sleep_kernel(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+#endif
+
 int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
   if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
   if (stride < kSegBlocks0 || stride > d->let_cap || (stride & 1)) return BH_ERR_BAD_ARG;
+#ifdef BH_STUDY
+  {
+    static const int fake_us = getenv("BH_DD_FAKE_X4_US") ? atoi(getenv("BH_DD_FAKE_X4_US")) : 0;
+    if (fake_us > 0) dd_sleep_kernel<<<1, 64, 0, c->stream>>>(100ll * fake_us);
+  }
+#endif
   // the segment headers (records each rank needed) go to the host for bh_dd_let_check: written to pinned memory by
   // the validation kernel's first block, announced by a sequence number in d->host[70]
   {
