@@ -281,9 +281,10 @@ def main():
     ap.add_argument("--force-coop", type=int, default=0,
                     help="tuning: waves per group of the force walk (bh_params.force_coop; 0 = automatic, 1 = one wave per group)")
     ap.add_argument("--dd-split", action="store_true",
-                    help="N > 1: two force passes per step (own pieces while the LET travels, then the remote pass): "
-                         "the default with more than one rank")
-    ap.add_argument("--dd-one-pass", action="store_true", help="N > 1: one force pass per step, after X4")
+                    help="N > 1: the first 30 %% of a rank's bodies in two force passes (own pieces while X4 travels, "
+                         "then the remote pass) whatever X4 costs; default: adaptive (one pass while the measured X4 "
+                         "is short)")
+    ap.add_argument("--dd-one-pass", action="store_true", help="N > 1: one force pass per step, after X4, always")
     ap.add_argument("--graph", action="store_true",
                     help="time bh_step replayed as a HIP graph (no per-stage event records inside the timed region; "
                          "the force-launch time of the roofline block then comes from 10 extra timed-stage steps)")
@@ -397,7 +398,7 @@ def main():
 
     def domain_stepper(ic_, let_cap=None, slack=1.3):
         return bhdist.DomainStepper(pkg, ic_, make_comm(), local_rank, let_cap=let_cap, slack=slack,
-                                    split=True if args.dd_split else (False if args.dd_one_pass else None), **engine_kw)
+                                    split=True if args.dd_split else (False if args.dd_one_pass else "adaptive"), **engine_kw)
 
     def replicated():
         e, st = bhdist.make_gpu_stepper(pkg, n_total, device=local_rank, leaf_cap=args.leaf_cap,
@@ -636,7 +637,12 @@ def main():
                 "bodies_rank0": int(stepper.n_loc), "let_records_per_rank": [int(v) for v in stepper.let_counts],
                 "let_stride": int(stepper.stride), "emigrants_last_step_max": int(stepper.mig_last),
                 "x4": "per-destination segments, all-to-all" if stepper.let_mode == 1 else "union segment, all-gather",
-                "force_passes": "own pieces beside X4, then the remote pass" if stepper.split else "one, after X4",
+                "force_passes": {0: "one, after X4", 1: "first part of the bodies in two (own pieces beside X4, then the "
+                                 "remote pass), the rest in one", 2: "adaptive: one pass while the measured X4 is short, "
+                                 "the split form from ~0.2 ms on"}[int(stepper.split)],
+                "split_now_rank0": int(stepper.split_now),
+                # adaptive form: the exchange as this rank's stream saw it (events around X4, running mean), or null
+                "x4_ms_measured_rank0": (stepper.x4_us / 1000.0) if stepper.x4_us >= 0 else None,
                 "x4_bytes_received_per_gpu_per_step": int(world * stepper.stride * 32),
                 "let_retries": int(stepper.let_retries), "extra_migration_rounds": int(stepper.mig_rounds),
                 "phase_ms_rank0": stepper.phase_ms()}

@@ -424,15 +424,17 @@ typedef struct bh_rank_opts {
   int32_t mig_cap;  /* emigrant slots of the X2 buffers; 0 = min(max(4096, n_cap / 2), 4 n_cap / world)        */
   int32_t let_cap;  /* records per LET segment; 0 = 516 + n_cap                                                */
   int32_t let_mode; /* X4: 1 = per-destination segments, all-to-all (default); 0 = one union segment, all-gather */
-  int32_t split;    /* -1 = automatic (default): 1 when world > 1 and the rank's capacity is >= 400,000 bodies (its launches
-                       fill the GPU), else 0;  0 = one force pass after X4;  1 = two passes
-                       for the first split_pct per cent of the rank's bodies — own pieces on a side stream, launched
-                       behind the LET export, while X4 is in flight; remote pieces after X4 — and one pass after X4 for
-                       the rest: X4 leaves the critical path for the price of two passes on a fraction of the bodies  */
+  int32_t split;    /* force passes per step.  0 (and -1, the default): ONE pass after X4.  1: two passes for the first
+                       split_pct per cent of the rank's bodies — own pieces on a side stream, launched behind the LET
+                       export, while X4 is in flight; remote pieces after X4 — and one pass after X4 for the rest.
+                       2: adaptive — one pass while the measured X4 (events around the exchange) is short, the split
+                       form once it lasts ~0.2 ms and more (where it pays: DESIGN.md §6); the rank's own decision, so
+                       results then depend on timing in the last bits.  Only with more than one rank and a capacity
+                       of >= 400,000 bodies (launches that fill the GPU), else one pass                            */
   int32_t log;      /* 1 = keep (emigrants, boundary action) per step for bh_rank_read_log: synchronises, tests  */
   int32_t serial;   /* 1 = bh_dd_set_serial (ranks sharing one GPU)                                               */
   int32_t split_pct; /* two-pass steps: per cent of the bodies whose walk is split (bh_dd_set_split_percent); 0 = default
-                        (20), 100 = every body in two passes                                                        */
+                        (30), 100 = every body in two passes                                                        */
   int32_t reserved[8];
 } bh_rank_opts;
 typedef struct bh_rank_plan { /* bh_rank_query: the resolved capacities and the byte sizes of the eight buffers */
@@ -452,7 +454,9 @@ typedef struct bh_rank_info {
   int32_t left_status;  /* this rank's own failing status when it is the one that left, else 0       */
   int64_t steps;        /* completed steps                                                           */
   int32_t let_counts[64]; /* records every rank needed in the last X4                                */
-  int32_t reserved[8];
+  int32_t split_now;    /* 1: the next step walks part of the bodies in two passes (split 1, or adaptive and on) */
+  int32_t x4_us;        /* adaptive form: running mean of the measured X4 duration, microseconds (-1: none yet) */
+  int32_t reserved[6];
 } bh_rank_info;
 
 int bh_rank_default_opts(bh_rank_opts* o);
@@ -475,6 +479,14 @@ int bh_rank_buffers_of(bh_rank* r, bh_rank_buffers* out, bh_rank_plan* plan);
 int bh_rank_set_profile(bh_rank* r, int on);
 int bh_rank_phase_ms(bh_rank* r, double mean_ms[BH_RANK_PHASES], int* steps);
 int bh_rank_read_log(bh_rank* r, int32_t* pairs, int capacity_pairs, int* n_pairs);
+/* Measurement only: the force phase of the LAST COMPLETED step run again on the rank's own two streams with nothing else
+   on the GPU — LET marking and export, an idle wave of x4_us microseconds on the main stream in the place of X4 (the
+   imported segments of the last step are still in the pool), validation, top trees, the force pass(es) without the
+   integration — `reps` times after one untimed round; *ms = mean time from the first LET kernel to the end of the last
+   force launch.  split = 0: one pass; 1: the two-pass form for split_pct per cent of the bodies.  What a rank-step
+   spends between X3 and its end on a GPU of its own, for every form, from a one-GPU rehearsal of P ranks (the other
+   ranks must be idle: call it for one rank at a time; `bh_bench --replay`).  The rank's state is as before. */
+int bh_rank_replay_force_phase(bh_rank* r, int split, int split_pct, int x4_us, int reps, float* ms);
 void bh_rank_destroy(bh_rank* r);
 /* Test hook: the same protocol around a SCRIPTED engine and host buffers (no GPU): tests/test_dist_cpu.py drives
    it over gloo.  The callbacks have the meaning of bh_dd_cube_pack, bh_dd_phase_migrate, bh_dd_migrate_pack,

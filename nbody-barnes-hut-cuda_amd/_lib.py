@@ -93,7 +93,8 @@ class BhRankBuffers(C.Structure):
 class BhRankInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n_loc", "stride", "mig_stride", "mig_last", "mig_rounds", "let_retries",
                                          "left_rank", "left_status")] + \
-               [("steps", C.c_int64), ("let_counts", C.c_int32 * 64), ("reserved", C.c_int32 * 8)]
+               [("steps", C.c_int64), ("let_counts", C.c_int32 * 64), ("split_now", C.c_int32), ("x4_us", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 _PI = C.POINTER(C.c_int)
@@ -203,6 +204,7 @@ SYMBOLS = [
     ("bh_rank_set_profile", C.c_int, [_P, C.c_int]),
     ("bh_rank_phase_ms", C.c_int, [_P, C.POINTER(C.c_double), _PI]),
     ("bh_rank_read_log", C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, _PI]),
+    ("bh_rank_replay_force_phase", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("bh_rank_destroy", None, [_P]),
     ("bh_create_group", C.c_int, [C.POINTER(_P), C.c_int, _PI, C.c_int64, C.POINTER(BhParams),
                                   C.POINTER(BhRankOpts), C.c_int]),

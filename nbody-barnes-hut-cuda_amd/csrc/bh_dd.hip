@@ -47,6 +47,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "bh_internal.h"
 #include "bh_keys.h"
 
@@ -112,6 +114,7 @@ struct bh_dd_state {
                    // that share one GPU in a rehearsal — their side streams would overlap each other's work)
   int* host;       // pinned: [world] LET counts, [64 .. 67] migration results, [68] their sequence number
   hipEvent_t ev_let;  // the LET export of this step has finished (main stream): the own pass may take the GPU
+  bool replay;        // bh_dd_replay_begin .. _end (measurement): the force passes do not integrate
   bool let_copy_pending;
   int* host_rows;  // pinned: [world][32] header + needs row (records 0..3) of every received X4 segment
   int let_mode;    // 0: X4 is an all-gather of the union every other rank may open; 1: per-destination segments
@@ -1766,8 +1769,44 @@ __global__ __launch_bounds__(256) void dd_pack_ids_kernel(const float* __restric
 // and (b) the side stream leaves kReserveCus compute units to the main stream (a CU mask; bits are dealt to the XCDs in
 // turn, so clearing the highest ones takes the same number of units from every XCD): X4's kernel, the validation and
 // the top-tree kernels start at once on them.  Without CU-mask support: a lowest-priority stream, as round 4.
+// Contexts of one process on one device (the ranks of a one-GPU rehearsal) share ONE such stream: every masked stream
+// is a hardware queue of its own, and with eight of them beside the main streams the queues are time-sliced — whole
+// ranks' side-stream launches then start hundreds of microseconds late (seen in bh_rank_replay_force_phase tables
+// as two or three ranks whose split forms cost 0.2-0.4 ms more, different ranks in every run).
 constexpr int kReserveCus = 16;
+namespace {
+struct side_stream_slot {
+  hipStream_t stream = nullptr;
+  int users = 0;
+};
+std::mutex g_side_mutex;
+side_stream_slot g_side[64];
+}  // namespace
+static bool dd_make_side_stream_raw(const bh_ctx* c, hipStream_t* out);
 static bool dd_make_side_stream(const bh_ctx* c, hipStream_t* out) {
+  if (c->device < 0 || c->device >= 64) return dd_make_side_stream_raw(c, out);
+  std::lock_guard<std::mutex> lk(g_side_mutex);
+  side_stream_slot& sl = g_side[c->device];
+  if (sl.users == 0 && !dd_make_side_stream_raw(c, &sl.stream)) return false;
+  sl.users++;
+  *out = sl.stream;
+  return true;
+}
+static void dd_release_side_stream(const bh_ctx* c, hipStream_t s) {
+  if (c->device >= 0 && c->device < 64) {
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    side_stream_slot& sl = g_side[c->device];
+    if (sl.stream == s) {
+      if (--sl.users == 0) {
+        (void)hipStreamDestroy(s);
+        sl.stream = nullptr;
+      }
+      return;
+    }
+  }
+  (void)hipStreamDestroy(s);
+}
+static bool dd_make_side_stream_raw(const bh_ctx* c, hipStream_t* out) {
   int reserve = kReserveCus;
 #ifdef BH_STUDY
   if (getenv("BH_DD_RESERVE_CUS")) reserve = atoi(getenv("BH_DD_RESERVE_CUS"));
@@ -1803,7 +1842,7 @@ void bh_dd_free(bh_ctx* c) {
   if (!d) return;
   if (d->stream_own) {  // the own pass may still be reading the arrays freed below
     (void)hipStreamSynchronize(d->stream_own);
-    (void)hipStreamDestroy(d->stream_own);
+    dd_release_side_stream(c, d->stream_own);
   }
   void* ptrs[] = {d->w, d->dst, d->flag, d->fpos, d->nloc, d->skeys, d->drift, d->piece_tmp,
                   d->piece_idx, d->ddi, d->boxes, d->rbox, d->top_ps, d->top_a, d->top_b, d->top_ci, d->acc2,
@@ -2231,27 +2270,19 @@ int bh_dd_force_local(bh_ctx* c, const void* gathered_x3) {
   return s ? s : dd_force_local_launch(c, false);
 }
 
-#ifdef BH_STUDY
-// study builds: BH_DD_FAKE_X4_US=<us> makes X4 last that much longer on the main stream — one idle wave, as an
-// exchange over the links would leave the GPU — so that what a side-stream pass hides can be timed at world size 1
-// (tools/r5_fake_x4.sh)
+// measurement: one wave that does nothing for `ticks` of the 100 MHz wall clock — the main stream is busy and the GPU
+// as free as during an exchange over the links (bh_dd_idle_wave; study builds of bh_group.hip: BH_DD_FAKE_X4_US=<us>
+// puts it behind every X4, tools/r5_fake_x4.sh)
 __global__ void dd_sleep_kernel(long long ticks) {
   const long long t0 = (long long)wall_clock64();
   while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
-#endif
 
 int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
   if (!c || !c->dd || !gathered_x3) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_COM)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
   if (stride < kSegBlocks0 || stride > d->let_cap || (stride & 1)) return BH_ERR_BAD_ARG;
-#ifdef BH_STUDY
-  {
-    static const int fake_us = getenv("BH_DD_FAKE_X4_US") ? atoi(getenv("BH_DD_FAKE_X4_US")) : 0;
-    if (fake_us > 0) dd_sleep_kernel<<<1, 64, 0, c->stream>>>(100ll * fake_us);
-  }
-#endif
   // the segment headers (records each rank needed) go to the host for bh_dd_let_check: written to pinned memory by
   // the validation kernel's first block, announced by a sequence number in d->host[70]
   {
@@ -2416,7 +2447,7 @@ int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* c
   // (one rank in two passes: the remote pass walks nothing but the top record, and a launch that short integrates
   // slower than the streaming kernel does — 0.100 against 0.055 + 0.021 ms at 1M bodies; one pass integrates as
   // bh_step's launch does)
-  return dd_force_impl(c, c->dd->world > 1 || !c->dd->split);
+  return dd_force_impl(c, !c->dd->replay && (c->dd->world > 1 || !c->dd->split));
 }
 
 int bh_dd_phase_end(bh_ctx* c, void* send_x1) {
@@ -2495,6 +2526,53 @@ int bh_dd_pass_times(bh_ctx* c, float ms[4]) {
   BH_HIP(c, hipStreamSynchronize(c->stream));
   BH_HIP(c, hipEventElapsedTime(&ms[partial ? 3 : 2], e[0], e[1]));
   for (int k = 0; k < 5; k++) (void)hipEventDestroy(e[k]);
+  return BH_OK;
+}
+
+// ---- measurement: the force phase of the last completed step run again (bh_rank_replay_force_phase)
+int bh_dd_replay_begin(bh_ctx* c, int split, int split_pct, int saved[4]) {
+  if (!c || !c->dd || !saved || (split && (split_pct < 1 || split_pct > 100))) return BH_ERR_BAD_ARG;
+  if (!(c->ever & BH_ST_FORCE)) return BH_ERR_ORDER;  // no step yet: no tree, no imported segments
+  bh_dd_state* d = c->dd;
+  BH_HIP(c, hipSetDevice(c->device));
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  BH_HIP(c, hipStreamSynchronize(d->stream_own));
+  saved[0] = c->stage;
+  saved[1] = d->split ? 1 : 0;
+  saved[2] = d->split_pct;
+  saved[3] = d->serial ? 1 : 0;
+  // the tree, the digests and the imported segments of the last step are all still there; the bodies have been
+  // integrated since (same order, positions one step on): the passes do the same work
+  c->stage |= BH_ST_BBOX | BH_ST_MORTON | BH_ST_SORT | BH_ST_BUILD | BH_ST_COM;
+  d->split = split != 0;
+  if (split) d->split_pct = split_pct;
+  d->serial = false;  // the rank's own two streams, as on a GPU of its own
+  d->replay = true;
+  return BH_OK;
+}
+int bh_dd_replay_end(bh_ctx* c, const int saved[4]) {
+  if (!c || !c->dd || !saved) return BH_ERR_BAD_ARG;
+  bh_dd_state* d = c->dd;
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  BH_HIP(c, hipStreamSynchronize(d->stream_own));
+  c->stage = saved[0];
+  d->split = saved[1] != 0;
+  d->split_pct = saved[2];
+  d->serial = saved[3] != 0;
+  d->replay = false;
+  c->dd_integrated = false;
+  return BH_OK;
+}
+// a rank that has stepped in two passes goes back to one (the adaptive form of bh_rank: bh_group.hip)
+int bh_dd_set_one_pass(bh_ctx* c) {
+  if (!c || !c->dd) return BH_ERR_BAD_ARG;
+  c->dd->split = false;
+  return BH_OK;
+}
+int bh_dd_idle_wave(bh_ctx* c, int us) {
+  if (!c || us < 0) return BH_ERR_BAD_ARG;
+  if (us > 0) dd_sleep_kernel<<<1, 64, 0, c->stream>>>(100ll * us);
+  BH_HIP(c, hipGetLastError());
   return BH_OK;
 }
 

@@ -238,6 +238,15 @@ struct bh_rank {
   char* buf[8];  // x1s x1r x2s x2r x3s x3r x4s pool
   bool own_buf;
   int stride, mig_stride, mig_rounds, mig_last, let_retries, n_loc;
+  int stride_last;  // the stride the last completed step's X4 used (the segments in the pool are laid out with it)
+  // which form the force takes this step: fixed by bh_rank_opts.split 0 / 1, or — split 2, adaptive — decided from the
+  // measured duration of X4 (events around the exchange on the rank's stream, read one step later): one pass while the
+  // exchange is short, the first part of the bodies in two passes once it lasts long enough to pay (kSplitOnMs)
+  int split_now;
+  bool adaptive, x4_timed;
+  hipEvent_t ev_xa, ev_xb;
+  float x4_ema_ms;
+  int x4_samples;
   bool x1_ready;
   int32_t let_counts[kMaxWorld];
   int left_rank, left_status;
@@ -333,9 +342,36 @@ struct phase_lock {
   }
 };
 
+// Adaptive form (bh_rank_opts.split 2).  Measured on an MI355X, 8 x 1M bodies, every rank's force phase replayed on a GPU
+// of its own (bh_rank_replay_force_phase, profiles/r05_dd/replay_8x1M.txt): one pass costs 1.24 ms + X4; the first 30 %
+// in two passes 1.41 ms + a fifth of X4 — the own pass hides the exchange at the price of two launches with a drain
+// each — so the split pays from an X4 of ~0.18 ms on.  The decision is the rank's own (the protocol does not change).
+constexpr float kSplitOnMs = 0.15f, kSplitOffMs = 0.09f;
+void rank_adapt(bh_rank* r) {
+  if (!r->adaptive || !r->x4_timed || !r->ctx) return;
+  r->x4_timed = false;
+  float t = 0.0f;
+  if (hipEventElapsedTime(&t, r->ev_xa, r->ev_xb) != hipSuccess) {
+    (void)hipGetLastError();  // (not complete: cannot be — the step that recorded them has checked X4's headers)
+    return;
+  }
+  r->x4_ema_ms = r->x4_samples == 0 ? t : 0.75f * r->x4_ema_ms + 0.25f * t;
+  if (++r->x4_samples < 4) return;
+  if (!r->split_now && r->x4_ema_ms > kSplitOnMs) {
+    // as many bodies as it takes for their own pass to outlast the exchange: an own pass of p % lasts ~0.0107 p ms
+    // at 1M bodies per rank and covers ~0.65 of that (its own drain is not filled while the main stream waits)
+    int pct = (int)(r->x4_ema_ms / (0.0107f * 0.65f) * (1.0e6f / (float)(r->n_loc > 0 ? r->n_loc : 1)));
+    pct = pct < 20 ? 20 : (pct > 60 ? 60 : pct);
+    if (bh_dd_set_split_percent(r->ctx, pct) == BH_OK) r->split_now = 1;
+  } else if (r->split_now && r->x4_ema_ms < kSplitOffMs) {
+    if (bh_dd_set_one_pass(r->ctx) == BH_OK) r->split_now = 0;
+  }
+}
+
 int rank_one_step(bh_rank* r) {
   const bh_comm& c = r->comm;
   rank_ops e = r->ops;
+  rank_adapt(r);
   {  // every engine call of the step under the phase lock (serial ranks only)
     struct wrap {
       static int cube_pack(void* u, void* a) { bh_rank* r = (bh_rank*)u; phase_lock l(r); return r->ops.cube_pack(r->ops.user, a); }
@@ -424,14 +460,26 @@ int rank_one_step(bh_rank* r) {
     char* seg = r->buf[POOL] + (size_t)sz.seg_base * 32;
     const int nseg = r->o.let_mode == 1 ? P : 1;  // segments this rank sends
     if (!failed)  // own pieces on the side stream (first try only: it overlaps X4), LET marked / exported
-      failed = e.phase_let(e.user, r->buf[X3R], r->buf[X4S], stride, (r->o.split && tries == 0) ? 1 : 0);
+      failed = e.phase_let(e.user, r->buf[X3R], r->buf[X4S], stride, (r->split_now && tries == 0) ? 1 : 0);
     if (failed) {
       if (rk_mark_left(r, nseg, stride)) return BH_ERR_HIP;
     }
     tries++;
+    const bool timed = r->adaptive && r->device_mem && tries == 1;
+    if (timed && hipEventRecord(r->ev_xa, r->stream) != hipSuccess) return BH_ERR_HIP;
     const int xs = r->o.let_mode == 1 ? c.all_to_all(c.user, seg, r->buf[X4S], (int64_t)stride * 32, st)
                                       : c.all_gather(c.user, seg, r->buf[X4S], (int64_t)stride * 32, st);
     if (xs) return BH_ERR_COMM;  // X4: LET records, in place
+#ifdef BH_STUDY
+    {  // an exchange that lasts longer, for measurements at world size 1 (tools/r5_fake_x4.sh)
+      static const int fake_us = getenv("BH_DD_FAKE_X4_US") ? atoi(getenv("BH_DD_FAKE_X4_US")) : 0;
+      if (fake_us > 0 && r->ctx && bh_dd_idle_wave(r->ctx, fake_us)) return BH_ERR_HIP;
+    }
+#endif
+    if (timed) {
+      if (hipEventRecord(r->ev_xb, r->stream) != hipSuccess) return BH_ERR_HIP;
+      r->x4_timed = true;
+    }
     if (failed) {
       r->left_rank = c.rank;
       r->left_status = failed;
@@ -451,7 +499,10 @@ int rank_one_step(bh_rank* r) {
       }
       if (r->let_counts[q] > need) need = r->let_counts[q];
     }
-    if (fits) break;
+    if (fits) {
+      r->stride_last = stride;
+      break;
+    }
     if (need > r->plan.let_cap) {  // every rank sees the same counts
       r->left_rank = -1;
       r->left_status = 0;
@@ -673,9 +724,11 @@ static void rank_common_init(bh_rank* r, const bh_comm* comm, const bh_rank_plan
   r->comm = *comm;
   r->plan = *plan;
   r->o = *o;
-  // two passes hide X4 — where a rank's launches fill the GPU: a rank of the strong-scaling sizes (125,000 bodies) runs
-  // three launches of some tens of microseconds each instead of one; one rank has nothing remote
-  if (r->o.split < 0) r->o.split = (comm->world > 1 && plan->n_cap >= 400000) ? 1 : 0;
+  // one pass unless told otherwise: measured (rank_adapt) the split pays only for an exchange of ~0.18 ms and more
+  if (r->o.split < 0) r->o.split = 0;
+  // (the adaptive form only where two passes can pay at all: ranks whose launches fill the GPU, more than one rank)
+  r->adaptive = r->o.split == 2 && comm->world > 1 && plan->n_cap >= 400000;
+  r->split_now = r->o.split == 1 ? 1 : 0;
   r->stride = plan->stride0;
   r->mig_stride = plan->mig_cap < 4096 ? plan->mig_cap : 4096;
   if (o->log) r->log = new (std::nothrow) std::vector<int32_t>();
@@ -731,10 +784,10 @@ int bh_rank_create(bh_rank** out, const bh_comm* comm, int64_t n_total, const bh
                          plan.sz.pool_records);
   if (!s) s = bh_dd_set_let_mode(r->ctx, o.let_mode);
   if (!s && o.serial) s = bh_dd_set_serial(r->ctx, 1);
-  // two-pass steps split the walk of the first 20 % of a rank's bodies unless told otherwise: their own pass — launched
-  // behind the LET export, beside X4 — lasts ~0.2 ms at 1M bodies per rank, an X4 of up to ~0.2 ms disappears behind it,
-  // and every 10 % cost ~0.03 ms of extra walk
-  if (!s) s = bh_dd_set_split_percent(r->ctx, o.split_pct <= 0 ? 20 : (o.split_pct > 100 ? 100 : o.split_pct));
+  if (!s && r->adaptive && (hipEventCreate(&r->ev_xa) != hipSuccess || hipEventCreate(&r->ev_xb) != hipSuccess)) s = BH_ERR_HIP;
+  // two-pass steps (split 1) split the walk of the first 30 % of a rank's bodies unless told otherwise: their own pass —
+  // launched behind the LET export, beside X4 — lasts ~0.3 ms at 1M bodies per rank and covers an X4 of ~0.2 ms
+  if (!s) s = bh_dd_set_split_percent(r->ctx, o.split_pct <= 0 ? 30 : (o.split_pct > 100 ? 100 : o.split_pct));
   if (s) {
     r->comm.release = nullptr;
     bh_rank_destroy(r);
@@ -809,6 +862,8 @@ int bh_rank_get_info(bh_rank* r, bh_rank_info* o) {
   o->left_rank = r->left_rank;
   o->left_status = r->left_status;
   o->steps = r->steps;
+  o->split_now = r->split_now;
+  o->x4_us = r->x4_samples > 0 ? (int32_t)(r->x4_ema_ms * 1000.0f + 0.5f) : -1;
   memcpy(o->let_counts, r->let_counts, sizeof(o->let_counts));
   return BH_OK;
 }
@@ -868,6 +923,38 @@ int bh_rank_read_log(bh_rank* r, int32_t* pairs, int capacity_pairs, int* n_pair
   return BH_OK;
 }
 
+// Measurement only: see include/bh.h.  The rank's buffers still hold the last step's gathered descriptors, the pool its
+// tree and the imported segments; the exchange itself is not repeated.
+int bh_rank_replay_force_phase(bh_rank* r, int split, int split_pct, int x4_us, int reps, float* ms) {
+  if (!r || !ms || reps < 1 || x4_us < 0 || (split && (split_pct < 1 || split_pct > 100))) return BH_ERR_BAD_ARG;
+  if (!r->ctx || !r->device_mem || r->steps < 1 || r->stride_last <= 0) return BH_ERR_ORDER;
+  if (hipSetDevice(r->device) != hipSuccess) return BH_ERR_NO_DEVICE;
+  int saved[4];
+  int s = bh_dd_replay_begin(r->ctx, split, split_pct, saved);
+  if (s) return s;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) s = BH_ERR_HIP;
+  double sum = 0.0;
+  int32_t counts[kMaxWorld];
+  for (int rep = -1; rep < reps && !s; rep++) {  // one untimed round first
+    if (hipEventRecord(e0, r->stream) != hipSuccess) s = BH_ERR_HIP;
+    if (!s) s = bh_dd_phase_let(r->ctx, r->buf[X3R], r->buf[X4S], r->stride_last, split ? 1 : 0);
+    if (!s) s = bh_dd_idle_wave(r->ctx, x4_us);
+    int fits = 0;
+    if (!s) s = bh_dd_phase_force(r->ctx, r->buf[X3R], r->stride_last, counts, &fits);
+    if (!s && !fits) s = BH_ERR_SMALL_BUFFER;
+    if (!s && (hipEventRecord(e1, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess)) s = BH_ERR_HIP;
+    float t = 0.0f;
+    if (!s && hipEventElapsedTime(&t, e0, e1) != hipSuccess) s = BH_ERR_HIP;
+    if (rep >= 0) sum += t;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  const int s2 = bh_dd_replay_end(r->ctx, saved);
+  *ms = (float)(sum / reps);
+  return s ? s : s2;
+}
+
 void bh_rank_destroy(bh_rank* r) {
   if (!r) return;
   if (r->device_mem) (void)hipSetDevice(r->device);
@@ -879,6 +966,8 @@ void bh_rank_destroy(bh_rank* r) {
     rk_prof_clear(r);
     delete r->prof_ev;
   }
+  if (r->ev_xa) (void)hipEventDestroy(r->ev_xa);
+  if (r->ev_xb) (void)hipEventDestroy(r->ev_xb);
   delete r->log;
   if (r->own_buf)
     for (int k = 0; k < 8; k++)

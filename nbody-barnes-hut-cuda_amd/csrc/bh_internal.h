@@ -308,6 +308,11 @@ int bhk_force_walk_rows(const bh_ctx* c);               // waves (rows) of that 
 hipError_t bhk_force_trace(bh_ctx* c, u32* trace, int cap_rows, int* rows);  // measurement: one row per wave
 hipError_t bhk_integrate(bh_ctx* c, bool with_bbox);
 void bh_dd_free(bh_ctx* c);  // bh_dd.hip
+// measurement (bh_rank_replay_force_phase, bh_group.hip): the force phase of the last completed step run again
+extern "C" int bh_dd_replay_begin(bh_ctx* c, int split, int split_pct, int saved[4]);
+extern "C" int bh_dd_replay_end(bh_ctx* c, const int saved[4]);
+extern "C" int bh_dd_idle_wave(bh_ctx* c, int us);
+extern "C" int bh_dd_set_one_pass(bh_ctx* c);
 
 // device-wide scans (bh_scan.hip)
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);

@@ -265,11 +265,11 @@ def global_morton_order(pkg, ic, device, params=None, **kw):
         return e.download_order()
 
 
-# Force passes per step when the caller does not choose: None = the library's rule (bh_rank_opts.split -1): with more
-# than one rank and ranks large enough to fill the GPU (capacity >= 400,000 bodies) the walk of the first 20 % of a
-# rank's bodies is split in two passes — own pieces on a side stream behind the LET export, while X4 is in flight;
-# remote pieces after X4, beside the one pass of the other bodies (profiles/r05_dd/split_vs_one_pass.txt,
-# two_stream_overlap_world1.txt) —, else one pass after X4.
+# Force passes per step when the caller does not choose: None = the library's rule (bh_rank_opts.split -1): ONE pass
+# after X4.  split=True: the walk of the first split_pct (30) per cent of a rank's bodies in two passes — own pieces on a
+# side stream behind the LET export, while X4 is in flight; remote pieces after X4, beside the one pass of the other
+# bodies.  split="adaptive" (bh_rank_opts.split 2; bench.py): one pass while the measured X4 is short, the split form
+# once it lasts ~0.2 ms and more — where it pays (profiles/r05_dd/replay_8x1M.txt, fake_x4_world1.txt).
 SPLIT_DEFAULT = None
 
 # X4 flavour of DomainStepper when the caller does not choose: per-destination segments + all-to-all
@@ -295,7 +295,7 @@ class DomainStepper:
         self.pkg, self.comm = pkg, comm
         if split is None:
             split = SPLIT_DEFAULT
-        self.split = None if split is None else bool(split)   # None: the library's rule, read back below
+        self.split = None if split is None else (2 if split == "adaptive" else int(bool(split)))
         self.let_mode = LET_MODE_DEFAULT if let_mode is None else int(let_mode)
         self.world, self.rank = comm.world, comm.rank
         P, r = self.world, self.rank
@@ -323,8 +323,8 @@ class DomainStepper:
         st = L.lib.bh_rank_query(n, P, C.byref(o), C.byref(plan))
         if st != 0:
             raise pkg.BhError(st, "bh_rank_query")
-        if self.split is None:   # (bh_rank_opts.split -1: two passes when the rank's launches fill the GPU)
-            self.split = P > 1 and plan.n_cap >= 400000
+        if self.split is None:   # (bh_rank_opts.split -1: one pass)
+            self.split = 0
         self.stream = stream if stream is not None else torch.cuda.Stream(device)
         bufs = None
         self._buffers = []
@@ -462,6 +462,7 @@ class DomainStepper:
         L.lib.bh_rank_get_info(self._h, C.byref(i))
         self.n_loc, self.stride, self.mig_stride, self.mig_last = i.n_loc, i.stride, i.mig_stride, i.mig_last
         self.mig_rounds, self.let_retries = i.mig_rounds, i.let_retries
+        self.split_now, self.x4_us = int(i.split_now), int(i.x4_us)   # (adaptive form: what it runs now, measured X4)
         self.let_counts = np.array(i.let_counts[:self.world], np.int32) if i.steps or i.let_retries else None
         self._info = i
         if getattr(self, "e", None) is not None and hasattr(self.e, "_h") and i.n_loc:

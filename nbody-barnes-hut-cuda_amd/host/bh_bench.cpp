@@ -17,6 +17,11 @@
 //                                transport (one-GPU rehearsal of G ranks)
 //            [--split | --one-pass]  two force passes per step (own pieces beside X4, then the remote pass: the
 //                                default with more than one rank) or one pass after X4
+//            [--split-pct P]     per cent of a rank's bodies whose walk is split (default 20)
+//            [--replay | --replay-rank Q]  after the run (Q: that rank only): every rank's force phase of the last step run again on its own
+//                                streams with nothing else on the GPU, one pass / 20 / 30 / 100 % split, an idle
+//                                wave of 0 / 125 / 250 us in the place of X4 (one-GPU rehearsals: what a rank-step
+//                                spends between X3 and its end on a GPU of its own)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +46,8 @@ static double now_ms() {
 
 // the frame loop of main() (ref:353-367) over bh_step_group: every rank steps, then the whole node is synchronised
 static int run_group(int N, int frames, int warmup, bool quiet, const bh_params& p, const std::vector<int>& devs,
-                     int split, int split_pct, const char* ic_name, std::vector<float>* a, const char* dump_path, const char* snap_path) {
+                     int split, int split_pct, const char* ic_name, std::vector<float>* a, const char* dump_path, const char* snap_path,
+                     bool replay, int replay_rank) {
   bh_rank_opts o;
   bh_rank_default_opts(&o);
   o.split = split;
@@ -86,6 +92,30 @@ static int run_group(int N, int frames, int warmup, bool quiet, const bh_params&
          "rounds %d LET retries %d\n",
          ph_steps, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], info.n_loc, info.stride, info.mig_last, info.mig_rounds,
          info.let_retries);
+  if (replay) {
+    // Between X3 and the end of the force on a GPU of its own, rank by rank (the others idle): the last step's force
+    // phase run again in every form, an idle wave in the place of X4 (bh_rank_replay_force_phase)
+    CK(bh_group_sync(g));
+    const int x4[3] = {0, 125, 250};
+    const int forms[4][2] = {{0, 0}, {1, 20}, {1, 30}, {1, 100}};
+    printf("\nforce phase of the last step, replayed per rank on its own streams, ms (LET kernels -> end of the last force "
+           "launch; X4 = an idle wave)\nrank | form            | X4 0 us | 125 us | 250 us\n");
+    double mean[4][3] = {};
+    for (int q = 0; q < (int)devs.size(); q++)
+      for (int f = 0; f < 4 && (replay_rank < 0 || q == replay_rank); f++) {
+        float ms[3];
+        for (int k = 0; k < 3; k++) CK(bh_rank_replay_force_phase(bh_group_rank(g, q), forms[f][0], forms[f][1], x4[k], 5, &ms[k]));
+        char name[32];
+        if (forms[f][0]) snprintf(name, sizeof(name), "first %3d %% split", forms[f][1]); else snprintf(name, sizeof(name), "one pass");
+        printf("%4d | %-15s | %7.3f | %6.3f | %6.3f\n", q, name, ms[0], ms[1], ms[2]);
+        for (int k = 0; k < 3; k++) mean[f][k] += ms[k] / (double)devs.size();
+      }
+    for (int f = 0; f < 4; f++) {
+      char name[32];
+      if (forms[f][0]) snprintf(name, sizeof(name), "first %3d %% split", forms[f][1]); else snprintf(name, sizeof(name), "one pass");
+      printf("mean | %-15s | %7.3f | %6.3f | %6.3f\n", name, mean[f][0], mean[f][1], mean[f][2]);
+    }
+  }
   if (dump_path || snap_path) {
     CK(bh_group_download(g, a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data()));
     if (dump_path)
@@ -105,6 +135,8 @@ int main(int argc, char** argv) {
   int gpus = 0;
   bool dist = false;
   int split = -1, split_pct = 0;
+  bool replay = false;
+  int replay_rank = -1;
   std::vector<int> devs;
   int frames = 1000;  // ref:353
   int warmup = 0;
@@ -136,6 +168,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--dist")) dist = true;
     else if (!strcmp(argv[i], "--split")) split = 1;
     else if (!strcmp(argv[i], "--one-pass")) split = 0;
+    else if (!strcmp(argv[i], "--replay")) replay = true;
+    else if (arg("--replay-rank")) { replay = true; replay_rank = atoi(argv[++i]); }
     else if (arg("--split-pct")) split_pct = atoi(argv[++i]);
     else if (arg("--dump")) dump_path = argv[++i];
     else if (arg("--snapshot")) snap_path = argv[++i];
@@ -162,7 +196,7 @@ int main(int argc, char** argv) {
       for (int q = 0; q < (gpus > 0 ? gpus : 1); q++) devs.push_back(device + q);
     std::vector<float> a[7] = {x, y, z, vx, vy, vz, m};
     return run_group(N, frames, warmup, quiet, p, devs, split, split_pct,
-                     plummer ? "plummer" : (msvc ? "disc(msvc rand)" : "disc"), a, dump_path, snap_path);
+                     plummer ? "plummer" : (msvc ? "disc(msvc rand)" : "disc"), a, dump_path, snap_path, replay, replay_rank);
   }
 
   bh_ctx* c = nullptr;

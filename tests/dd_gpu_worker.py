@@ -17,7 +17,7 @@ import bhpkg  # noqa: E402
 
 def main():
     out_path, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    split = {"one": False, "two": True, "auto": None}[sys.argv[4] if len(sys.argv) > 4 else "auto"]
+    split = {"one": False, "two": True, "auto": None, "adaptive": "adaptive"}[sys.argv[4] if len(sys.argv) > 4 else "auto"]
     split_pct = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     dist.init_process_group("gloo")
     torch.cuda.set_device(0)
@@ -49,7 +49,9 @@ def main():
         p1 = np.stack([x, y, z], 1)
         a1 = np.stack([ax, ay, az], 1)
         rel = np.linalg.norm(a - a1, axis=1) / np.maximum(np.linalg.norm(a1, axis=1), 1e-30)
+        st._sync_info()
         json.dump({"world": world, "owned_once": bool((seen == 1).all()), "flags": fl,
+                   "split_now": st.split_now, "x4_us": st.x4_us,
                    "max_dpos": float(np.abs(pos - p1).max()), "acc_rel_median": float(np.median(rel)),
                    "acc_rel_max": float(rel.max())}, open(out_path, "w"))
     dist.barrier()

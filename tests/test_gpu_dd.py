@@ -725,3 +725,51 @@ class _DevBytes:
     def __init__(self, ptr, nbytes):
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
                                          "version": 2}
+
+
+def test_replayed_force_phase_leaves_the_run_as_it_was():
+    """bh_rank_replay_force_phase (measurement: the last step's LET kernels, an idle wave for X4, validation, top
+    trees and force passes run again on the rank's own two streams, without integration) returns a positive time for
+    every form — also the two-pass forms on ranks that step with one pass — and the run continues bit for bit as if
+    it had not been called: 3 ranks x 20,000 bodies, 3 steps, replays, 2 steps == 5 steps."""
+    import ctypes as C
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import _lib as L
+    n, world = 60000, 3
+    ic = pkg.plummer(n, seed=5)
+    F = L._F
+
+    def run(replay):
+        g = C.c_void_p()
+        dev = (C.c_int * world)(*([0] * world))
+        assert L.lib.bh_create_group(C.byref(g), world, dev, n, None, None, 0) == 0
+        try:
+            assert L.lib.bh_group_upload(g, *[np.ascontiguousarray(a).ctypes.data_as(F) for a in ic]) == 0
+            ms = C.c_float()
+            # before any step there is nothing to replay
+            assert L.lib.bh_rank_replay_force_phase(L.lib.bh_group_rank(g, 0), 0, 0, 0, 1, C.byref(ms)) == -6  # BH_ERR_ORDER
+            assert L.lib.bh_step_group(g, 3) == 0 and L.lib.bh_group_sync(g) == 0
+            times = []
+            if replay:
+                for q in range(world):
+                    for split, pct, us in ((0, 0, 0), (1, 20, 0), (1, 100, 50), (0, 0, 100)):
+                        assert L.lib.bh_rank_replay_force_phase(L.lib.bh_group_rank(g, q), split, pct, us, 2, C.byref(ms)) == 0
+                        times.append((split, pct, us, ms.value))
+                assert L.lib.bh_rank_replay_force_phase(L.lib.bh_group_rank(g, 0), 1, 0, 0, 1, C.byref(ms)) == -1  # bad pct
+            assert L.lib.bh_step_group(g, 2) == 0 and L.lib.bh_group_sync(g) == 0
+            st6 = [np.full(n, np.nan, np.float32) for _ in range(6)]
+            assert L.lib.bh_group_download(g, *[a.ctypes.data_as(F) for a in st6]) == 0
+            acc = [np.full(n, np.nan, np.float32) for _ in range(3)]
+            assert L.lib.bh_group_download_acc(g, *[a.ctypes.data_as(F) for a in acc]) == 0
+            return st6 + acc, times
+        finally:
+            L.lib.bh_destroy_group(g)
+
+    a, times = run(True)
+    b, _ = run(False)
+    assert all(t[3] > 0.0 for t in times)
+    # an idle wave of 100 us in the place of X4 shows in the one-pass form
+    one = [t[3] for t in times if t[0] == 0]
+    assert all(one[2 * q + 1] > one[2 * q] + 0.05 for q in range(world))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

@@ -104,8 +104,8 @@ def test_bench_two_ranks_domain_fallback_is_collective():
 def test_domain_stepper_multiprocess_one_gpu(world, split, pct, tmp_path):
     """the real multi-process flow of the domain-decomposed step (torch.distributed, one process per rank, every rank
     with its OWN main and side stream — the in-process tests serialise a rank's launches on one stream) with `world`
-    ranks sharing this one GPU over the gloo backend; one pass, the default partial two-pass form (own pass of the
-    first 30 % beside the LET kernels and X4, then their remote pass beside the one pass of the rest: two launches at
+    ranks sharing this one GPU over the gloo backend; one pass, the partial two-pass form (own pass of the
+    first 30 % behind the LET export, beside X4, then their remote pass beside the one pass of the rest: two launches at
     once that share one fold) and every body in two passes; rank 0 compares the gathered state with a single-context
     run (tests/dd_gpu_worker.py)"""
     env = dict(os.environ)
@@ -136,6 +136,26 @@ def test_domain_stepper_multiprocess_large_ranks_two_launches_at_once(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.loads(out.read_text())
     assert res["world"] == 2 and res["owned_once"] and res["flags"] == 0
+    assert res["max_dpos"] < 5e-2, res
+    assert res["acc_rel_median"] < 1e-4, res
+
+
+def test_adaptive_form_turns_the_split_on_when_the_exchange_is_slow(tmp_path):
+    """bh_rank_opts.split 2 (what bench.py uses under torchrun): the rank times X4 with events on its stream and walks
+    part of its bodies in two passes once the exchange lasts ~0.2 ms and more.  Here X4 goes through gloo (device ->
+    host -> TCP -> device: milliseconds), so after the first few steps of 2 x 500,000 bodies the split form must be
+    on, the measured duration reported, and the state still that of the single-context run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = tmp_path / "dd.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dd_gpu_worker.py"), str(out), "1000000", "8", "adaptive", "0"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(out.read_text())
+    assert res["world"] == 2 and res["owned_once"] and res["flags"] == 0
+    assert res["x4_us"] > 200 and res["split_now"] == 1, res
     assert res["max_dpos"] < 5e-2, res
     assert res["acc_rel_median"] < 1e-4, res
 
