@@ -32,8 +32,8 @@
 // The stitched pool [local tree + body digests | two top trees | world x LET segment] is the same canonical octree a
 // single GPU builds; the unchanged force walk traverses it from a top-tree root.
 //
-// Force passes: one pass over the stitched tree after X4, or — the default with more than one rank, for the first
-// split_pct per cent of the rank's bodies — two: the own pieces (two thirds of the pair work; they need nothing from
+// Force passes: one pass over the stitched tree after X4 (the default), or — the split form, for the first split_pct
+// per cent of the rank's bodies; it pays when X4 lasts ~0.1 ms and more: bh_group.hip rank_adapt — two: the own pieces (two thirds of the pair work; they need nothing from
 // other ranks) on a side stream, launched behind the LET export, with the other ranks' pieces as null records and
 // every top cell carrying this rank's share of its mass, while the main stream runs X4; then the mirror image (top
 // tree re-emitted from the first one's structure), whose launch adds the own pass's accelerations — beside the ONE

@@ -15,9 +15,9 @@
 //            [--dist]            with --gpus 1: the multi-GPU step at world size 1 (RCCL path on one GPU)
 //            [--devices a,b,..]  explicit device per rank; a device listed twice selects the in-process
 //                                transport (one-GPU rehearsal of G ranks)
-//            [--split | --one-pass]  two force passes per step (own pieces beside X4, then the remote pass: the
-//                                default with more than one rank) or one pass after X4
-//            [--split-pct P]     per cent of a rank's bodies whose walk is split (default 20)
+//            [--split | --one-pass]  the first part of a rank's bodies in two force passes (own pieces beside X4,
+//                                then the remote pass) or one pass after X4 (the default)
+//            [--split-pct P]     per cent of a rank's bodies whose walk is split (default 30)
 //            [--replay | --replay-rank Q]  after the run (Q: that rank only): every rank's force phase of the last step run again on its own
 //                                streams with nothing else on the GPU, one pass / 20 / 30 / 100 % split, an idle
 //                                wave of 0 / 125 / 250 us in the place of X4 (one-GPU rehearsals: what a rank-step
