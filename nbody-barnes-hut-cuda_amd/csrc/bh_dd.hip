@@ -115,6 +115,7 @@ struct bh_dd_state {
   int* host;       // pinned: [world] LET counts, [64 .. 67] migration results, [68] their sequence number
   hipEvent_t ev_let;  // the LET export of this step has finished (main stream): the own pass may take the GPU
   bool replay;        // bh_dd_replay_begin .. _end (measurement): the force passes do not integrate
+  bool top_early;     // one-pass step: the top tree's structure was built beside the LET kernels (dd_top_early)
   bool let_copy_pending;
   int* host_rows;  // pinned: [world][32] header + needs row (records 0..3) of every received X4 segment
   int let_mode;    // 0: X4 is an all-gather of the union every other rank may open; 1: per-destination segments
@@ -1399,14 +1400,29 @@ __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ 
                                                           int* __restrict__ host_rows, int* __restrict__ host_seq,
                                                           int seq) {
   if (blockIdx.x == 0) {
+    __shared__ int s_rows[64 * 32];
+    __shared__ int s_hold;
+    if (threadIdx.x == 0) s_hold = 0;
     for (int i = threadIdx.x; i < world * 32; i += 256) {
       const int q = i >> 5, dw = i & 31;
       const int v = reinterpret_cast<const int*>(pool)[((size_t)seg_base + (size_t)q * stride) * 8 + dw];
+      s_rows[i] = v;
       __hip_atomic_store(host_rows + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's row words have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the decision bh_dd_let_check takes on the host from these rows, taken here too: the force launches are enqueued
+    // before the host has seen them and hold themselves back if the exchange has to be repeated (bh_devinfo.dd_hold)
+    for (int q = threadIdx.x; q < world; q += 256) {
+      const int* seg = s_rows + 32 * q;
+      int need = seg[10];  // header record 0, field `first`; negative: that rank left the step
+      if (need >= 0)
+        for (int j = 0; j < world; j++) need = max(need, seg[seg_row_dword(j)]);
+      if (need < 0 || need > stride) atomicOr(&s_hold, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) info->dd_hold = s_hold;
   }
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)world * stride) return;
@@ -2258,6 +2274,25 @@ static int dd_force_local_launch(bh_ctx* c, bool after_let) {
   return BH_OK;
 }
 
+// One-pass step: the top tree's STRUCTURE (child ranges, branching levels, block offsets, prefix sums of the pieces'
+// fp64 sums) needs X3 only — one block, 16 us — so it is built on the side stream beside the LET kernels, as the tree
+// of an own pass would be (remote pieces null); after X4 bh_dd_top only re-emits the records with every piece real
+// (dd_top_emit_kernel, 5 us): 11 us less between X4 and the force launch.
+static int dd_top_early(bh_ctx* c, const void* gathered_x3) {
+  bh_dd_state* d = c->dd;
+  hipStream_t so = d->serial ? c->stream : d->stream_own;
+  BH_HIP(c, hipEventRecord(d->ev_x3, c->stream));  // the X3 gather and the local tree are complete here
+  BH_HIP(c, hipStreamWaitEvent(so, d->ev_x3, 0));
+  dd_top_kernel<<<1, 1024, 0, so>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool, d->top_base2,
+                                    d->seg_base, kSegBlocks0, c->bounds, c->p.G, c->p.theta,
+                                    d->top_ps + (kTopMax + 1), d->top_a + kTopCap, d->top_b + kTopCap,
+                                    d->top_ci + kTopCap, d->ddi, c->info, 1);
+  BH_HIP(c, hipGetLastError());
+  BH_HIP(c, hipEventRecord(d->ev_top1, so));
+  d->top_early = true;
+  return BH_OK;
+}
+
 // Own pass of the two-pass force, on the side stream: it needs only the gathered piece descriptors and
 // the local tree, so it runs while the X4 exchange occupies the main stream.  Top tree of this pass: other
 // ranks' pieces are null records, top cells carry this rank's share of their mass (bh_dd_top builds the mirror
@@ -2305,6 +2340,13 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
           (const bh_dd_piece*)gathered_x3, d->rank, d->pool, d->top_base3, d->seg_base, stride, c->bounds, c->p.G,
           c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + kTopCap, d->top_b + kTopCap,
           d->top_ci + kTopCap, d->ddi, 0);
+  } else if (d->top_early) {  // one pass: structure built beside the LET kernels (dd_top_early), every piece real
+    d->top_early = false;
+    BH_HIP(c, hipStreamWaitEvent(c->stream, d->ev_top1, 0));
+    dd_top_emit_kernel<<<(kTopCap + 255) / 256, 256, 0, c->stream>>>(
+        (const bh_dd_piece*)gathered_x3, d->rank, d->pool, d->top_base, d->seg_base, stride, c->bounds, c->p.G,
+        c->p.theta, d->top_ps + (kTopMax + 1), d->top_a + kTopCap, d->top_b + kTopCap,
+        d->top_ci + kTopCap, d->ddi, 0);
   } else {
     dd_top_kernel<<<1, 1024, 0, c->stream>>>((const bh_dd_piece*)gathered_x3, d->world, d->rank, d->pool,
                                              d->top_base, d->seg_base, stride, c->bounds, c->p.G, c->p.theta,
@@ -2421,6 +2463,9 @@ int bh_dd_phase_let(bh_ctx* c, const void* gathered_x3, void* send_x4, int strid
     int s = dd_force_local_prepare(c, gathered_x3);
     if (!s && !after_let) s = dd_force_local_launch(c, false);
     if (s) return s;
+  } else if (!c->dd->split) {
+    const int s = dd_top_early(c, gathered_x3);
+    if (s) return s;
   }
   int s = bh_dd_let_pack(c, gathered_x3, send_x4, stride);
   if (!s && own_pass && after_let) s = dd_force_local_launch(c, true);
@@ -2435,19 +2480,28 @@ int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* c
   if (s) return s;
   int32_t own_counts[64];  // a caller that does not ask for the counts must still not walk a departed rank's LET
   if (!counts) counts = own_counts;
-  s = bh_dd_let_check(c, stride, counts);
-  if (fits) *fits = (s == BH_OK) ? 1 : 0;
-  if (s == BH_ERR_SMALL_BUFFER) return BH_OK;  // the caller repeats X4 with a larger stride
-  if (s) return s;
-  for (int q = 0; q < c->dd->world; q++)
-    if (counts[q] < 0) {  // a rank left the step: the caller raises on every rank, nothing to walk
-      if (fits) *fits = 0;
-      return counts == own_counts ? BH_ERR_DOMAIN_LEFT : BH_OK;
-    }
+  // The force launches go out BEFORE the host has looked at the X4 headers: the validation kernel takes the same
+  // decision on the device (bh_devinfo.dd_hold) and a launch behind an exchange that has to be repeated — or that a rank
+  // has left — returns at once.  The host's look (a polled pinned word) then costs the step nothing.
   // (one rank in two passes: the remote pass walks nothing but the top record, and a launch that short integrates
   // slower than the streaming kernel does — 0.100 against 0.055 + 0.021 ms at 1M bodies; one pass integrates as
   // bh_step's launch does)
-  return dd_force_impl(c, !c->dd->replay && (c->dd->world > 1 || !c->dd->split));
+  const int stage0 = c->stage;
+  s = dd_force_impl(c, !c->dd->replay && (c->dd->world > 1 || !c->dd->split));
+  if (s) return s;
+  s = bh_dd_let_check(c, stride, counts);
+  bool left = false;
+  if (s == BH_OK || s == BH_ERR_SMALL_BUFFER)
+    for (int q = 0; q < c->dd->world; q++) left = left || counts[q] < 0;
+  if (s != BH_OK || left) {  // the launches held themselves back: nothing was walked, nothing integrated
+    c->dd_integrated = false;
+    c->stage = stage0;
+  }
+  if (fits) *fits = (s == BH_OK && !left) ? 1 : 0;
+  if (s == BH_ERR_SMALL_BUFFER && !left) return BH_OK;  // the caller repeats X4 with a larger stride
+  if (s != BH_OK && s != BH_ERR_SMALL_BUFFER) return s;
+  if (left) return counts == own_counts ? BH_ERR_DOMAIN_LEFT : BH_OK;  // the caller raises on every rank
+  return BH_OK;
 }
 
 int bh_dd_phase_end(bh_ctx* c, void* send_x1) {

@@ -947,6 +947,12 @@ __device__ __forceinline__ void trace_row(u32* tr, int row, u32 t0) {
 // a three-pair record window, the walk in s10 .. s73, 80 scalar registers for the whole kernel -> 8 waves (the
 // compiler's own values live in VGPR lanes across the walk: 62 spilled SGPRs, 64 VGPRs, no scratch)
 #define BH_WALK_SGPRS __attribute__((amdgpu_num_sgpr(80)))
+// Domain-decomposed step: the launch was enqueued behind an X4 whose fit the host had not yet looked at; the
+// validation kernel has (bh_devinfo.dd_hold, bh_dd.hip): the exchange is repeated, or a rank has left — nothing to
+// walk.  One scalar load per workgroup; always zero outside the decomposed step.
+__device__ __forceinline__ bool force_held(const bh_devinfo* info) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&info->dd_hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+}
 template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const float* __restrict__ frec_g,
                                                          const float4* posm,  // (FUSE: fz.posm is the same buffer)
@@ -954,6 +960,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const flo
                                                          float eps2, int xcd_mode,
                                                          bh_devinfo* __restrict__ info, int root, int budget,
                                                          int group, bh_fuse_args fz = bh_fuse_args{}) {
+  if (force_held(info)) return;
   cfloat_t* frec = (cfloat_t*)frec_g;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
@@ -1234,6 +1241,7 @@ __global__ __launch_bounds__(512) BH_WALK_SGPRS void force_coop_kernel(const flo
                                                          int xcd_mode, bh_devinfo* __restrict__ info, int group,
                                                          bh_fuse_args fz, int root = 0) {
   extern __shared__ __attribute__((aligned(16))) u32 coop_lds[];
+  if (force_held(info)) return;
   const int K = (int)(blockDim.x >> 6);
   const int g = block_chunk(xcd_mode);  // one group per workgroup
   // (lo is a multiple of the group size: lo / group + g is the group's index among all groups of the context — what
@@ -1264,6 +1272,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
                                                           bh_fuse_args fz, int root = 0, int g0 = 0) {
   // g0: the launch covers the groups g0 .. of the context (bodies [64 g0, hi)), gb of them by one wave each
   __shared__ __attribute__((aligned(16))) u32 coop_lds[coop_lds_bytes(kMixedK, SUBSH) / 4];
+  if (force_held(info)) return;
   const int lane = threadIdx.x & 63;
   const int wib = rfl((int)(threadIdx.x >> 6));
   if ((int)blockIdx.x >= nbulk) {

@@ -86,7 +86,10 @@ struct bh_devinfo {
   int flags;       // BH_FLAG_*
   int redo_waves;  // force waves that redid their walk with the generic loop (stack > 64 entries or a block of > 8 children)
   int slow_buckets;  // splitter-sort buckets that did not fit LDS (sorted by one workgroup through global memory)
-  int pad[2];
+  int dd_hold;     // domain-decomposed step: the X4 that just arrived does not fit or a rank has left (dd_validate_kernel):
+                   // the force launches enqueued behind it return at once (bh_force.hip force_held) — they are enqueued
+                   // before the host has looked at the headers, which it does while they run
+  int pad[1];
 };
 
 struct bh_ctx {
