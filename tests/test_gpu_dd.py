@@ -773,3 +773,24 @@ def test_replayed_force_phase_leaves_the_run_as_it_was():
     assert all(one[2 * q + 1] > one[2 * q] + 0.05 for q in range(world))
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_let_that_outgrows_its_stride_is_exchanged_again_and_the_held_back_launches_do_no_harm(split):
+    """The force launches of a step are enqueued BEFORE the host has read the X4 headers; the validation kernel takes
+    the fit decision on the device (bh_devinfo.dd_hold) and a launch behind an exchange that does not fit returns at
+    once.  theta = 0.2 with 2 ranks x 30,000 bodies needs several times the first stride (516 + capacity / 8): the
+    first step must repeat X4 (let_retries >= 1 on every rank, the same number) — one pass and the two-pass form, whose
+    own pass runs once — and still give the single-context step's forces and positions."""
+    pkg = bhpkg.load()
+    n, world = 60000, 2
+    ic = pkg.plummer(n, seed=11)
+    p1, v1, a1 = single(ic, 2, theta=0.2)
+    out = run_ranks(world, ic, 2, split=split, theta=0.2)
+    retries = [o[5] for o in out]
+    assert retries[0] >= 1 and len(set(retries)) == 1, retries
+    p, v, a = merge(out, n)
+    e = rel(a, a1)
+    assert np.median(e) < 5e-6, np.median(e)
+    assert np.quantile(e, 0.9999) < 2e-4, np.quantile(e, 0.9999)
+    assert np.abs(p - p1).max() < 2e-3
