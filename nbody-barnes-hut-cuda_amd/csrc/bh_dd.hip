@@ -116,6 +116,7 @@ struct bh_dd_state {
   hipEvent_t ev_let;  // the LET export of this step has finished (main stream): the own pass may take the GPU
   bool replay;        // bh_dd_replay_begin .. _end (measurement): the force passes do not integrate
   bool top_early;     // one-pass step: the top tree's structure was built beside the LET kernels (dd_top_early)
+  bool keys_spec;     // the key kernel of this step's sort was launched while the host waited for the body count
   bool let_copy_pending;
   int* host_rows;  // pinned: [world][32] header + needs row (records 0..3) of every received X4 segment
   int let_mode;    // 0: X4 is an all-gather of the union every other rank may open; 1: per-destination segments
@@ -2123,9 +2124,22 @@ int bh_dd_migrate_apply(bh_ctx* c, const void* gathered_x2, int limit, int* n_lo
   dd_absorb_copy_kernel<<<blocks, 256, 0, c->stream>>>(g, d->world, limit, f4, cpr, d->rank, n_cap, mine_f, bbase,
                                                        c->posm[c->cur], c->velid[c->cur]);
   BH_HIP(c, hipGetLastError());
-  // the host needs the new body count before it can size the next launches: poll the pinned result words (a
-  // few microseconds after the kernel's store) instead of hipStreamSynchronize (tens of microseconds of wake-up
-  // latency: a 40 us hole on the stream in round 2's trace); bounded, then the stream wait decides
+  // The host needs the new body count before it can size the next launches — but not the first of them: the key
+  // kernel of the splitter sort reads the count the absorb kernel left on the device (nloc) and is launched here on a
+  // bound (what this rank held + every slot of the exchange), so the stream has ~18 us of work while the host polls.
+  // If another migration round follows, its keys are never sorted: bh_dd_migrate_pack voids the bucket counts.
+  d->keys_spec = false;
+  {
+    const long long bound = (long long)c->n + (long long)d->world * limit;
+    const int n_upper = (int)(bound < n_cap ? bound : n_cap);
+    if (c->B == 21 && bhk_sort_split_eligible(c, n_upper)) {
+      BH_HIP(c, bhk_keys_split(c, d->nloc + d->rank, n_upper));
+      d->keys_spec = true;
+    }
+  }
+  // poll the pinned result words (a few microseconds after the kernel's store) instead of hipStreamSynchronize (tens
+  // of microseconds of wake-up latency: a 40 us hole on the stream in round 2's trace); bounded, then the stream wait
+  // decides
   {
     volatile int* hs = d->host + 68;
     bool seen = false;
@@ -2158,7 +2172,10 @@ int bh_dd_tree(bh_ctx* c, void* send_x3) {
   if (!c || !c->dd || !send_x3) return BH_ERR_BAD_ARG;
   if (!(c->stage & BH_ST_BBOX)) return BH_ERR_ORDER;
   bh_dd_state* d = c->dd;
-  BH_HIP(c, bhk_keys(c));
+  if (d->keys_spec && c->keys_split)  // the keys, splitters and bucket counts are on their way (bh_dd_migrate_apply)
+    d->keys_spec = false;
+  else
+    BH_HIP(c, bhk_keys(c));
   c->key_buf = 0;
   BH_HIP(c, bhk_sort(c));
   BH_HIP(c, bhk_build(c, true));  // (+ the fp64 COM prefix scan, riding in the build's launches: as bh_step)

@@ -294,8 +294,8 @@ hipError_t bhk_bounds_from_rows(bh_ctx* c, const float* rows, int nrows, int str
 hipError_t bhk_keys(bh_ctx* c, bool for_sort = true);
 hipError_t bhk_sort(bh_ctx* c);  // sort + gather
 hipError_t bhk_sort_onesweep(bh_ctx* c);              // radix implementation (bh_sort_onesweep.hip)
-bool bhk_sort_split_eligible(const bh_ctx* c);        // splitter sort: keys + bucket counts, then partition + local sort
-hipError_t bhk_keys_split(bh_ctx* c);
+bool bhk_sort_split_eligible(const bh_ctx* c, int n_upper = 0);  // splitter sort: keys + bucket counts, then partition + local sort
+hipError_t bhk_keys_split(bh_ctx* c, const int* n_dev = nullptr, int n_upper = 0);
 hipError_t bhk_sort_split(bh_ctx* c);
 hipError_t bhk_build(bh_ctx* c, bool pm_scan = false);  // pm_scan: + the COM prefix scan (small steps, bh_tree.hip)
 hipError_t bhk_com(bh_ctx* c);

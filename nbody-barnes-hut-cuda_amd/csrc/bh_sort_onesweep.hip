@@ -455,10 +455,22 @@ __global__ __launch_bounds__(kKsThreads) void keys_split_kernel(const float4* __
                                                                int curve, float nb_over_n,
                                                                u64* __restrict__ keys,
                                                                u64* __restrict__ splitters,
-                                                               u32* __restrict__ bcount) {
+                                                               u32* __restrict__ bcount,
+                                                               const int* __restrict__ n_dev = nullptr) {
   __shared__ u64 raw[256];
   __shared__ u64 sp[256];
   __shared__ u32 cnt[256];
+  // n_dev: the body count is still on its way to the host (domain-decomposed step: bh_dd_migrate_apply launches this
+  // kernel on an upper bound while it polls for the count the absorb kernel wrote) — taken from the device, with the
+  // bucket count and the guess scale bhk_sort_split will derive from it on the host; blocks beyond it have nothing to do
+  if (n_dev) {
+    n = max(1, min(*n_dev, n));  // (n: the bound the grid was sized for — a count beyond the rank's capacity is an error
+                                 // the host reports once it has seen it; nothing may be read out of bounds meanwhile)
+    nb = (n + 511) / 512;
+    nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);  // split_buckets
+    nb_over_n = (float)nb / (float)n;
+    if ((int)blockIdx.x * TILE >= n && blockIdx.x != 0) return;
+  }
   const float minX = bounds[0], minY = bounds[1], minZ = bounds[2];
   const float size = bounds[6];  // fmaxf(bounds[3]-bounds[0], 1) ref:55
   const int tid = threadIdx.x, lane = tid & 63;
@@ -962,19 +974,21 @@ static int split_buckets(int n) {
 }
 
 // The splitter sort needs the bodies in (about) key order and buckets that fit LDS with room for drift.
-bool bhk_sort_split_eligible(const bh_ctx* c) {
+bool bhk_sort_split_eligible(const bh_ctx* c, int n_upper) {
   const int v = c->p.sort_variant;
   if (v != 0 && v != 3) return false;
   if (c->p.step_graph == 1) return false;  // the call parity of the bucket counters is not a graph constant
-  if (c->n > 256 * 6144) return false;     // (domain-decomposed contexts: n is the current local body count)
+  // (domain-decomposed contexts: n is the current local body count — or, n_upper, a bound on the count to come)
+  if ((n_upper > 0 ? n_upper : c->n) > 256 * 6144) return false;
   // buckets that overflowed LDS were seen (bh_get_stats): many equal keys or an order that drifted too far — the
   // one-workgroup global-memory path is orders of magnitude slower than eight radix passes
   if (v != 3 && c->splitter_off) return false;
   return v == 3 || c->order_hint;
 }
 
-hipError_t bhk_keys_split(bh_ctx* c) {
-  const int n = c->n;
+// n_dev / n_upper: launch before the host knows the body count (see keys_split_kernel): the grid covers n_upper bodies
+hipError_t bhk_keys_split(bh_ctx* c, const int* n_dev, int n_upper) {
+  const int n = n_dev ? n_upper : c->n;
   u32* bc = c->sp_count + 256 * (c->sp_par & 1);
   if (c->keys_split) {  // counted before and never consumed by a sort: start over
     const hipError_t e = hipMemsetAsync(bc, 0, 256 * sizeof(u32), c->stream);
@@ -982,21 +996,21 @@ hipError_t bhk_keys_split(bh_ctx* c) {
   }
   const int nb = split_buckets(n);
   const bool small = n <= BH_KS_SMALL_N;  // one key per thread: four times the blocks (65,536 bodies: 64)
-  const int grid = small ? (n + 1023) / 1024 : c->sort_tiles;
+  const int grid = small ? (n + 1023) / 1024 : (n + kTile - 1) / kTile;
   if (c->B == 10) {
     if (small)
       keys_split_kernel<10, 1024><<<grid, kKsThreads, 0, c->stream>>>(
-          c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+          c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc, n_dev);
     else
       keys_split_kernel<10, kTile><<<grid, kKsThreads, 0, c->stream>>>(
-          c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+          c->posm[c->cur], c->bounds, n, nb, 0, (float)nb / (float)n, c->keys[0], c->sp_keys, bc, n_dev);
   } else {
     if (small)
       keys_split_kernel<21, 1024><<<grid, kKsThreads, 0, c->stream>>>(
-          c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+          c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc, n_dev);
     else
       keys_split_kernel<21, kTile><<<grid, kKsThreads, 0, c->stream>>>(
-          c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc);
+          c->posm[c->cur], c->bounds, n, nb, c->p.key_curve, (float)nb / (float)n, c->keys[0], c->sp_keys, bc, n_dev);
   }
   c->keys_split = true;
   return hipGetLastError();
