@@ -949,9 +949,12 @@ __device__ __forceinline__ void trace_row(u32* tr, int row, u32 t0) {
 #define BH_WALK_SGPRS __attribute__((amdgpu_num_sgpr(80)))
 // Domain-decomposed step: the launch was enqueued behind an X4 whose fit the host had not yet looked at; the
 // validation kernel has (bh_devinfo.dd_hold, bh_dd.hip): the exchange is repeated, or a rank has left — nothing to
-// walk.  One scalar load per workgroup; always zero outside the decomposed step.
-__device__ __forceinline__ bool force_held(const bh_devinfo* info) {
-  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&info->dd_hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+// walk.
+// `hold` is null for every launch outside the decomposed step (no load at all); the load is issued first thing and
+// consumed after the wave's own position load has been issued, so that it adds no latency of its own to the wave's
+// start (a launch of a few dozen microseconds per workgroup shows a dependent load at its head: +1.5 % at 65,536).
+__device__ __forceinline__ int force_hold_load(const int* hold) {
+  return hold ? __hip_atomic_load(hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 }
 template <int VARIANT, bool BUDGET, bool PF = false, bool FUSE = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const float* __restrict__ frec_g,
@@ -959,8 +962,9 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const flo
                                                          float4* __restrict__ acc, int lo, int hi, float G,
                                                          float eps2, int xcd_mode,
                                                          bh_devinfo* __restrict__ info, int root, int budget,
-                                                         int group, bh_fuse_args fz = bh_fuse_args{}) {
-  if (force_held(info)) return;
+                                                         int group, bh_fuse_args fz = bh_fuse_args{},
+                                                         const int* __restrict__ hold = nullptr) {
+  const int held = force_hold_load(hold);
   cfloat_t* frec = (cfloat_t*)frec_g;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
@@ -977,6 +981,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_fast_kernel(const flo
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
     px = p.x; py = p.y; pz = p.z; pm = p.w;
   }
+  if (__builtin_amdgcn_readfirstlane(held)) return;
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
   const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
   if (m0 == 0) return;  // (a wave without bodies: not one of fz.waves)
@@ -1172,7 +1177,7 @@ template <bool FUSE, int SUBSH, bool TRACE = false>
 __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane, const float* __restrict__ frec_g,
                                            const float4* posm, float4* __restrict__ acc, int lo, int hi, float eps2,
                                            bh_devinfo* __restrict__ info, int g, int group, const bh_fuse_args& fz,
-                                           int trace_row0, int root = 0) {
+                                           int trace_row0, int root = 0, int held = 0) {
   const int i = lo + g * group + lane;
   const bool valid = lane < group && i < hi;
   const u32 tr0 = TRACE ? (u32)__builtin_amdgcn_s_memrealtime() : 0u;
@@ -1181,6 +1186,7 @@ __device__ __forceinline__ void coop_group(u32* coop_lds, int K, int j, int lane
     const float4 p = valid ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // ref:196
     px = p.x; py = p.y; pz = p.z; pm = p.w;
   }
+  if (__builtin_amdgcn_readfirstlane(held)) return;  // (force_hold_load; the whole workgroup alike)
   const u64 m0 = __builtin_amdgcn_ballot_w64(valid);
   if (m0 == 0) return;  // the whole workgroup: every wave holds the same bodies
   // level buffers: [2][K][kCoopSub bytes]; then the partial accelerations [K][64][3] and K flags
@@ -1239,15 +1245,16 @@ template <bool FUSE, int SUBSH, bool TRACE = false>
 __global__ __launch_bounds__(512) BH_WALK_SGPRS void force_coop_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                          float4* __restrict__ acc, int lo, int hi, float eps2,
                                                          int xcd_mode, bh_devinfo* __restrict__ info, int group,
-                                                         bh_fuse_args fz, int root = 0) {
+                                                         bh_fuse_args fz, int root = 0,
+                                                         const int* __restrict__ hold = nullptr) {
   extern __shared__ __attribute__((aligned(16))) u32 coop_lds[];
-  if (force_held(info)) return;
+  const int held = force_hold_load(hold);
   const int K = (int)(blockDim.x >> 6);
   const int g = block_chunk(xcd_mode);  // one group per workgroup
   // (lo is a multiple of the group size: lo / group + g is the group's index among all groups of the context — what
   // the fused epilogue files its rows under when several launches share one fold, bhk_force_root)
   coop_group<FUSE, SUBSH, TRACE>(coop_lds, K, rfl((int)(threadIdx.x >> 6)), threadIdx.x & 63, frec_g, posm, acc, 0, hi,
-                                 eps2, info, lo / group + g, group, fz, g * K, root);
+                                 eps2, info, lo / group + g, group, fz, g * K, root, held);
 }
 
 // A launch that fills the GPU many times over still ends with one wave lifetime (~0.35 ms at 1M bodies) in which no
@@ -1269,10 +1276,11 @@ template <bool FUSE, int SUBSH, bool BUDGET = false, bool TRACE = false>
 __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const float* __restrict__ frec_g, const float4* posm,
                                                           float4* __restrict__ acc, int hi, float eps2, int xcd_mode,
                                                           bh_devinfo* __restrict__ info, int nbulk, int gb,
-                                                          bh_fuse_args fz, int root = 0, int g0 = 0) {
+                                                          bh_fuse_args fz, int root = 0, int g0 = 0,
+                                                          const int* __restrict__ hold = nullptr) {
   // g0: the launch covers the groups g0 .. of the context (bodies [64 g0, hi)), gb of them by one wave each
   __shared__ __attribute__((aligned(16))) u32 coop_lds[coop_lds_bytes(kMixedK, SUBSH) / 4];
-  if (force_held(info)) return;
+  const int held = force_hold_load(hold);
   const int lane = threadIdx.x & 63;
   const int wib = rfl((int)(threadIdx.x >> 6));
   if ((int)blockIdx.x >= nbulk) {
@@ -1280,7 +1288,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
     // eight in mode 2, so a workgroup's XCD is also that of its index in the tail)
     const int t = block_chunk_of<kTailRun>(xcd_mode == 2 ? 2 : 1, (int)blockIdx.x - nbulk, 0);
     coop_group<FUSE, SUBSH, TRACE>(coop_lds, kMixedK, wib, lane, frec_g, posm, acc, 0, hi, eps2, info, g0 + gb + t, 64,
-                                   fz, gb + t * kMixedK, root);
+                                   fz, gb + t * kMixedK, root, held);
     return;
   }
   const int wl = block_chunk_of<kMixedRun>(xcd_mode, blockIdx.x, nbulk) * 4 + wib;  // the wave's group in the launch
@@ -1289,6 +1297,7 @@ __global__ __launch_bounds__(256) BH_WALK_SGPRS void force_mixed_kernel(const fl
   const int i = w * 64 + lane;  // (groups below gb are full: (g0 + gb) * 64 <= hi)
   const u32 tr0 = TRACE ? (u32)__builtin_amdgcn_s_memrealtime() : 0u;
   const float4 p = posm[i];  // ref:196
+  if (__builtin_amdgcn_readfirstlane(held)) return;
   float px = p.x, py = p.y, pz = p.z;
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
   const u64 m0 = ~0ull;
@@ -1752,6 +1761,8 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
   if (mode == 2) g2 = (g2 + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
   // a wave pops one child block per opened cell: no wave of a well-formed pool can pop more blocks than
   // the pool has records, so this bound never fires on valid data and always ends a walk over a cycle
+  // (the decomposed step's launches are enqueued before the host knows whether the X4 behind them fits: bh_dd.hip)
+  const int* hold = c->dd ? &c->info->dd_hold : nullptr;
   const int budget = kTraversalBudget;
   const bool aligned = lo % 256 == 0;  // the launch's groups are the context's groups
   const long long G = ((long long)(hi - lo) + 63) / 64;  // groups of this launch
@@ -1770,13 +1781,13 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
     if (mmode == 2) nbulk = (nbulk + 8 * kMixedRun - 1) / (8 * kMixedRun) * (8 * kMixedRun);
     if (can_fuse) {
       force_mixed_kernel<true, 11, true><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, stream>>>(
-          (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, fz, root, lo / 64);
+          (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, fz, root, lo / 64, hold);
       *fused = true;
       return hipGetLastError();
     }
     force_mixed_kernel<false, 11, true><<<nbulk + mixed_tail_grid(mmode, tail), 256, 0, stream>>>(
         (const float*)c->frec, c->posm[c->cur], acc, hi, c->p.eps2, mmode, c->info, nbulk, gb, bh_fuse_args{}, root,
-        lo / 64);
+        lo / 64, hold);
     return hipGetLastError();
   }
   // ... and a pass that would not fill the GPU is cooperative throughout (force_coop_kernel from the top-tree root:
@@ -1791,23 +1802,23 @@ hipError_t bhk_force_root(bh_ctx* c, int lo, int hi, int root, hipStream_t strea
     if (cmode == 2) gc = (gc + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);
     if (can_fuse) {
       force_coop_kernel<true, 11><<<gc, K * 64, coop_lds_bytes(K, 11), stream>>>(
-          (const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.eps2, cmode, c->info, 64, fz, root);
+          (const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.eps2, cmode, c->info, 64, fz, root, hold);
       *fused = true;
       return hipGetLastError();
     }
     force_coop_kernel<false, 11><<<gc, K * 64, coop_lds_bytes(K, 11), stream>>>(
-        (const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.eps2, cmode, c->info, 64, bh_fuse_args{}, root);
+        (const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.eps2, cmode, c->info, 64, bh_fuse_args{}, root, hold);
     return hipGetLastError();
   }
   if (c->p.force_variant == 1)
     force_fast_kernel<1, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
-                                                       c->p.eps2, mode, c->info, root, budget, group);
+                                                       c->p.eps2, mode, c->info, root, budget, group, bh_fuse_args{}, hold);
   else if (hi - lo <= kPrefetchMaxBodies)
     force_fast_kernel<0, true, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi,
-                                                             c->p.G, c->p.eps2, mode, c->info, root, budget, group);
+                                                             c->p.G, c->p.eps2, mode, c->info, root, budget, group, bh_fuse_args{}, hold);
   else
     force_fast_kernel<0, true><<<g2, tpb, 0, stream>>>((const float*)c->frec, c->posm[c->cur], acc, lo, hi, c->p.G,
-                                                       c->p.eps2, mode, c->info, root, budget, group);
+                                                       c->p.eps2, mode, c->info, root, budget, group, bh_fuse_args{}, hold);
   return hipGetLastError();
 }
 
