@@ -15,8 +15,9 @@
 //            [--dist]            with --gpus 1: the multi-GPU step at world size 1 (RCCL path on one GPU)
 //            [--devices a,b,..]  explicit device per rank; a device listed twice selects the in-process
 //                                transport (one-GPU rehearsal of G ranks)
-//            [--split | --one-pass]  the first part of a rank's bodies in two force passes (own pieces beside X4,
-//                                then the remote pass) or one pass after X4 (the default)
+//            [--split | --one-pass | --adaptive]  the first part of a rank's bodies in two force passes (own pieces
+//                                beside X4, then the remote pass), one pass after X4 (the default), or whichever the
+//                                measured X4 makes cheaper (bh_rank_opts.split 2)
 //            [--split-pct P]     per cent of a rank's bodies whose walk is split (default 30)
 //            [--replay | --replay-rank Q]  after the run (Q: that rank only): every rank's force phase of the last step run again on its own
 //                                streams with nothing else on the GPU, one pass / 20 / 30 / 100 % split, an idle
@@ -168,6 +169,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--dist")) dist = true;
     else if (!strcmp(argv[i], "--split")) split = 1;
     else if (!strcmp(argv[i], "--one-pass")) split = 0;
+    else if (!strcmp(argv[i], "--adaptive")) split = 2;
     else if (!strcmp(argv[i], "--replay")) replay = true;
     else if (arg("--replay-rank")) { replay = true; replay_rank = atoi(argv[++i]); }
     else if (arg("--split-pct")) split_pct = atoi(argv[++i]);
