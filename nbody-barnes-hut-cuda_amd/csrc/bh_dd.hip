@@ -860,6 +860,14 @@ constexpr int kMarkChunk = 512;
 #endif
 constexpr int kMarkBoxes = BH_MARK_BOXES;  // remote boxes staged in LDS (more are read from memory)
 constexpr int kMarkPer = kMarkChunk / 256;
+// blocks per compute unit: five fit (27 KB of LDS each) and overlap one block's loads with another's candidate tests —
+// a core rank's launch at 8 x 1M bodies 67 -> 58 us against four (tools/dd_mark_trace.py).  Handing the chunks out
+// as blocks come free (an atomic counter) instead of round-robin measured 66 us: a device-scope atomic and two
+// barriers per chunk cost more than the imbalance they remove.
+#ifndef BH_MARK_GRID
+#define BH_MARK_GRID 5
+#endif
+constexpr int kMarkGrid = BH_MARK_GRID;
 // no point of the box [lo, hi] can open the candidate q = (com, threshold): |com - box|^2 + eps2 > thr2, with slack
 __device__ __forceinline__ bool box_too_far(const float4 lo, const float4 hi, const float4 q, float eps2) {
   const float dx = fmaxf(fmaxf(lo.x - q.x, q.x - hi.x), 0.0f);
@@ -2201,7 +2209,7 @@ int bh_dd_let_pack(bh_ctx* c, const void* gathered_x3, void* send_x4, int stride
                                                    d->boxes, d->rbox, d->ddi);
   const int blocks = (c->rec_cap + 1 + 255) / 256;
   const int mark_blocks = (c->rec_cap + kMarkChunk) / kMarkChunk;
-  dd_mark_kernel<<<mark_blocks < 4 * c->num_cus ? mark_blocks : 4 * c->num_cus, 256, 0, c->stream>>>(
+  dd_mark_kernel<<<mark_blocks < kMarkGrid * c->num_cus ? mark_blocks : kMarkGrid * c->num_cus, 256, 0, c->stream>>>(
       c->frec, c->info, c->rec_cap, d->boxes, d->rbox, d->world, d->ddi, c->p.eps2, d->w,
       d->let_mode == 1 ? d->wmask : nullptr, d->dst, d->mark_cnt, d->mark_cnt + mark_blocks + 1, d->mark_done, mark_blocks);
   BH_HIP(c, hipGetLastError());
