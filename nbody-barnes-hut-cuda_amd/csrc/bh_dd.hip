@@ -860,12 +860,12 @@ constexpr int kMarkChunk = 512;
 #endif
 constexpr int kMarkBoxes = BH_MARK_BOXES;  // remote boxes staged in LDS (more are read from memory)
 constexpr int kMarkPer = kMarkChunk / 256;
-// blocks per compute unit: five fit (27 KB of LDS each) and overlap one block's loads with another's candidate tests —
-// a core rank's launch at 8 x 1M bodies 67 -> 58 us against four (tools/dd_mark_trace.py).  Handing the chunks out
-// as blocks come free (an atomic counter) instead of round-robin measured 66 us: a device-scope atomic and two
-// barriers per chunk cost more than the imbalance they remove.
+// blocks per compute unit.  (Five — 27 KB of LDS each, five fit — and a prefetch of a block's next chunk looked like
+// -10 us on a core rank's launch in the instrumented build, tools/dd_mark_trace.py; under rocprofv3 the product
+// build ran 72.5 us against 68.3 with four and no prefetch, tools/mark_ab.sh.  Handing the chunks out through an atomic
+// counter instead of round-robin: +8 us.)
 #ifndef BH_MARK_GRID
-#define BH_MARK_GRID 5
+#define BH_MARK_GRID 4
 #endif
 constexpr int kMarkGrid = BH_MARK_GRID;
 // no point of the box [lo, hi] can open the candidate q = (com, threshold): |com - box|^2 + eps2 > thr2, with slack
