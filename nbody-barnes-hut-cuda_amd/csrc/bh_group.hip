@@ -343,9 +343,11 @@ struct phase_lock {
 };
 
 // Adaptive form (bh_rank_opts.split 2).  Measured on an MI355X, 8 x 1M bodies, every rank's force phase replayed on a GPU
-// of its own (bh_rank_replay_force_phase, profiles/r05_dd/replay_8x1M.txt): one pass costs 1.24 ms + X4; the first 30 %
-// in two passes 1.41 ms + a fifth of X4 — the own pass hides the exchange at the price of two launches with a drain
-// each — so the split pays from an X4 of ~0.18 ms on.  The decision is the rank's own (the protocol does not change).
+// of its own (bh_rank_replay_force_phase, profiles/r05_dd/replay_8x1M.txt; mean of the ranks, X4 = 0 / 0.125 / 0.25 ms):
+// one pass 1.240 / 1.371 / 1.499 ms; the first 20 % in two passes 1.308 / 1.349 / 1.448; 30 %: 1.360 / 1.358 / 1.391 —
+// the own pass hides the exchange at the price of two more launches with a drain each, so the split pays from an X4
+// of ~0.1 ms on and by 0.1 ms at 0.25; switched on at 0.15 ms (off again below 0.09) to stay clear of the break-even.
+// The decision is the rank's own (the protocol does not change).
 constexpr float kSplitOnMs = 0.15f, kSplitOffMs = 0.09f;
 void rank_adapt(bh_rank* r) {
   if (!r->adaptive || !r->x4_timed || !r->ctx) return;
