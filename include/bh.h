@@ -485,7 +485,8 @@ int bh_rank_read_log(bh_rank* r, int32_t* pairs, int capacity_pairs, int* n_pair
    integration — `reps` times after one untimed round; *ms = mean time from the first LET kernel to the end of the last
    force launch.  split = 0: one pass; 1: the two-pass form for split_pct per cent of the bodies.  What a rank-step
    spends between X3 and its end on a GPU of its own, for every form, from a one-GPU rehearsal of P ranks (the other
-   ranks must be idle: call it for one rank at a time; `bh_bench --replay`).  The rank's state is as before. */
+   ranks must be idle: call it for one rank at a time; `bh_bench --replay`).  The rank steps on afterwards as if it had
+   not been called; only the acceleration arrays hold the replay's values until the next step. */
 int bh_rank_replay_force_phase(bh_rank* r, int split, int split_pct, int x4_us, int reps, float* ms);
 void bh_rank_destroy(bh_rank* r);
 /* Test hook: the same protocol around a SCRIPTED engine and host buffers (no GPU): tests/test_dist_cpu.py drives

@@ -2617,7 +2617,7 @@ int bh_dd_replay_begin(bh_ctx* c, int split, int split_pct, int saved[4]) {
   BH_HIP(c, hipStreamSynchronize(c->stream));
   BH_HIP(c, hipStreamSynchronize(d->stream_own));
   saved[0] = c->stage;
-  saved[1] = d->split ? 1 : 0;
+  saved[1] = (d->split ? 1 : 0) | (c->acc2 ? 2 : 0);
   saved[2] = d->split_pct;
   saved[3] = d->serial ? 1 : 0;
   // the tree, the digests and the imported segments of the last step are all still there; the bodies have been
@@ -2635,7 +2635,8 @@ int bh_dd_replay_end(bh_ctx* c, const int saved[4]) {
   BH_HIP(c, hipStreamSynchronize(c->stream));
   BH_HIP(c, hipStreamSynchronize(d->stream_own));
   c->stage = saved[0];
-  d->split = saved[1] != 0;
+  d->split = (saved[1] & 1) != 0;
+  c->acc2 = (saved[1] & 2) ? d->acc2 : nullptr;
   d->split_pct = saved[2];
   d->serial = saved[3] != 0;
   d->replay = false;
