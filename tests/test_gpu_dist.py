@@ -75,6 +75,10 @@ def test_bench_two_ranks_rehearsal(mode):
     if mode == "domain":
         assert len(out["config"]["domain"]["let_records_per_rank"]) == 2
         assert out["strong"]["n_total"] == 150000 and len(out["strong"]["let_records_per_rank"]) == 2
+        # the line says which force form ran and — adaptive form, ranks large enough for it — what X4 was measured at
+        dom = out["config"]["domain"]
+        assert dom["force_passes"].startswith("adaptive") and dom["split_now_rank0"] in (0, 1)
+        assert "x4_ms_measured_rank0" in dom   # (null here: 150,000 bodies per rank never split)
 
 
 def test_bench_two_ranks_domain_fallback_is_collective():
