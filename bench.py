@@ -643,7 +643,10 @@ def main():
                 "split_now_rank0": int(stepper.split_now),
                 # adaptive form: the exchange as this rank's stream saw it (events around X4, running mean), or null
                 "x4_ms_measured_rank0": (stepper.x4_us / 1000.0) if stepper.x4_us >= 0 else None,
-                "x4_bytes_received_per_gpu_per_step": int(world * stepper.stride * 32),
+                # per pair, what the pair needed in the last step + a quarter + 4096 records (bh_comm.all_to_all_v);
+                # one size for all pairs (the slot) would be x4_bytes_slots
+                "x4_bytes_received_per_gpu_per_step": int(stepper.x4_recv_bytes),
+                "x4_bytes_slots": int(world * stepper.stride * 32),
                 "let_retries": int(stepper.let_retries), "extra_migration_rounds": int(stepper.mig_rounds),
                 "phase_ms_rank0": stepper.phase_ms()}
         assert st.status_flags == 0, st.status_flags

@@ -27,9 +27,9 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 5 /* 2: bh_params grew key_curve (72 bytes); 3: bh_dd_phase_*, timing mode 3; 4: force_coop,
+#define BH_ABI_VERSION 6 /* 2: bh_params grew key_curve (72 bytes); 3: bh_dd_phase_*, timing mode 3; 4: force_coop,
                              bh_dd_get_info, larger X1 payload (boundary proposals), bh_walk_stats fields; 5: bh_comm,
-                             bh_rank_*, bh_group (the multi-GPU step behind the ABI), BH_ERR_COMM / _DOMAIN_LEFT */
+                             bh_rank_*, bh_group (the multi-GPU step behind the ABI), BH_ERR_COMM / _DOMAIN_LEFT; 6: bh_comm.all_to_all_v */
 
 typedef struct bh_ctx bh_ctx; /* opaque; replaces the globals ref:31-40 */
 
@@ -371,6 +371,9 @@ int bh_dd_walk_stats(bh_ctx* c, int which, bh_walk_stats* out);
    once on two streams, ms[3] 0.  Partial step (split_pct < 100): ms[0] / ms[1] own / remote pass of the split part,
    ms[2] the one pass of the other bodies, ms[3] that one pass and the remote pass at once, as the step runs them */
 int bh_dd_pass_times(bh_ctx* c, float ms[4]);
+/* Measurement only: the needs matrix of the last X4 — out[q * world + j] = records rank q's segment for receiver j
+   needed (header + pieces + exported blocks; 0 on the diagonal) — as every rank sees it in the received headers */
+int bh_dd_needs_matrix(bh_ctx* c, int32_t* out);
 /* what the last step's migration did, for logs and tests (synchronises): out[0] bodies this rank holds, [1] emigrants
    it found in its last classification, [2] steps since bh_dd_init in which the domain boundaries moved, [3] what the
    last step did with them: 0 kept (a rank owns a fixed interval of the curve: the splitter keys persist from step
@@ -398,6 +401,12 @@ typedef struct bh_comm { /* how a rank's buffers travel.  Functions return 0 or 
   /* recv chunk q <- rank q's send chunk `rank`, chunks of bytes_per_peer */
   int (*all_to_all)(void* user, void* recv, const void* send, int64_t bytes_per_peer, void* hip_stream);
   void (*release)(void* user); /* called once by bh_rank_destroy (or by the caller if no rank took the comm); may be NULL */
+  /* ABI 6, may be NULL (the library then uses all_to_all): the all-to-all with a size per pair.  Send slot q and receive
+     slot q lie slot_bytes apart as in all_to_all; the first recv_bytes[q] bytes of receive slot q <- the first
+     send_bytes[rank] bytes of rank q's send slot `rank` (equal by construction: every rank derives all sizes from the
+     same all-gathered numbers).  X4's segments are two thirds padding under one size for all pairs. */
+  int (*all_to_all_v)(void* user, void* recv, const void* send, int64_t slot_bytes, const int64_t* send_bytes,
+                      const int64_t* recv_bytes, void* hip_stream);
 } bh_comm;
 
 /* RCCL transport (librccl.so.1 is opened at the first call, not linked: a process that already holds RCCL — torch —
@@ -456,7 +465,8 @@ typedef struct bh_rank_info {
   int32_t let_counts[64]; /* records every rank needed in the last X4                                */
   int32_t split_now;    /* 1: the next step walks part of the bodies in two passes (split 1, or adaptive and on) */
   int32_t x4_us;        /* adaptive form: running mean of the measured X4 duration, microseconds (-1: none yet) */
-  int32_t reserved[6];
+  int32_t x4_recv_kb;   /* KiB this rank received in the last step's (last) X4                                  */
+  int32_t reserved[5];
 } bh_rank_info;
 
 int bh_rank_default_opts(bh_rank_opts* o);

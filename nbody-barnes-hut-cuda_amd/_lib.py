@@ -67,12 +67,15 @@ BH_ERR_COMM, BH_ERR_DOMAIN_LEFT = -9, -10
 # ---- the multi-GPU step behind the ABI (bh_comm / bh_rank / bh_group)
 COMM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 COMM_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)
+COMM_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
+                        C.POINTER(C.c_int64), C.c_void_p)   # all_to_all_v (ABI 6; may be NULL)
 
 
 class BhComm(C.Structure):
     """struct bh_comm: how a rank's buffers travel (all_gather / all_to_all on a HIP stream)."""
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("user", C.c_void_p),
-                ("all_gather", COMM_FN), ("all_to_all", COMM_FN), ("release", COMM_RELEASE_FN)]
+                ("all_gather", COMM_FN), ("all_to_all", COMM_FN), ("release", COMM_RELEASE_FN),
+                ("all_to_all_v", COMM_V_FN)]
 
 
 class BhRankOpts(C.Structure):
@@ -94,7 +97,7 @@ class BhRankInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n_loc", "stride", "mig_stride", "mig_last", "mig_rounds", "let_retries",
                                          "left_rank", "left_status")] + \
                [("steps", C.c_int64), ("let_counts", C.c_int32 * 64), ("split_now", C.c_int32), ("x4_us", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("x4_recv_kb", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 _PI = C.POINTER(C.c_int)
@@ -182,6 +185,7 @@ SYMBOLS = [
     ("bh_dd_get_info", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("bh_dd_walk_stats", C.c_int, [_P, C.c_int, C.POINTER(BhWalkStats)]),
     ("bh_dd_pass_times", C.c_int, [_P, _F]),
+    ("bh_dd_needs_matrix", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("bh_comm_rccl_from", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int]),
     ("bh_comm_rccl_unique_id", C.c_int, [_P]),
     ("bh_comm_rccl_init_rank", C.c_int, [C.POINTER(BhComm), _P, C.c_int, C.c_int, C.c_int]),

@@ -117,6 +117,14 @@ struct bh_dd_state {
   bool replay;        // bh_dd_replay_begin .. _end (measurement): the force passes do not integrate
   bool top_early;     // one-pass step: the top tree's structure was built beside the LET kernels (dd_top_early)
   bool keys_spec;     // the key kernel of this step's sort was launched while the host waited for the body count
+  // X4 with a size per pair (bh_comm.all_to_all_v): what rank q sends rank j this step is limited to
+  // x4_chunk(what q needed for j in the LAST fitting X4) — every rank holds that matrix (the needs rows in the segment
+  // headers) on the host (prev_rows) and on the device (prev_rows_dev, kept by dd_validate_kernel) and derives the
+  // same sizes; a pair that outgrows its size makes the exchange "not fit": repeated with one size for all
+  int* prev_rows;      // [world][32] host copy of the header rows of the last fitting X4
+  int* prev_rows_dev;  // the same on the device
+  bool prev_ok;        // prev_rows holds a matrix
+  bool x4_v;           // this try's X4 moves a size per pair
   bool let_copy_pending;
   int* host_rows;  // pinned: [world][32] header + needs row (records 0..3) of every received X4 segment
   int let_mode;    // 0: X4 is an all-gather of the union every other rank may open; 1: per-destination segments
@@ -154,6 +162,15 @@ __host__ __device__ inline int seg_row_dword(int j) {
   const int r = 1 + j / 8, f = j % 8;
   return (r >> 1) * 16 + 2 * f + (r & 1);
 }
+// records pair (q -> j) may move when sizes follow the last step's needs: a quarter more than it needed then + 4096
+// (measured at 8 x 1M, tools/dd_needs.py: a pair's need grows 1-2 % per step and by up to 20,000 records — 22 % of
+// a near pair's 90,000, several times a far pair's 1,000-10,000 — in a step that moves the domain boundaries), whole
+// 256-record units, never more than the stride (the slot)
+__host__ __device__ inline int x4_chunk(int need_prev, int stride) {
+  const long long c = (((long long)need_prev * 5 / 4 + 4096 + 255) / 256) * 256;
+  return (int)(c < stride ? c : stride);
+}
+constexpr int kNeedsRowMax = 24;  // ranks a segment's needs row has room for (records 1..3)
 constexpr int kTopCap = 4 * 4096 + 8;  // records of one top tree incl. padding (kTopMax pieces)
 
 constexpr int kSampTotal = 2048;  // position samples in the whole system (bitonic sort in LDS by one block, on the
@@ -1407,7 +1424,8 @@ __global__ __launch_bounds__(256) void dd_export_pd_kernel(const bh_frec* __rest
 __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ pool, int seg_base, int stride,
                                                           int world, int me, bh_devinfo* __restrict__ info,
                                                           int* __restrict__ host_rows, int* __restrict__ host_seq,
-                                                          int seq) {
+                                                          int seq, int* __restrict__ prev_rows, int use_prev) {
+  // use_prev: this X4 moved a size per pair (x4_chunk of the needs in prev_rows) instead of the whole slot
   if (blockIdx.x == 0) {
     __shared__ int s_rows[64 * 32];
     __shared__ int s_hold;
@@ -1426,12 +1444,22 @@ __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ 
     for (int q = threadIdx.x; q < world; q += 256) {
       const int* seg = s_rows + 32 * q;
       int need = seg[10];  // header record 0, field `first`; negative: that rank left the step
+      bool over = false;
       if (need >= 0)
-        for (int j = 0; j < world; j++) need = max(need, seg[seg_row_dword(j)]);
-      if (need < 0 || need > stride) atomicOr(&s_hold, 1);
+        for (int j = 0; j < world; j++) {
+          const int nj = seg[seg_row_dword(j)];
+          need = max(need, nj);
+          if (use_prev && j != q) over = over || nj > x4_chunk(prev_rows[32 * q + seg_row_dword(j)], stride);
+        }
+      if (need < 0 || need > stride || over) atomicOr(&s_hold, 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) info->dd_hold = s_hold;
+    // a fitting exchange becomes the next step's yardstick (the host keeps the same copy: bh_dd_phase_force)
+    if (!s_hold && prev_rows) {
+      __syncthreads();  // (everybody has read the old rows)
+      for (int i = threadIdx.x; i < world * 32; i += 256) prev_rows[i] = s_rows[i];
+    }
   }
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)world * stride) return;
@@ -1441,7 +1469,9 @@ __global__ __launch_bounds__(256) void dd_validate_kernel(bh_frec* __restrict__ 
   // the header's count = records the sender needed: beyond it (or in a segment sent closed because it did
   // not fit) nothing was written this step and nothing is reachable
   const int used = frec_get(pool, seg0).first;
-  if (used > stride ? k >= kSegBlocks0 : k >= used) return;
+  // (a size per pair: what lies beyond this pair's size did not travel — the exchange is then being repeated anyway)
+  const int got = use_prev ? min(used, x4_chunk(prev_rows[32 * q + seg_row_dword(me)], stride)) : used;
+  if (used > stride ? k >= kSegBlocks0 : k >= got) return;
   const long long e = (long long)seg_base + t;
   const bh_frec r = frec_get(pool, e);
   if (r.thr2 < 0.0f) return;  // closed (always accepted).  A NaN threshold fails this test and falls through to the
@@ -1877,6 +1907,8 @@ void bh_dd_free(bh_ctx* c) {
     if (p) (void)hipFree(p);
   if (d->host) (void)hipHostFree(d->host);
   if (d->host_rows) (void)hipHostFree(d->host_rows);
+  if (d->prev_rows_dev) (void)hipFree(d->prev_rows_dev);
+  free(d->prev_rows);
   if (d->ev_let) (void)hipEventDestroy(d->ev_let);
   if (d->ev_x3) (void)hipEventDestroy(d->ev_x3);
   if (d->ev_own) (void)hipEventDestroy(d->ev_own);
@@ -1977,6 +2009,10 @@ int bh_dd_init(bh_ctx* c, int world, int rank, int64_t n_total, int mig_cap, int
   ok = ok && hipHostMalloc((void**)&d->host, (64 + 8) * sizeof(int)) == hipSuccess;
   if (ok) memset(d->host, 0, (64 + 8) * sizeof(int));  // [64..67] migration results, [68] their sequence number, [70] X4 headers'
   ok = ok && hipHostMalloc((void**)&d->host_rows, 64 * 32 * sizeof(int)) == hipSuccess;
+  d->prev_rows = (int*)calloc(64 * 32, sizeof(int));
+  ok = ok && d->prev_rows != nullptr;
+  ok = ok && hipMalloc((void**)&d->prev_rows_dev, 64 * 32 * sizeof(int)) == hipSuccess;
+  ok = ok && hipMemset(d->prev_rows_dev, 0, 64 * 32 * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->wmask, ((size_t)c->rec_cap + 1 + 64) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->list_e, ((size_t)n_cap + 64) * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&d->list_w, ((size_t)n_cap + 64) * 4) == hipSuccess;
@@ -2049,6 +2085,8 @@ int bh_dd_upload(bh_ctx* c, int n_loc, const float* x, const float* y, const flo
   BH_HIP(c, hipMemsetAsync(c->dd->ddi + 9, 0, 4 * sizeof(int), c->stream));
   BH_HIP(c, hipMemsetAsync(c->dd->nloc, 0, 64 * sizeof(int), c->stream));
   BH_HIP(c, hipMemsetAsync(c->dd->drift, 0, 192 * sizeof(int), c->stream));
+  c->dd->prev_ok = false;  // (sizes per pair start over: the first X4 moves whole slots)
+  c->dd->x4_v = false;
   BH_HIP(c, hipStreamSynchronize(c->stream));
   c->stage = BH_ST_UPLOADED;
   c->ever = BH_ST_UPLOADED;
@@ -2350,7 +2388,8 @@ int bh_dd_top(bh_ctx* c, const void* gathered_x3, int stride) {
     d->let_seq++;
     dd_validate_kernel<<<(unsigned)((recs + 255) / 256), 256, 0, c->stream>>>(d->pool, d->seg_base, stride, d->world,
                                                                             d->rank, c->info, d->host_rows,
-                                                                            d->host + 70, d->let_seq);
+                                                                            d->host + 70, d->let_seq, d->prev_rows_dev,
+                                                                            d->x4_v ? 1 : 0);
     BH_HIP(c, hipGetLastError());
   }
   d->let_copy_pending = true;
@@ -2450,15 +2489,41 @@ int bh_dd_let_check(bh_ctx* c, int stride, int32_t* counts) {
   // counts[q] = the most records rank q needed for any receiver (its needs row: every rank holds the same matrix,
   // so every rank takes the same decision); a negative header marks a rank that left the step
   int worst = 0;
+  bool over = false;  // (a size per pair: some pair outgrew its size — dd_validate_kernel takes the same decision)
   for (int q = 0; q < d->world; q++) {
     const int* seg = d->host_rows + 32 * q;
     int need = seg[10];  // header record 0, field `first`
     if (need >= 0)
-      for (int j = 0; j < d->world; j++) need = seg[seg_row_dword(j)] > need ? seg[seg_row_dword(j)] : need;
+      for (int j = 0; j < d->world; j++) {
+        const int nj = seg[seg_row_dword(j)];
+        need = nj > need ? nj : need;
+        if (d->x4_v && j != q) over = over || nj > x4_chunk(d->prev_rows[32 * q + seg_row_dword(j)], stride);
+      }
     if (counts) counts[q] = need;
     if (need > worst) worst = need;
   }
-  return worst > stride ? BH_ERR_SMALL_BUFFER : BH_OK;
+  return (worst > stride || over) ? BH_ERR_SMALL_BUFFER : BH_OK;
+}
+
+// The sizes of this try's X4 (bh_group.hip, before the exchange).  allow_prev: a size per pair from the last fitting
+// exchange's needs if there is one (first try of a step); else — a repeated exchange, the first step, more ranks than a
+// needs row holds — the whole slot for every pair.  send_bytes[q] / recv_bytes[q]: what this rank sends to / receives
+// from rank q.  The validation and the fit decision of this try follow what is chosen here.
+int bh_dd_x4_sizes(bh_ctx* c, int stride, int allow_prev, int64_t* send_bytes, int64_t* recv_bytes) {
+  if (!c || !c->dd || !send_bytes || !recv_bytes) return BH_ERR_BAD_ARG;
+  bh_dd_state* d = c->dd;
+  if (stride < kSegBlocks0 || stride > d->let_cap || (stride & 1)) return BH_ERR_BAD_ARG;
+  d->x4_v = allow_prev && d->prev_ok && d->world <= kNeedsRowMax && d->let_mode == 1;
+  for (int q = 0; q < d->world; q++) {
+    int s = stride, r = stride;
+    if (d->x4_v) {
+      s = x4_chunk(d->prev_rows[32 * d->rank + seg_row_dword(q)], stride);
+      r = x4_chunk(d->prev_rows[32 * q + seg_row_dword(d->rank)], stride);
+    }
+    send_bytes[q] = (int64_t)s * 32;
+    recv_bytes[q] = (int64_t)r * 32;
+  }
+  return BH_OK;
 }
 
 // ---- one entry point per phase group: the per-step protocol of dist.DomainStepper in five calls (each is the
@@ -2521,6 +2586,9 @@ int bh_dd_phase_force(bh_ctx* c, const void* gathered_x3, int stride, int32_t* c
   if (s != BH_OK || left) {  // the launches held themselves back: nothing was walked, nothing integrated
     c->dd_integrated = false;
     c->stage = stage0;
+  } else if (!c->dd->replay) {  // a fitting exchange: its needs size the next step's (dd_validate_kernel kept the device's copy)
+    memcpy(c->dd->prev_rows, c->dd->host_rows, (size_t)c->dd->world * 32 * sizeof(int));
+    c->dd->prev_ok = true;
   }
   if (fits) *fits = (s == BH_OK && !left) ? 1 : 0;
   if (s == BH_ERR_SMALL_BUFFER && !left) return BH_OK;  // the caller repeats X4 with a larger stride
@@ -2627,6 +2695,7 @@ int bh_dd_replay_begin(bh_ctx* c, int split, int split_pct, int saved[4]) {
   if (split) d->split_pct = split_pct;
   d->serial = false;  // the rank's own two streams, as on a GPU of its own
   d->replay = true;
+  d->x4_v = false;  // (nothing travels: what the real step received is in the pool, validated as whole slots)
   return BH_OK;
 }
 int bh_dd_replay_end(bh_ctx* c, const int saved[4]) {
@@ -2647,6 +2716,17 @@ int bh_dd_replay_end(bh_ctx* c, const int saved[4]) {
 int bh_dd_set_one_pass(bh_ctx* c) {
   if (!c || !c->dd) return BH_ERR_BAD_ARG;
   c->dd->split = false;
+  return BH_OK;
+}
+// measurement: the needs matrix of the last X4 as this rank saw it in the segment headers — out[q * world + j] =
+// records rank q needed in its segment for receiver j (0 on the diagonal) — the same on every rank
+int bh_dd_needs_matrix(bh_ctx* c, int32_t* out) {
+  if (!c || !c->dd || !out) return BH_ERR_BAD_ARG;
+  const bh_dd_state* d = c->dd;
+  if (!(c->ever & BH_ST_FORCE)) return BH_ERR_ORDER;
+  BH_HIP(c, hipStreamSynchronize(c->stream));
+  for (int q = 0; q < d->world; q++)
+    for (int j = 0; j < d->world; j++) out[q * d->world + j] = j < 24 ? d->host_rows[32 * q + seg_row_dword(j)] : 0;
   return BH_OK;
 }
 int bh_dd_idle_wave(bh_ctx* c, int us) {

@@ -116,6 +116,21 @@ int rccl_all_to_all(void* user, void* recv, const void* send, int64_t bytes, voi
   return s ? s : e;
 }
 
+int rccl_all_to_all_v(void* user, void* recv, const void* send, int64_t slot, const int64_t* sb, const int64_t* rb,
+                      void* stream) {
+  rccl_user* u = (rccl_user*)user;
+  rccl_api* a = rccl();
+  int s = a->GroupStart();
+  for (int q = 0; q < u->world && !s; q++) {
+    if (sb[q] > 0)
+      s = a->Send((const char*)send + (size_t)q * slot, (size_t)sb[q], kNcclInt8, q, u->comm, (hipStream_t)stream);
+    if (!s && rb[q] > 0)
+      s = a->Recv((char*)recv + (size_t)q * slot, (size_t)rb[q], kNcclInt8, q, u->comm, (hipStream_t)stream);
+  }
+  const int e = a->GroupEnd();
+  return s ? s : e;
+}
+
 void rccl_release(void* user) {
   rccl_user* u = (rccl_user*)user;
   if (u->own && u->comm && rccl()) (void)rccl()->CommDestroy(u->comm);
@@ -135,6 +150,7 @@ int rccl_fill(bh_comm* out, nccl_comm_t comm, bool own, int world, int rank) {
   out->all_gather = rccl_all_gather;
   out->all_to_all = rccl_all_to_all;
   out->release = rccl_release;
+  out->all_to_all_v = rccl_all_to_all_v;
   return BH_OK;
 }
 
@@ -177,7 +193,8 @@ struct hub_user {
 };
 
 // mode 0: all-gather (every rank reads all of rank q's send); 1: all-to-all (chunk `rank` of it)
-int hub_exchange(void* user, void* recv, const void* send, int64_t bytes, void* stream_, int mode) {
+int hub_exchange(void* user, void* recv, const void* send, int64_t bytes, void* stream_, int mode,
+                 const int64_t* recv_bytes = nullptr) {  // recv_bytes: mode 1 with a size per pair (slots `bytes` apart)
   hub_user* u = (hub_user*)user;
   bh_hub* h = u->hub;
   const int r = u->rank, P = h->world;
@@ -195,7 +212,8 @@ int hub_exchange(void* user, void* recv, const void* send, int64_t bytes, void* 
   for (int q = 0; q < P; q++) {
     if (h->stream[q] != st && hipStreamWaitEvent(st, h->ev_post[q], 0) != hipSuccess) return 1;
     const char* s = (const char*)h->src[q] + (mode ? (size_t)r * bytes : 0);
-    if (hipMemcpyAsync((char*)recv + (size_t)q * bytes, s, (size_t)bytes, hipMemcpyDefault, st) != hipSuccess) return 1;
+    const size_t nbytes = recv_bytes ? (size_t)recv_bytes[q] : (size_t)bytes;
+    if (nbytes && hipMemcpyAsync((char*)recv + (size_t)q * bytes, s, nbytes, hipMemcpyDefault, st) != hipSuccess) return 1;
   }
   if (hipEventRecord(h->ev_done[r], st) != hipSuccess) return 1;  // I have read everybody's payload
   if (!h->barrier()) return 1;
@@ -208,6 +226,10 @@ int hub_all_gather(void* u, void* recv, const void* send, int64_t bytes, void* s
 }
 int hub_all_to_all(void* u, void* recv, const void* send, int64_t bytes, void* st) {
   return hub_exchange(u, recv, send, bytes, st, 1);
+}
+int hub_all_to_all_v(void* u, void* recv, const void* send, int64_t slot, const int64_t* sb, const int64_t* rb, void* st) {
+  (void)sb;  // (every reader copies what it receives)
+  return hub_exchange(u, recv, send, slot, st, 1, rb);
 }
 void hub_release(void* user) { free(user); }
 
@@ -239,6 +261,7 @@ struct bh_rank {
   bool own_buf;
   int stride, mig_stride, mig_rounds, mig_last, let_retries, n_loc;
   int stride_last;  // the stride the last completed step's X4 used (the segments in the pool are laid out with it)
+  long long x4_recv_bytes;  // what this rank received in the last X4
   // which form the force takes this step: fixed by bh_rank_opts.split 0 / 1, or — split 2, adaptive — decided from the
   // measured duration of X4 (events around the exchange on the rank's stream, read one step later): one pass while the
   // exchange is short, the first part of the bodies in two passes once it lasts long enough to pay (kSplitOnMs)
@@ -469,9 +492,26 @@ int rank_one_step(bh_rank* r) {
     tries++;
     const bool timed = r->adaptive && r->device_mem && tries == 1;
     if (timed && hipEventRecord(r->ev_xa, r->stream) != hipSuccess) return BH_ERR_HIP;
-    const int xs = r->o.let_mode == 1 ? c.all_to_all(c.user, seg, r->buf[X4S], (int64_t)stride * 32, st)
-                                      : c.all_gather(c.user, seg, r->buf[X4S], (int64_t)stride * 32, st);
-    if (xs) return BH_ERR_COMM;  // X4: LET records, in place
+    // X4: LET records, in place.  First try of a step over a transport that can: a size per pair, from what every
+    // pair needed in the last fitting exchange (bh_dd_x4_sizes: two thirds of the slots are padding, tools/dd_needs.py);
+    // a pair that outgrew its size shows as "does not fit" and the repeat moves whole slots.
+    int xs;
+    int64_t sb[kMaxWorld], rb[kMaxWorld];
+    bool sized = false;
+    if (r->ctx && r->device_mem && r->o.let_mode == 1) {
+      if (bh_dd_x4_sizes(r->ctx, stride, (tries == 1 && c.all_to_all_v) ? 1 : 0, sb, rb)) return BH_ERR_BAD_ARG;
+      sized = true;
+    }
+    if (sized && c.all_to_all_v && tries == 1) {
+      xs = c.all_to_all_v(c.user, seg, r->buf[X4S], (int64_t)stride * 32, sb, rb, st);
+      r->x4_recv_bytes = 0;
+      for (int q = 0; q < P; q++) r->x4_recv_bytes += rb[q];
+    } else {
+      xs = r->o.let_mode == 1 ? c.all_to_all(c.user, seg, r->buf[X4S], (int64_t)stride * 32, st)
+                              : c.all_gather(c.user, seg, r->buf[X4S], (int64_t)stride * 32, st);
+      r->x4_recv_bytes = (long long)P * stride * 32;
+    }
+    if (xs) return BH_ERR_COMM;
 #ifdef BH_STUDY
     {  // an exchange that lasts longer, for measurements at world size 1 (tools/r5_fake_x4.sh)
       static const int fake_us = getenv("BH_DD_FAKE_X4_US") ? atoi(getenv("BH_DD_FAKE_X4_US")) : 0;
@@ -617,6 +657,24 @@ int bh_comm_check(const bh_comm* comm) {
           break;
         }
       }
+    // the exchange with a size per pair, if the transport has one: rank q gets the first (q + me) % W + 1 words of my
+    // chunk q, the rest of the slot stays as it was (zero)
+    if (ok && comm->all_to_all_v) {
+      int64_t sb[kMaxWorld], rbv[kMaxWorld];
+      for (int q = 0; q < P; q++) sb[q] = rbv[q] = 4 * (int64_t)((q + r) % W + 1);
+      if (hipMemsetAsync(d + 2 * words, 0, words * 4, st) != hipSuccess) break;
+      if (comm->all_to_all_v(comm->user, d + 2 * words, d, (int64_t)W * 4, sb, rbv, st)) break;
+      if (hipMemcpyAsync(back.data(), d + 2 * words, words * 4, hipMemcpyDeviceToHost, st) != hipSuccess) break;
+      if (hipStreamSynchronize(st) != hipSuccess) break;
+      for (int q = 0; q < P && ok; q++)
+        for (int w = 0; w < W; w++) {
+          const uint32_t aa = w < (q + r) % W + 1 ? (0x5a000000u | (uint32_t)q << 16 | (uint32_t)r << 8 | (uint32_t)w) : 0u;
+          if (back[(size_t)q * W + w] != aa) {
+            ok = false;
+            break;
+          }
+        }
+    }
     ret = ok ? BH_OK : BH_ERR_COMM;
   } while (false);
   if (st) (void)hipStreamDestroy(st);
@@ -650,6 +708,7 @@ int bh_comm_hub(bh_comm* out, bh_hub* hub, int rank) {
   out->all_gather = hub_all_gather;
   out->all_to_all = hub_all_to_all;
   out->release = hub_release;
+  out->all_to_all_v = hub_all_to_all_v;
   return BH_OK;
 }
 
@@ -866,6 +925,7 @@ int bh_rank_get_info(bh_rank* r, bh_rank_info* o) {
   o->steps = r->steps;
   o->split_now = r->split_now;
   o->x4_us = r->x4_samples > 0 ? (int32_t)(r->x4_ema_ms * 1000.0f + 0.5f) : -1;
+  o->x4_recv_kb = (int32_t)(r->x4_recv_bytes >> 10);
   memcpy(o->let_counts, r->let_counts, sizeof(o->let_counts));
   return BH_OK;
 }

@@ -316,6 +316,7 @@ extern "C" int bh_dd_replay_begin(bh_ctx* c, int split, int split_pct, int saved
 extern "C" int bh_dd_replay_end(bh_ctx* c, const int saved[4]);
 extern "C" int bh_dd_idle_wave(bh_ctx* c, int us);
 extern "C" int bh_dd_set_one_pass(bh_ctx* c);
+extern "C" int bh_dd_x4_sizes(bh_ctx* c, int stride, int allow_prev, int64_t* send_bytes, int64_t* recv_bytes);
 
 // device-wide scans (bh_scan.hip)
 hipError_t bhk_scan_i32(bh_ctx* c, const int* in, int* out /* n+1 */, int n, const int* n_dev);

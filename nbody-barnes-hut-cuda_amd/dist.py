@@ -463,6 +463,7 @@ class DomainStepper:
         self.n_loc, self.stride, self.mig_stride, self.mig_last = i.n_loc, i.stride, i.mig_stride, i.mig_last
         self.mig_rounds, self.let_retries = i.mig_rounds, i.let_retries
         self.split_now, self.x4_us = int(i.split_now), int(i.x4_us)   # (adaptive form: what it runs now, measured X4)
+        self.x4_recv_bytes = int(i.x4_recv_kb) * 1024   # what this rank received in the last X4
         self.let_counts = np.array(i.let_counts[:self.world], np.int32) if i.steps or i.let_retries else None
         self._info = i
         if getattr(self, "e", None) is not None and hasattr(self.e, "_h") and i.n_loc:

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(pkg):
 def test_struct_layouts(pkg):
     assert C.sizeof(pkg.BhNode) == 32
     assert C.sizeof(pkg.BhParams) == 5 * 4 + 4 * 4 + 9 * 4
-    assert pkg.lib.bh_abi_version() == 5
+    assert pkg.lib.bh_abi_version() == 6
 
 
 def test_struct_layouts_match_the_c_compiler(pkg, tmp_path):

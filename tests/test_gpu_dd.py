@@ -794,3 +794,81 @@ def test_let_that_outgrows_its_stride_is_exchanged_again_and_the_held_back_launc
     assert np.median(e) < 5e-6, np.median(e)
     assert np.quantile(e, 0.9999) < 2e-4, np.quantile(e, 0.9999)
     assert np.abs(p - p1).max() < 2e-3
+
+
+def test_x4_with_a_size_per_pair_moves_a_fraction_of_the_slots_and_changes_nothing():
+    """bh_comm.all_to_all_v (ABI 6): after the first step every pair's transfer follows what the pair needed in the last
+    fitting exchange (x4_chunk: a quarter more + 4096 records) instead of the whole slot.  4 ranks x 50,000 bodies, 6
+    steps, through the in-process hub (sized exchange) and through a caller-callback transport that has no sized
+    exchange (whole slots): the same bits for every body, and the hub ranks receive clearly fewer bytes than the slots hold
+    (two thirds of them at this size — the 4096-record margin weighs on small segments; a third at 8 x 1M, tools/dd_needs.py)."""
+    import torch
+    pkg = bhpkg.load()
+    from nbody_barnes_hut_cuda_amd import dist as bhdist
+    n, world, steps = 200000, 4, 6
+    ic = pkg.plummer(n, seed=9)
+    order = bhdist.global_morton_order(pkg, ic, 0)
+
+    class SlotComm(bhdist.TensorComm):   # device copies in Python; all_to_all_v stays NULL
+        def __init__(self, group, rank):
+            super().__init__(group.world, rank)
+            self.g = group
+
+        def all_gather(self, out, send):
+            g = self.g
+            g.slots[self.rank] = send
+            g.barrier.wait()
+            k = send.numel()
+            for q in range(self.world):
+                out.view(-1)[q * k:(q + 1) * k].copy_(g.slots[q].view(-1))
+            torch.cuda.synchronize()
+            g.barrier.wait()
+
+        def all_to_all(self, out, send):
+            g = self.g
+            g.slots[self.rank] = send
+            g.barrier.wait()
+            k = send.numel() // self.world
+            for q in range(self.world):
+                out.view(-1)[q * k:(q + 1) * k].copy_(g.slots[q].view(-1)[self.rank * k:(self.rank + 1) * k])
+            torch.cuda.synchronize()
+            g.barrier.wait()
+
+    def run(kind):
+        group = bhdist.LocalGroup(world)
+        group.slots = [None] * world
+        stream = torch.cuda.Stream(0)
+        out, errs = [None] * world, []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(0)
+                comm = bhdist.LocalComm(group, r) if kind == "hub" else SlotComm(group, r)
+                st = bhdist.DomainStepper(pkg, ic, comm, 0, stream=stream, order=order)
+                group.barrier.wait()
+                st.step(steps)
+                st._sync_info()
+                out[r] = st.local_state() + (st.x4_recv_bytes, st.stride, st.let_retries)
+                group.barrier.wait()
+                st.close()
+            except BaseException as ex:  # noqa: BLE001
+                errs.append(ex)
+                group.abort()
+                group.barrier.abort()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if errs:
+            raise errs[0]
+        return out
+
+    a, b = run("hub"), run("slots")
+    pa, va, aa = merge([o[:4] for o in a], n)
+    pb, vb, ab = merge([o[:4] for o in b], n)
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb) and np.array_equal(aa, ab)
+    for r in range(world):
+        sized, slots = a[r][4], b[r][4]
+        assert slots == world * b[r][5] * 32 or b[r][6] > 0      # whole slots (the stride the step used, unless repeated)
+        assert sized < 0.8 * slots, (r, sized, slots)
+    print("X4 bytes received per rank, sized / slots:", [(o[4], p[4]) for o, p in zip(a, b)])

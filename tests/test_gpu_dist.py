@@ -45,7 +45,7 @@ def test_bench_distributed_path_world1(mode, word):
     assert "200,000 bodies per GPU" in out["metric"] and "theta=0.5" in out["metric"]
     assert out["n1_ms_per_step"] > 0 and out["n1"]["bodies"] == 200000
     assert abs(out["aggregate_x"] - out["n1_ms_per_step"] / out["ms_per_step"]) < 1e-6 * out["aggregate_x"]
-    assert len(out["build"]["csrc_sha16"]) == 16 and out["build"]["abi"] == 5
+    assert len(out["build"]["csrc_sha16"]) == 16 and out["build"]["abi"] == 6
     if mode == "domain":
         assert "library RCCL transport" in out["config"]["parallelism"]      # ncclCommInitRank at world size 1
         assert out["strong"]["n_total"] == 200000 and out["strong"]["value"] > 0 and out["strong"]["scaling"] == "strong"
