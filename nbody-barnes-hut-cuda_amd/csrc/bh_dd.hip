@@ -27,7 +27,8 @@
 //                        (all-to-all; let_mode 0: one union segment, all-gather), written with pool-relative child
 //                        indices so that the received segments are traversable in place.  Every segment carries its
 //                        sender's needs for all receivers: every rank holds the same needs matrix and takes the same
-//                        decision on the next stride.
+//                        decision on the next stride — and on what every PAIR moves in the next exchange (x4_chunk of
+//                        what the pair needed: the slots are two thirds padding; bh_dd_x4_sizes).
 //
 // The stitched pool [local tree + body digests | two top trees | world x LET segment] is the same canonical octree a
 // single GPU builds; the unchanged force walk traverses it from a top-tree root.
